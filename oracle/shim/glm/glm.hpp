@@ -1,0 +1,136 @@
+// Minimal glm stand-in for building the reference hot path headless (TEST INFRASTRUCTURE ONLY).
+//
+// glm is a system dependency of the reference (source/layermap.h:25, Makefile:9) that is NOT
+// vendored under /root/reference and is not installed in this image. This header restates the
+// definitions of glm 0.9.9 for exactly the surface the hot path uses:
+//   normalize(v) = v * (T(1)/sqrt(dot(v,v)))      (glm/detail/func_geometric.inl, func_exponential.inl)
+//   dot: vec2 x+y, vec3 x+y+z (left to right), vec4 (x+y)+(z+w)
+//   cross(x,y) = (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y)
+//   mix(x,y,a:U) = vec<T>( vec<U>(x)*(U(1)-a) + vec<U>(y)*a )
+//   round -> std::round (C++11 STL path), floor -> std::floor, fract(x) = x - floor(x)
+// No reference test pins these semantics ("parity unpinned" at the glm boundary).
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <type_traits>
+
+namespace glm {
+
+typedef unsigned int uint;
+
+template <typename T> struct tvec2;
+template <typename T> struct tvec3;
+template <typename T> struct tvec4;
+
+template <typename T> struct tvec2 {
+  T x, y;
+  tvec2() : x(0), y(0) {}
+  template <typename S, typename = std::enable_if_t<std::is_arithmetic_v<S>>> tvec2(S s) : x(static_cast<T>(s)), y(static_cast<T>(s)) {}
+  template <typename A, typename B> tvec2(A a, B b) : x(static_cast<T>(a)), y(static_cast<T>(b)) {}
+  template <typename U> tvec2(const tvec2<U>& v) : x(static_cast<T>(v.x)), y(static_cast<T>(v.y)) {}
+  T& operator[](int i) { return (&x)[i]; }
+  const T& operator[](int i) const { return (&x)[i]; }
+  tvec2& operator+=(const tvec2& o) { x += o.x; y += o.y; return *this; }
+  tvec2& operator-=(const tvec2& o) { x -= o.x; y -= o.y; return *this; }
+};
+
+template <typename T> struct tvec3 {
+  T x, y, z;
+  tvec3() : x(0), y(0), z(0) {}
+  template <typename S, typename = std::enable_if_t<std::is_arithmetic_v<S>>> tvec3(S s) : x(static_cast<T>(s)), y(static_cast<T>(s)), z(static_cast<T>(s)) {}
+  template <typename A, typename B, typename C>
+  tvec3(A a, B b, C c) : x(static_cast<T>(a)), y(static_cast<T>(b)), z(static_cast<T>(c)) {}
+  template <typename U> tvec3(const tvec3<U>& v)
+      : x(static_cast<T>(v.x)), y(static_cast<T>(v.y)), z(static_cast<T>(v.z)) {}
+  template <typename U> explicit tvec3(const tvec4<U>& v);
+  T& operator[](int i) { return (&x)[i]; }
+  const T& operator[](int i) const { return (&x)[i]; }
+  tvec3& operator+=(const tvec3& o) { x += o.x; y += o.y; z += o.z; return *this; }
+  tvec3& operator-=(const tvec3& o) { x -= o.x; y -= o.y; z -= o.z; return *this; }
+};
+
+template <typename T> struct tvec4 {
+  T x, y, z, w;
+  tvec4() : x(0), y(0), z(0), w(0) {}
+  template <typename S, typename = std::enable_if_t<std::is_arithmetic_v<S>>> tvec4(S s)
+      : x(static_cast<T>(s)), y(static_cast<T>(s)), z(static_cast<T>(s)), w(static_cast<T>(s)) {}
+  template <typename A, typename B, typename C, typename D>
+  tvec4(A a, B b, C c, D d)
+      : x(static_cast<T>(a)), y(static_cast<T>(b)), z(static_cast<T>(c)), w(static_cast<T>(d)) {}
+  template <typename U> tvec4(const tvec4<U>& v)
+      : x(static_cast<T>(v.x)), y(static_cast<T>(v.y)), z(static_cast<T>(v.z)), w(static_cast<T>(v.w)) {}
+  T& operator[](int i) { return (&x)[i]; }
+  const T& operator[](int i) const { return (&x)[i]; }
+};
+
+template <typename T> template <typename U>
+tvec3<T>::tvec3(const tvec4<U>& v) : x(static_cast<T>(v.x)), y(static_cast<T>(v.y)), z(static_cast<T>(v.z)) {}
+
+typedef tvec2<float> vec2;
+typedef tvec3<float> vec3;
+typedef tvec4<float> vec4;
+typedef tvec2<int> ivec2;
+typedef tvec3<int> ivec3;
+typedef tvec2<bool> bvec2;
+typedef tvec2<double> dvec2;
+typedef tvec3<double> dvec3;
+typedef tvec4<double> dvec4;
+
+// ---- vec2 arithmetic (component-wise, same T) ----
+template <typename T> tvec2<T> operator+(const tvec2<T>& a, const tvec2<T>& b) { return tvec2<T>(a.x + b.x, a.y + b.y); }
+template <typename T> tvec2<T> operator-(const tvec2<T>& a, const tvec2<T>& b) { return tvec2<T>(a.x - b.x, a.y - b.y); }
+template <typename T> tvec2<T> operator*(const tvec2<T>& a, const tvec2<T>& b) { return tvec2<T>(a.x * b.x, a.y * b.y); }
+template <typename T> tvec2<T> operator/(const tvec2<T>& a, const tvec2<T>& b) { return tvec2<T>(a.x / b.x, a.y / b.y); }
+template <typename T> tvec2<T> operator+(const tvec2<T>& a, T s) { return tvec2<T>(a.x + s, a.y + s); }
+template <typename T> tvec2<T> operator-(const tvec2<T>& a, T s) { return tvec2<T>(a.x - s, a.y - s); }
+template <typename T> tvec2<T> operator*(const tvec2<T>& a, T s) { return tvec2<T>(a.x * s, a.y * s); }
+template <typename T> tvec2<T> operator/(const tvec2<T>& a, T s) { return tvec2<T>(a.x / s, a.y / s); }
+template <typename T> tvec2<T> operator*(T s, const tvec2<T>& a) { return tvec2<T>(s * a.x, s * a.y); }
+template <typename T> tvec2<T> operator-(const tvec2<T>& a) { return tvec2<T>(-a.x, -a.y); }
+template <typename T> bool operator==(const tvec2<T>& a, const tvec2<T>& b) { return a.x == b.x && a.y == b.y; }
+
+// ---- vec3 arithmetic ----
+template <typename T> tvec3<T> operator+(const tvec3<T>& a, const tvec3<T>& b) { return tvec3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename T> tvec3<T> operator-(const tvec3<T>& a, const tvec3<T>& b) { return tvec3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename T> tvec3<T> operator*(const tvec3<T>& a, const tvec3<T>& b) { return tvec3<T>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <typename T> tvec3<T> operator/(const tvec3<T>& a, const tvec3<T>& b) { return tvec3<T>(a.x / b.x, a.y / b.y, a.z / b.z); }
+template <typename T> tvec3<T> operator*(const tvec3<T>& a, T s) { return tvec3<T>(a.x * s, a.y * s, a.z * s); }
+template <typename T> tvec3<T> operator/(const tvec3<T>& a, T s) { return tvec3<T>(a.x / s, a.y / s, a.z / s); }
+template <typename T> tvec3<T> operator*(T s, const tvec3<T>& a) { return tvec3<T>(s * a.x, s * a.y, s * a.z); }
+template <typename T> tvec3<T> operator-(const tvec3<T>& a) { return tvec3<T>(-a.x, -a.y, -a.z); }
+
+// ---- vec4 arithmetic ----
+template <typename T> tvec4<T> operator+(const tvec4<T>& a, const tvec4<T>& b) { return tvec4<T>(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+template <typename T> tvec4<T> operator*(const tvec4<T>& a, T s) { return tvec4<T>(a.x * s, a.y * s, a.z * s, a.w * s); }
+template <typename T> tvec4<T> operator/(const tvec4<T>& a, T s) { return tvec4<T>(a.x / s, a.y / s, a.z / s, a.w / s); }
+
+// ---- common ----
+inline vec2 floor(const vec2& v) { return vec2(std::floor(v.x), std::floor(v.y)); }
+inline vec2 round(const vec2& v) { return vec2(std::round(v.x), std::round(v.y)); }
+inline vec2 fract(const vec2& v) { return v - floor(v); }
+
+template <typename T> T dot(const tvec2<T>& a, const tvec2<T>& b) { tvec2<T> t(a * b); return t.x + t.y; }
+template <typename T> T dot(const tvec3<T>& a, const tvec3<T>& b) { tvec3<T> t(a * b); return t.x + t.y + t.z; }
+template <typename T> T length(const tvec2<T>& v) { return std::sqrt(dot(v, v)); }
+template <typename T> T length(const tvec3<T>& v) { return std::sqrt(dot(v, v)); }
+template <typename T> tvec2<T> normalize(const tvec2<T>& v) { return v * (static_cast<T>(1) / std::sqrt(dot(v, v))); }
+template <typename T> tvec3<T> normalize(const tvec3<T>& v) { return v * (static_cast<T>(1) / std::sqrt(dot(v, v))); }
+template <typename T> tvec3<T> cross(const tvec3<T>& x, const tvec3<T>& y) {
+  return tvec3<T>(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+
+template <typename T, typename U> tvec2<T> mix(const tvec2<T>& x, const tvec2<T>& y, U a) {
+  return tvec2<T>(tvec2<U>(x) * (static_cast<U>(1) - a) + tvec2<U>(y) * a);
+}
+template <typename T, typename U> tvec3<T> mix(const tvec3<T>& x, const tvec3<T>& y, U a) {
+  return tvec3<T>(tvec3<U>(x) * (static_cast<U>(1) - a) + tvec3<U>(y) * a);
+}
+template <typename T, typename U> tvec4<T> mix(const tvec4<T>& x, const tvec4<T>& y, U a) {
+  return tvec4<T>(tvec4<U>(x) * (static_cast<U>(1) - a) + tvec4<U>(y) * a);
+}
+
+template <typename T> bvec2 greaterThanEqual(const tvec2<T>& a, const tvec2<T>& b) { return bvec2(a.x >= b.x, a.y >= b.y); }
+template <typename T> bvec2 lessThan(const tvec2<T>& a, const tvec2<T>& b) { return bvec2(a.x < b.x, a.y < b.y); }
+inline bool all(const bvec2& v) { return v.x && v.y; }
+
+}  // namespace glm
