@@ -1,0 +1,225 @@
+"""`.soil` parser -- host-side mirror of the reference's ``loadsoil`` (source/io.h:7-230).
+
+The soil table is an *input* of the hot path: the reference fills the global
+``soils`` / ``soilmap`` / ``layers`` tables and the WORLD globals from a text file, then the
+particles read them every step.  This module restates that parser, **including its quirks**
+(SURVEY.md Appendix D#9), so the POD tables handed to the C-ABI (``smx_set_soils``) are the same
+the reference would use:
+
+* one ``SurfParam`` value is reused for every ``SOIL`` block (io.h:35): keys a block does not set
+  are inherited from the previous block;
+* forward references (``TRANSPORTS X`` before ``SOIL X``) allocate the soil index at first mention
+  (io.h:125-152), so index order is first-mention order;
+* soil names are ``val[:find('{')-1]`` (io.h:74), values are parsed with ``stof``/``stoi``
+  semantics (leading number, trailing junk ignored);
+* index 0 is always "Air" (surface.h:41-57), which doubles as *water*.
+
+Pinned by tests/test_soilfile.py against tests/golden/soils_*.json, which were produced by the
+reference's own ``loadsoil`` (oracle/ref_driver.cpp ``--soils-out``).
+"""
+from __future__ import annotations
+
+import copy
+import re
+from dataclasses import dataclass, field, asdict
+from typing import Dict, List
+
+import numpy as np
+
+_NUM = re.compile(r"^\s*[-+]?(\d+\.?\d*([eE][-+]?\d+)?|\.\d+([eE][-+]?\d+)?)")
+_INT = re.compile(r"^\s*[-+]?\d+")
+
+
+def _stof(s: str) -> float:
+    m = _NUM.match(s)
+    if not m:
+        raise ValueError(f"stof: no conversion for {s!r}")
+    return float(np.float32(float(m.group(0))))
+
+
+def _stoi(s: str) -> int:
+    m = _INT.match(s)
+    if not m:
+        raise ValueError(f"stoi: no conversion for {s!r}")
+    return int(m.group(0))
+
+
+@dataclass
+class SurfParam:
+    """POD part of SurfParam (surface.h:11-39); colour / phong are render-only and dropped."""
+    name: str = ""
+    density: float = 0.0      # uninitialised in the reference (surface.h:15); never read on the hot path
+    porosity: float = 0.0
+    transports: int = 0
+    solubility: float = 1.0
+    equrate: float = 1.0
+    friction: float = 1.0
+    erodes: int = 0
+    erosionrate: float = 0.0
+    cascades: int = 0
+    maxdiff: float = 1.0
+    settling: float = 0.0
+    abrades: int = 0
+    suspension: float = 0.0
+    abrasion: float = 0.0
+
+
+@dataclass
+class SurfLayer:
+    """SurfLayer (surface.h:65-101)."""
+    type: int = 0
+    min: float = 0.0
+    bias: float = 0.0
+    scale: float = 1.0
+    octaves: float = 1.0
+    lacunarity: float = 1.0
+    gain: float = 0.0
+    frequency: float = 1.0
+
+
+@dataclass
+class SoilConfig:
+    soils: List[SurfParam] = field(default_factory=list)
+    soilmap: Dict[str, int] = field(default_factory=dict)
+    layers: List[SurfLayer] = field(default_factory=list)
+    # WORLD globals with the defaults of SoilMachine.cpp:9-14
+    SIZEX: int = 256
+    SIZEY: int = 256
+    SCALE: int = 80
+    NWIND: int = 250
+    NWATER: int = 250
+
+    def to_json(self) -> dict:
+        return {
+            "scale": self.SCALE, "sizex": self.SIZEX, "sizey": self.SIZEY,
+            "nwater": self.NWATER, "nwind": self.NWIND,
+            "soils": [asdict(s) for s in self.soils],
+            "layers": [asdict(l) for l in self.layers],
+        }
+
+
+def _air() -> SurfParam:
+    # surface.h:43-49
+    return SurfParam(name="Air", density=0.0, porosity=1.0, transports=0, solubility=0.0, equrate=0.0,
+                     friction=0.0, erodes=0, erosionrate=0.0, cascades=0, maxdiff=0.0, settling=0.0,
+                     abrades=0, suspension=0.0, abrasion=0.0)
+
+
+def loadsoil(path: str) -> SoilConfig:
+    """Restatement of loadsoil (io.h:7-230)."""
+    cfg = SoilConfig(soils=[_air()], soilmap={"Air": 0})
+    param = SurfParam()
+    is_open = False
+    soillayer = ""
+    with open(path, "r") as f:
+        text = f.read()
+    for linenr, line in enumerate(text.split("\n"), 1):
+        found = line.find("#")
+        if found != -1:
+            line = line[:found]
+        if line == "":
+            continue
+        if line == "}":
+            if not is_open:
+                raise SyntaxError(f"Incorrect Syntax in Line {linenr}")
+            if soillayer == "SOIL":
+                cfg.soils[cfg.soilmap[param.name]] = copy.copy(param)
+            is_open = False
+            continue
+        found = line.find(" ")
+        if found == -1:
+            raise SyntaxError(f"Incorrect Syntax in Line {linenr}")
+        tag, val = line[:found], line[found + 1:]
+
+        if tag in ("SOIL", "LAYER", "WORLD"):
+            b = val.find("{")
+            if b == -1:
+                raise SyntaxError(f"Incorrect Syntax in Line {linenr}")
+            if tag == "SOIL":
+                param.name = val[:b - 1] if b >= 1 else val[:0]
+                if param.name not in cfg.soilmap:
+                    cfg.soilmap[param.name] = len(cfg.soils)
+                    cfg.soils.append(copy.copy(param))
+            elif tag == "LAYER":
+                param.name = val[:b - 1] if b >= 1 else val[:0]
+                if param.name not in cfg.soilmap:
+                    raise SyntaxError(f"Can't find SOIL {param.name}")
+                cfg.layers.append(SurfLayer(type=cfg.soilmap[param.name]))
+            soillayer = tag
+            is_open = True
+            continue
+
+        if soillayer == "SOIL":
+            if tag in ("TRANSPORTS", "ERODES", "CASCADES", "ABRADES"):
+                if val not in cfg.soilmap:
+                    cfg.soilmap[val] = len(cfg.soils)
+                    cfg.soils.append(copy.copy(param))
+                setattr(param, tag.lower(), cfg.soilmap[val])
+            elif tag == "DENSITY":
+                param.density = _stof(val)
+            elif tag == "POROSITY":
+                param.porosity = _stof(val)
+            elif tag == "SOLUBILITY":
+                param.solubility = _stof(val)
+            elif tag == "EQUILIBRIUM":
+                param.equrate = _stof(val)
+            elif tag == "FRICTION":
+                param.friction = _stof(val)
+            elif tag == "EROSIONRATE":
+                param.erosionrate = _stof(val)
+            elif tag == "MAXDIFF":
+                param.maxdiff = _stof(val)
+            elif tag == "SETTLING":
+                param.settling = _stof(val)
+            elif tag == "SUSPENSION":
+                param.suspension = _stof(val)
+            elif tag == "ABRASION":
+                param.abrasion = _stof(val)
+        if soillayer == "LAYER":
+            lay = cfg.layers[-1]
+            if tag == "MIN":
+                lay.min = _stof(val)
+            elif tag == "BIAS":
+                lay.bias = _stof(val)
+            elif tag == "SCALE":
+                lay.scale = _stof(val)
+            elif tag == "OCTAVES":
+                lay.octaves = _stof(val)
+            elif tag == "LACUNARITY":
+                lay.lacunarity = _stof(val)
+            elif tag == "GAIN":
+                lay.gain = _stof(val)
+            elif tag == "FREQUENCY":
+                lay.frequency = _stof(val)
+        if soillayer == "WORLD":
+            if tag in ("SIZEX", "SIZEY", "SCALE", "NWIND", "NWATER"):
+                setattr(cfg, tag, _stoi(val))
+    return cfg
+
+
+SOIL_DTYPE = np.dtype([
+    ("transports", "<u4"), ("erodes", "<u4"), ("cascades", "<u4"), ("abrades", "<u4"),
+    ("density", "<f4"), ("porosity", "<f4"), ("solubility", "<f4"), ("equrate", "<f4"), ("friction", "<f4"),
+    ("erosionrate", "<f4"), ("maxdiff", "<f4"), ("settling", "<f4"), ("suspension", "<f4"), ("abrasion", "<f4"),
+])
+LAYER_DTYPE = np.dtype([
+    ("type", "<u4"), ("min", "<f4"), ("bias", "<f4"), ("scale", "<f4"), ("octaves", "<f4"),
+    ("lacunarity", "<f4"), ("gain", "<f4"), ("frequency", "<f4"),
+])
+
+
+def soils_array(cfg: SoilConfig) -> np.ndarray:
+    """POD soil table in the layout of ``smx_soil`` (include/soilmx.h)."""
+    a = np.zeros(len(cfg.soils), dtype=SOIL_DTYPE)
+    for i, s in enumerate(cfg.soils):
+        for k in SOIL_DTYPE.names:
+            a[i][k] = getattr(s, k)
+    return a
+
+
+def layers_array(cfg: SoilConfig) -> np.ndarray:
+    a = np.zeros(len(cfg.layers), dtype=LAYER_DTYPE)
+    for i, l in enumerate(cfg.layers):
+        for k in LAYER_DTYPE.names:
+            a[i][k] = getattr(l, k)
+    return a

@@ -1,0 +1,172 @@
+"""ctypes wrapper around oracle/libsoil_oracle.so and the oracle/_ref binaries (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import subprocess
+import numpy as np
+
+from soilmachine_amd.snapshot import Snapshot
+from soilmachine_amd.soilfile import SoilConfig, soils_array, layers_array
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libsoil_oracle.so")
+REF_BIN = os.path.join(ORACLE_DIR, "_ref", "soil_ref")
+REF_LEAN_BIN = os.path.join(ORACLE_DIR, "_ref", "soil_ref_lean")
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
+        "cascade_transfers", "wcascade_calls", "grid_active_cells", "rand_calls", "pool_free", "pool_overflow")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-f", os.path.join(ORACLE_DIR, "Makefile"), "oracle"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build_oracle()
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.so_create.restype = vp
+        L.so_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64]
+        L.so_destroy.argtypes = [vp]
+        L.so_set_soils.argtypes = [vp, vp, C.c_int]
+        L.so_set_scale.argtypes = [vp, C.c_int]
+        L.so_srand.argtypes = [vp, C.c_uint]
+        L.so_rand.argtypes = [vp]
+        L.so_rand.restype = C.c_int
+        L.so_initialize.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.so_import.argtypes = [vp] + [vp] * 8 + [C.c_uint64]
+        L.so_import.restype = C.c_int
+        L.so_num_sections.argtypes = [vp]
+        L.so_num_sections.restype = C.c_uint64
+        L.so_export.argtypes = [vp] + [vp] * 8
+        L.so_heights.argtypes = [vp, vp]
+        L.so_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        for f in ("so_water_particles", "so_wind_particles"):
+            getattr(L, f).argtypes = [vp, C.c_int]
+        for f in ("so_grid_pass", "so_map_frequency", "so_reset_frequency"):
+            getattr(L, f).argtypes = [vp]
+        L.so_get_counters.argtypes = [vp, C.POINTER(Counters)]
+        L.so_height.argtypes = [vp, C.c_int, C.c_int]
+        L.so_height.restype = C.c_double
+        L.so_height_bilinear.argtypes = [vp, C.c_float, C.c_float]
+        L.so_height_bilinear.restype = C.c_double
+        L.so_normal.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.so_surface.argtypes = [vp, C.c_int, C.c_int]
+        L.so_surface.restype = C.c_uint32
+        L.so_add.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_uint32]
+        L.so_remove.argtypes = [vp, C.c_int, C.c_int, C.c_double]
+        L.so_remove.restype = C.c_double
+        L.so_particle_cascade.argtypes = [vp, C.c_float, C.c_float, C.c_int]
+        L.so_water_cascade.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.so_seep.argtypes = [vp, C.c_int, C.c_int]
+        L.so_noise_fbm.argtypes = [C.c_float] * 3 + [C.c_int] + [C.c_float] * 3
+        L.so_noise_fbm.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    """The CPU restatement (oracle/soil_oracle.cpp) behind a small Python object."""
+
+    def __init__(self, cfg: SoilConfig, dimx: int, dimy: int, pool: int | None = None, seed: int = 0):
+        self.L = lib()
+        self.cfg, self.dimx, self.dimy = cfg, dimx, dimy
+        self.pool = int(pool if pool is not None else max(4 * dimx * dimy, 1 << 16))
+        self.h = self.L.so_create(dimx, dimy, cfg.SCALE, self.pool)
+        self._soils = soils_array(cfg)
+        self.L.so_set_soils(self.h, _p(self._soils), len(self._soils))
+        self.L.so_srand(self.h, seed)
+        self.seed = seed
+
+    def close(self):
+        if self.h:
+            self.L.so_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def initialize(self, seed: int | None = None):
+        lay = layers_array(self.cfg)
+        self.L.so_initialize(self.h, self.seed if seed is None else seed, _p(lay), len(lay))
+
+    def load(self, s: Snapshot):
+        rc = self.L.so_import(self.h, _p(s.count), _p(s.type), _p(s.size), _p(s.floor), _p(s.sat),
+                              _p(s.wfreq), _p(s.wtrack), _p(s.windfreq), s.rand_calls)
+        if rc != 0:
+            raise RuntimeError("oracle pool exhausted on import")
+
+    def snapshot(self) -> Snapshot:
+        nc = self.dimx * self.dimy
+        ns = int(self.L.so_num_sections(self.h))
+        count = np.zeros(nc, np.uint32); ty = np.zeros(ns, np.uint32)
+        size = np.zeros(ns); floor = np.zeros(ns); sat = np.zeros(ns)
+        wf = np.zeros(nc, np.float32); wt = np.zeros(nc, np.float32); wi = np.zeros(nc, np.float32)
+        self.L.so_export(self.h, _p(count), _p(ty), _p(size), _p(floor), _p(sat), _p(wf), _p(wt), _p(wi))
+        c = self.counters()
+        return Snapshot(self.dimx, self.dimy, self.cfg.SCALE, len(self.cfg.soils), c["rand_calls"], c["pool_free"],
+                        count, ty, size, floor, sat, wf, wt, wi)
+
+    def tick(self, nwater: int, nwind: int, dowater: bool = True, dowind: bool = True):
+        self.L.so_tick(self.h, nwater, nwind, int(dowater), int(dowind))
+
+    def counters(self) -> dict:
+        c = Counters()
+        self.L.so_get_counters(self.h, C.byref(c))
+        return c.as_dict()
+
+    def heights(self) -> np.ndarray:
+        out = np.zeros(self.dimx * self.dimy)
+        self.L.so_heights(self.h, _p(out))
+        return out
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_BIN)
+
+
+def run_ref(soil: str, seed: int = 0, size: int = 0, ticks: int = 1, nwater: int = -1, nwind: int = -1,
+            water: bool = True, wind: bool = True, pool: int | None = None, dump_prefix: str | None = None,
+            dump_at=(), soils_out: str | None = None, lean: bool = False, timeout: float | None = None) -> dict:
+    """Run oracle/_ref/soil_ref (the reference's own headers, compiled headless) and return its JSON line."""
+    cmd = [REF_LEAN_BIN if lean else REF_BIN, "--soil", soil, "--seed", str(seed), "--ticks", str(ticks),
+           "--water", str(int(water)), "--wind", str(int(wind))]
+    if size:
+        cmd += ["--size", str(size)]
+    if nwater >= 0:
+        cmd += ["--nwater", str(nwater)]
+    if nwind >= 0:
+        cmd += ["--nwind", str(nwind)]
+    if pool:
+        cmd += ["--pool", str(pool)]
+    if dump_prefix:
+        cmd += ["--dump-prefix", dump_prefix, "--dump-at", ",".join(str(t) for t in dump_at)]
+    if soils_out:
+        cmd += ["--soils-out", soils_out]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=timeout).stdout
+    for line in out.splitlines():
+        if line.startswith("JSON "):
+            return json.loads(line[5:])
+    raise RuntimeError("soil_ref produced no JSON line:\n" + out)
