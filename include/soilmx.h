@@ -1,0 +1,132 @@
+/* soilmx -- C-ABI of the MI355X-native SoilMachine particle-transport hot path.
+ *
+ * The reference (weigert/SoilMachine) has no FFI layer: its boundary is a source-level C++ header API
+ * consumed by one translation unit (SoilMachine.cpp:19-28). This header is the seam a maintainer would
+ * bind instead: every entry point names the reference interface it replaces (paths relative to the
+ * reference root). Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * Conventions: all functions return 0 on success, <0 on error (smx_last_error() gives the text);
+ * the caller is single-threaded per context (as the reference is, SURVEY.md §8b "Threading");
+ * buffers are caller-allocated; "cell order" is the Layermap index x*dimy + y (source/layermap.h:151),
+ * "frequency order" is y*dimx + x (source/particle/water.h:53,349).
+ *
+ * Exactness contract: smx_tick* executes the reference's sequential semantics (SoilMachine.cpp:283-329)
+ * -- results are bit-identical to the reference CPU path for the same soil table, terrain, SCALE and
+ * libc rand() stream, whichever execution engine (SMX_ENGINE_*) runs them.
+ */
+#ifndef SOILMX_H
+#define SOILMX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smx_ctx smx_ctx;
+
+/* POD mirror of SurfParam (source/surface.h:11-39); render-only fields (name, color, phong) dropped. */
+typedef struct smx_soil {
+  uint32_t transports, erodes, cascades, abrades;
+  float density, porosity, solubility, equrate, friction, erosionrate, maxdiff, settling, suspension, abrasion;
+} smx_soil;
+
+/* POD mirror of SurfLayer (source/surface.h:65-101). */
+typedef struct smx_layer {
+  uint32_t type;
+  float min, bias, scale, octaves, lacunarity, gain, frequency;
+} smx_layer;
+
+enum { SMX_ENGINE_SERIAL = 0,      /* one device walker, reference order (parity anchor)            */
+       SMX_ENGINE_SPECULATIVE = 1  /* optimistic parallel particles, ordered commit, same results    */ };
+
+typedef struct smx_config {
+  int32_t dimx, dimy;              /* SIZEX, SIZEY (SoilMachine.cpp:9-10)                            */
+  int32_t scale;                   /* SCALE (SoilMachine.cpp:11)                                     */
+  int32_t device;                  /* HIP device ordinal                                             */
+  uint64_t pool_capacity;          /* POOLSIZE (SoilMachine.cpp:16): max live sections               */
+  int32_t engine;                  /* SMX_ENGINE_*                                                   */
+  int32_t reserved;
+} smx_config;
+
+typedef struct smx_counters {
+  uint64_t steps_water_top;        /* WaterParticle::move()==true for top-level particles            */
+  uint64_t steps_water_all;        /* ... including nested particles (water.h:251-262)               */
+  uint64_t steps_wind;
+  uint64_t nested_particles;
+  uint64_t floods;
+  uint64_t cascade_calls;          /* Particle::cascade (particle.h:24)                              */
+  uint64_t cascade_transfers;
+  uint64_t wcascade_calls;         /* WaterParticle::cascade (water.h:151)                           */
+  uint64_t grid_active_cells;      /* cells the exact grid pass had to visit                         */
+  uint64_t rand_calls;             /* rand() draws consumed since smx_srand                          */
+  uint64_t pool_free;              /* == map.pool.free.size() (layermap.h:69, SoilMachine.cpp:116)   */
+  uint64_t pool_overflow;          /* pool.get() on an empty pool (layermap.h:92-95)                 */
+  uint64_t spec_rounds;            /* speculative engine: execution rounds                           */
+  uint64_t spec_aborts;            /* speculative engine: particle executions thrown away            */
+  uint64_t reserved[2];
+} smx_counters;
+
+/* Elapsed device time of the phases of the last smx_tick* calls, measured with HIP events on the
+ * context's stream (milliseconds, accumulated since smx_timing_reset). */
+typedef struct smx_timing {
+  double ms_water, ms_grid, ms_wind, ms_freq;
+  uint64_t launches_water, launches_grid, launches_wind, launches_freq;
+} smx_timing;
+
+/* ---- life cycle: replaces Layermap::Layermap + secpool::reserve (layermap.h:64-119,218-226) ---- */
+int smx_create(const smx_config* cfg, smx_ctx** out);
+void smx_destroy(smx_ctx* ctx);
+const char* smx_last_error(smx_ctx* ctx);
+
+/* ---- tables: replaces the globals soils[] / SCALE read by every particle (surface.h:41, SoilMachine.cpp:11) ---- */
+int smx_set_soils(smx_ctx* ctx, const smx_soil* soils, int32_t n);
+int smx_set_scale(smx_ctx* ctx, int32_t scale);
+
+/* ---- libc rand() stream hand-off: replaces srand(SEED)/rand() (SoilMachine.cpp:41, water.h:13, wind.h:15) ---- */
+int smx_srand(smx_ctx* ctx, uint32_t seed);
+int smx_rand(smx_ctx* ctx, int32_t* out);               /* draw one value on behalf of the host */
+int smx_rand_advance(smx_ctx* ctx, uint64_t ndraws);    /* discard ndraws values (resume a stream at a known offset) */
+
+/* ---- terrain: replaces Layermap::initialize + SurfLayer::get + FastNoiseLite (layermap.h:163-216, surface.h:82-99) ---- */
+int smx_initialize(smx_ctx* ctx, int32_t seed, const smx_layer* layers, int32_t nlayers);
+
+/* ---- state hand-over (snapshot layout, columns bottom->top in cell order); replaces direct access to
+ *      Layermap::dat / sec lists (layermap.h:37-62,131) and WaterParticle/WindParticle::frequency,track ---- */
+int smx_import_columns(smx_ctx* ctx, const uint32_t* count, const uint32_t* type, const double* size,
+                       const double* floor, const double* sat);
+int smx_import_frequency(smx_ctx* ctx, const float* wfreq, const float* wtrack, const float* windfreq);
+int smx_num_sections(smx_ctx* ctx, uint64_t* out);
+int smx_export_columns(smx_ctx* ctx, uint32_t* count, uint32_t* type, double* size, double* floor, double* sat);
+int smx_read_frequency(smx_ctx* ctx, float* wfreq, float* wtrack, float* windfreq);   /* NULL = skip */
+int smx_read_heights(smx_ctx* ctx, double* out);        /* Layermap::height(ivec2) for every cell (layermap.h:422) */
+int smx_read_surface(smx_ctx* ctx, uint32_t* out);      /* Layermap::surface(ivec2) for every cell (layermap.h:417) */
+
+/* ---- the hot path, phase by phase: replaces SoilMachine.cpp:287-320 ---- */
+int smx_tick_water(smx_ctx* ctx, int32_t nwater);       /* :287-298  NWATER x {WaterParticle ctor; move/interact; flood} */
+int smx_grid_pass(smx_ctx* ctx);                        /* :300-301  WaterParticle::seep(map) (water.h:335-343)          */
+int smx_tick_wind(smx_ctx* ctx, int32_t nwind);         /* :303-307  NWIND x {WindParticle ctor; move/interact}          */
+int smx_map_frequency(smx_ctx* ctx);                    /* :314      WaterParticle::mapfrequency (water.h:358-365)       */
+int smx_reset_frequency(smx_ctx* ctx);                  /* :319      WaterParticle::resetfrequency (water.h:353-356)     */
+int smx_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater, int32_t dowind);   /* all of the above, in order */
+int smx_sync(smx_ctx* ctx);                             /* wait for all queued device work */
+
+/* ---- point operations for API fidelity (Layermap::add/remove, Particle::cascade, ... called by host code) ---- */
+int smx_add(smx_ctx* ctx, int32_t x, int32_t y, double size, uint32_t type);            /* layermap.h:230 */
+int smx_remove(smx_ctx* ctx, int32_t x, int32_t y, double h, double* remainder);        /* layermap.h:310 */
+int smx_particle_cascade(smx_ctx* ctx, float px, float py, int32_t transferloop);       /* particle.h:24  */
+int smx_water_cascade(smx_ctx* ctx, int32_t x, int32_t y, int32_t spill);               /* water.h:151    */
+int smx_seep(smx_ctx* ctx, int32_t x, int32_t y);                                       /* water.h:285    */
+int smx_normals(smx_ctx* ctx, float* out3);             /* Layermap::normal(ivec2) for every cell, xyz interleaved (layermap.h:341) */
+int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out);      /* Layermap::height(vec2) (layermap.h:427) */
+
+/* ---- observability ---- */
+int smx_get_counters(smx_ctx* ctx, smx_counters* out);
+int smx_get_timing(smx_ctx* ctx, smx_timing* out);
+int smx_timing_reset(smx_ctx* ctx);
+int smx_set_engine(smx_ctx* ctx, int32_t engine);
+void* smx_stream(smx_ctx* ctx);                          /* the hipStream_t all work is queued on */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOILMX_H */

@@ -95,12 +95,14 @@ static double now_s() {
 
 int main(int argc, char** argv) {
   std::string soil = "soil/default.soil", dump_prefix, dump_at, soils_out;
-  int size = 0, ticks = 1, nwater = -1, nwind = -1, dowater = 1, dowind = 1, quiet = 1;
+  int size = 0, sizex = 0, sizey = 0, ticks = 1, nwater = -1, nwind = -1, dowater = 1, dowind = 1, quiet = 1;
   for (int i = 1; i + 1 < argc; i += 2) {
     std::string k = argv[i], v = argv[i + 1];
     if (k == "--soil") soil = v;
     else if (k == "--seed") SEED = atoi(v.c_str());
     else if (k == "--size") size = atoi(v.c_str());
+    else if (k == "--sizex") sizex = atoi(v.c_str());
+    else if (k == "--sizey") sizey = atoi(v.c_str());
     else if (k == "--ticks") ticks = atoi(v.c_str());
     else if (k == "--nwater") nwater = atoi(v.c_str());
     else if (k == "--nwind") nwind = atoi(v.c_str());
@@ -122,7 +124,9 @@ int main(int argc, char** argv) {
 
   srand(SEED);                       // SoilMachine.cpp:41
   loadsoil(soil);                    // SoilMachine.cpp:43-45 (overwrites SIZEX/SIZEY/SCALE/NWIND/NWATER)
-  if (size > 0) { SIZEX = size; SIZEY = size; }   // forced map size (SURVEY.md §5 "Config")
+  if (size > 0) { SIZEX = size; SIZEY = size; }
+  if (sizex > 0) SIZEX = sizex;
+  if (sizey > 0) SIZEY = sizey;   // forced map size (SURVEY.md §5 "Config")
   if (nwater >= 0) NWATER = nwater;
   if (nwind >= 0) NWIND = nwind;
   SLICE = 2 * SCALE;

@@ -1,0 +1,111 @@
+"""ctypes binding of the C-ABI in include/soilmx.h (libsoilmx.so, hand-written HIP for gfx950).
+
+There is NO CPU fallback: importing the library without a built ``libsoilmx.so`` raises, and creating a
+context without a visible HIP device fails with the library's own error text.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsoilmx.so")
+
+ENGINE_SERIAL = 0
+ENGINE_SPECULATIVE = 1
+
+
+class Config(C.Structure):
+    _fields_ = [("dimx", C.c_int32), ("dimy", C.c_int32), ("scale", C.c_int32), ("device", C.c_int32),
+                ("pool_capacity", C.c_uint64), ("engine", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
+        "cascade_transfers", "wcascade_calls", "grid_active_cells", "rand_calls", "pool_free", "pool_overflow",
+        "spec_rounds", "spec_aborts")] + [("reserved", C.c_uint64 * 2)]
+
+    def as_dict(self) -> dict:
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms_water", C.c_double), ("ms_grid", C.c_double), ("ms_wind", C.c_double), ("ms_freq", C.c_double),
+                ("launches_water", C.c_uint64), ("launches_grid", C.c_uint64), ("launches_wind", C.c_uint64),
+                ("launches_freq", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/soilmx.h declares (tests/test_capi_symbols.py checks the library exports them all)
+SYMBOLS = [
+    "smx_create", "smx_destroy", "smx_last_error", "smx_set_soils", "smx_set_scale", "smx_srand", "smx_rand", "smx_rand_advance",
+    "smx_initialize", "smx_import_columns", "smx_import_frequency", "smx_num_sections", "smx_export_columns",
+    "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
+    "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
+    "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_normals", "smx_heights_bilinear",
+    "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libsoilmx.so and declare the prototypes. Fails loudly if the HIP library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build the HIP extension first "
+                           f"(python -c 'import __graft_entry__ as g; g.build()'); soilmx has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64, dbl, flt = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_double, C.c_float
+    L.smx_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.smx_destroy.argtypes = [vp]; L.smx_destroy.restype = None
+    L.smx_last_error.argtypes = [vp]; L.smx_last_error.restype = C.c_char_p
+    L.smx_set_soils.argtypes = [vp, vp, i32]
+    L.smx_set_scale.argtypes = [vp, i32]
+    L.smx_srand.argtypes = [vp, u32]
+    L.smx_rand.argtypes = [vp, C.POINTER(i32)]
+    L.smx_rand_advance.argtypes = [vp, u64]
+    L.smx_initialize.argtypes = [vp, i32, vp, i32]
+    L.smx_import_columns.argtypes = [vp] + [vp] * 5
+    L.smx_import_frequency.argtypes = [vp] + [vp] * 3
+    L.smx_num_sections.argtypes = [vp, C.POINTER(u64)]
+    L.smx_export_columns.argtypes = [vp] + [vp] * 5
+    L.smx_read_frequency.argtypes = [vp] + [vp] * 3
+    L.smx_read_heights.argtypes = [vp, vp]
+    L.smx_read_surface.argtypes = [vp, vp]
+    L.smx_tick_water.argtypes = [vp, i32]
+    L.smx_grid_pass.argtypes = [vp]
+    L.smx_tick_wind.argtypes = [vp, i32]
+    L.smx_map_frequency.argtypes = [vp]
+    L.smx_reset_frequency.argtypes = [vp]
+    L.smx_tick.argtypes = [vp, i32, i32, i32, i32]
+    L.smx_sync.argtypes = [vp]
+    L.smx_add.argtypes = [vp, i32, i32, dbl, u32]
+    L.smx_remove.argtypes = [vp, i32, i32, dbl, C.POINTER(dbl)]
+    L.smx_particle_cascade.argtypes = [vp, flt, flt, i32]
+    L.smx_water_cascade.argtypes = [vp, i32, i32, i32]
+    L.smx_seep.argtypes = [vp, i32, i32]
+    L.smx_normals.argtypes = [vp, vp]
+    L.smx_heights_bilinear.argtypes = [vp, vp, i32, vp]
+    L.smx_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.smx_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.smx_timing_reset.argtypes = [vp]
+    L.smx_set_engine.argtypes = [vp, i32]
+    L.smx_stream.argtypes = [vp]; L.smx_stream.restype = vp
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("smx_destroy", "smx_last_error", "smx_stream"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

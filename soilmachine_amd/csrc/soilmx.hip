@@ -1,0 +1,653 @@
+// soilmx.hip -- HIP kernels (gfx950) and the C-ABI of include/soilmx.h.
+//
+// Kernels (DESIGN.md "Kernels"):
+//   k_water_serial / k_wind_serial   exact engine: ONE lane walks the particles in reference order
+//                                    (SoilMachine.cpp:287-298,303-307) -- the parity anchor
+//   k_grid_classify                  O(cells), HBM-streaming: which cells can the grid pass change at all?
+//                                    (water.h:285-343 is a provable no-op unless a water top is within the
+//                                    3x3 neighbourhood or the column holds a non-zero saturation)
+//   k_grid_serial                    exact walk over the (dynamic) active set in the reference's x-major order
+//   k_map_frequency / k_reset_frequency   water.h:353-365, float4-vectorised streaming kernels
+//   k_init_terrain                   Layermap::initialize (layermap.h:163-216): FBm OpenSimplex2 per cell + column build
+//   k_heights / k_surface / k_normals / k_bilinear   whole-map read-side primitives (layermap.h:341-439)
+//
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/soilmx.h"
+#include "soil_core.h"
+#include "soil_noise.h"
+
+using namespace smx;
+
+static_assert(sizeof(SoilP) == sizeof(smx_soil), "smx_soil layout");
+static_assert(sizeof(Sec) == 32, "Sec must be 32 bytes");
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_water_serial(DevState s, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Sim sim(s);
+  for (int i = 0; i < n; i++) {
+    Water p;
+    sim.water_ctor(p);
+    sim.water_run(p, true);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_wind_serial(DevState s, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Sim sim(s);
+  for (int i = 0; i < n; i++) {
+    Wind p;
+    sim.wind_ctor(p);
+    sim.wind_run(p);
+  }
+}
+
+// One thread per cell, 256 consecutive cells (cell order) per block = 4 level-0 bitmap words.
+__global__ void __launch_bounds__(256) k_grid_classify(DevState s) {
+  const size_t n = (size_t)s.dimx * s.dimy;
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  bool act = false;
+  if (c < n) {
+    const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
+    uint8_t f = s.flags[c];
+    act = (f & F_SAT) != 0;
+    uint8_t any = f;
+    const bool xm = x > 0, xp = x < s.dimx - 1, ym = y > 0, yp = y < s.dimy - 1;
+    if (ym) any |= s.flags[c - 1];
+    if (yp) any |= s.flags[c + 1];
+    if (xm) { any |= s.flags[c - s.dimy]; if (ym) any |= s.flags[c - s.dimy - 1]; if (yp) any |= s.flags[c - s.dimy + 1]; }
+    if (xp) { any |= s.flags[c + s.dimy]; if (ym) any |= s.flags[c + s.dimy - 1]; if (yp) any |= s.flags[c + s.dimy + 1]; }
+    act = act || (any & F_AIR);
+  }
+  const unsigned long long m = __ballot(act);
+  if ((threadIdx.x & 63) == 0 && c < n) {
+    const size_t w0 = c >> 6;
+    s.active[w0] = m;
+    if (m) {
+      atomicOr(&s.active1[w0 >> 6], 1ull << (w0 & 63));
+      atomicOr(&s.active2[w0 >> 12], 1ull << ((w0 >> 6) & 63));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) k_grid_serial(DevState s) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Sim sim(s);
+  sim.grid_mode = true;
+  const size_t n = (size_t)s.dimx * s.dimy;
+  size_t c = sim.next_active(0);
+  unsigned long long visited = 0;
+  while (c < n) {
+    const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
+    sim.seep(x, y);                          // water.h:339
+    sim.water_cascade(x, y, 3);              // water.h:340
+    visited++;
+    c = sim.next_active(c + 1);
+  }
+  // every non-active cell still "calls" WaterParticle::cascade once in the reference (counter parity)
+  s.ctr[C_WCASCADE_CALLS] += n - visited;
+  s.ctr[C_GRID_ACTIVE] += visited;
+}
+
+__global__ void __launch_bounds__(256) k_map_frequency(float* __restrict__ freq, const float* __restrict__ track, size_t n4, size_t n) {
+  const float lrate = 0.01f, K = 50.0f;      // water.h:359-360
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = i; k < n4; k += stride) {
+    float4 f = reinterpret_cast<float4*>(freq)[k];
+    const float4 t = reinterpret_cast<const float4*>(track)[k];
+    f.x = (1.0f - lrate) * f.x + lrate * K * t.x / (1.0f + K * t.x);
+    f.y = (1.0f - lrate) * f.y + lrate * K * t.y / (1.0f + K * t.y);
+    f.z = (1.0f - lrate) * f.z + lrate * K * t.z / (1.0f + K * t.z);
+    f.w = (1.0f - lrate) * f.w + lrate * K * t.w / (1.0f + K * t.w);
+    reinterpret_cast<float4*>(freq)[k] = f;
+  }
+  for (size_t k = n4 * 4 + i; k < n; k += stride)
+    freq[k] = (1.0f - lrate) * freq[k] + lrate * K * track[k] / (1.0f + K * track[k]);
+}
+
+// Layermap::initialize (layermap.h:163-216). One thread per cell builds its whole column: the layers are
+// added in file order with the rules of Layermap::add (merge same type, water swap, push). Pool nodes for
+// buried sections come from an atomic bump on the free stack (node identity is unobservable).
+struct LayerDev { uint32_t type; float min, bias, scale; NoiseCfg noise; float z; };
+constexpr int MAX_LAYERS = 16;
+struct LayersDev { int n; LayerDev l[MAX_LAYERS]; };
+
+__global__ void __launch_bounds__(256) k_init_terrain(DevState s, LayersDev L) {
+  const size_t n = (size_t)s.dimx * s.dimy;
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  const int i = (int)(c / s.dimy), j = (int)(c % s.dimy);
+  double csize[MAX_LAYERS]; uint32_t ctype[MAX_LAYERS];
+  int ns = 0;
+  const float px = (float)i / (float)s.dimx, py = (float)j / (float)s.dimy;
+  for (int l = 0; l < L.n; l++) {
+    float val = L.l[l].bias + L.l[l].scale * noise_fbm(L.l[l].noise, px, py, L.l[l].z);   // SurfLayer::get surface.h:95-99
+    if (val < L.l[l].min) val = L.l[l].min;
+    const double h = val;
+    const uint32_t t = L.l[l].type;
+    if (h <= 0) continue;                                        // layermap.h:237-240
+    if (ns == 0) { csize[0] = h; ctype[0] = t; ns = 1; continue; }
+    if (ctype[ns - 1] == t) { csize[ns - 1] += h; continue; }    // :249-253
+    if (ctype[ns - 1] == AIR) {                                  // :258-275 water swap
+      const double wsize = csize[ns - 1];
+      ns--;
+      if (ns > 0 && ctype[ns - 1] == t) csize[ns - 1] += h;
+      else { csize[ns] = h; ctype[ns] = t; ns++; }
+      csize[ns] = wsize; ctype[ns] = AIR; ns++;
+      continue;
+    }
+    csize[ns] = h; ctype[ns] = t; ns++;
+  }
+  Sec cell;
+  cell.size = 0.0; cell.floor = 0.0; cell.sat = 0.0; cell.type = EMPTY; cell.prev = NIL;
+  uint8_t flag = 0;
+  if (ns > 0) {
+    uint32_t base = 0;
+    if (ns > 1) base = atomicSub(s.free_count, (uint32_t)(ns - 1));   // old count: our nodes are freelist[base-ns+1 .. base-1]
+    double fl = 0.0;
+    uint32_t pv = NIL;
+    for (int k = 0; k < ns; k++) {
+      Sec r; r.size = csize[k]; r.floor = fl; r.sat = 0.0; r.type = ctype[k]; r.prev = pv;
+      if (k == ns - 1) cell = r;
+      else { const uint32_t nd = s.freelist[base - 1 - k]; s.pool[nd] = r; pv = nd; }
+      fl = r.floor + r.size;                                     // E->floor = height(pos) (:304)
+    }
+    if (cell.type == AIR) flag |= F_AIR;
+    atomicAdd(&s.ctr[C_LIVE_SECTIONS], (unsigned long long)ns);
+  }
+  s.cells[c] = cell;
+  s.flags[c] = flag;
+}
+
+__global__ void __launch_bounds__(256) k_heights(DevState s, double* __restrict__ out) {
+  const size_t n = (size_t)s.dimx * s.dimy;
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < n) out[c] = s.cells[c].floor + s.cells[c].size;
+}
+__global__ void __launch_bounds__(256) k_surface(DevState s, uint32_t* __restrict__ out) {
+  const size_t n = (size_t)s.dimx * s.dimy;
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < n) { uint32_t t = s.cells[c].type; out[c] = (t == EMPTY) ? 0u : t; }
+}
+__global__ void __launch_bounds__(256) k_normals(DevState s, float* __restrict__ out) {
+  const size_t n = (size_t)s.dimx * s.dimy;
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  Sim sim(s);
+  f3 v = sim.normal((int)(c / s.dimy), (int)(c % s.dimy));
+  out[3 * c] = v.x; out[3 * c + 1] = v.y; out[3 * c + 2] = v.z;
+}
+__global__ void __launch_bounds__(256) k_bilinear(DevState s, const float* __restrict__ pos, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Sim sim(s);
+  out[i] = sim.height_bilinear(f2{pos[2 * i], pos[2 * i + 1]});
+}
+
+// single-operation kernels behind the point API (host-driven Layermap::add/remove etc.)
+struct PointOp { int op; int x, y; double a; uint32_t type; float px, py; int k; };
+__global__ void __launch_bounds__(64) k_point_op(DevState s, PointOp o, double* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Sim sim(s);
+  switch (o.op) {
+    case 0: sim.add(o.x, o.y, o.a, o.type); break;
+    case 1: *out = sim.remove(o.x, o.y, o.a); break;
+    case 2: sim.particle_cascade(f2{o.px, o.py}, o.k); break;
+    case 3: sim.water_cascade(o.x, o.y, o.k); break;
+    case 4: sim.seep(o.x, o.y); break;
+    case 5: *out = (double)sim.rand_(); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct EvPair { hipEvent_t a, b; int phase; };
+
+struct smx_ctx {
+  smx_config cfg;
+  DevState d;
+  hipStream_t stream = nullptr;
+  std::string err;
+  size_t ncells = 0, nw0 = 0, nw1 = 0, nw2 = 0;
+  SoilP* d_soils = nullptr;
+  int nsoils = 0;
+  double* d_scratch = nullptr;        // 1 double for point ops
+  std::vector<EvPair> pending;
+  std::vector<hipEvent_t> evpool;
+  smx_timing timing{};
+  uint64_t spec_rounds = 0, spec_aborts = 0;
+};
+
+#define HIPCHK(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                   \
+      return -1;                                                                                      \
+    }                                                                                                 \
+  } while (0)
+
+static hipEvent_t ev_get(smx_ctx* ctx) {
+  if (!ctx->evpool.empty()) { hipEvent_t e = ctx->evpool.back(); ctx->evpool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+static void drain_events(smx_ctx* ctx) {
+  for (EvPair& p : ctx->pending) {
+    hipEventSynchronize(p.b);
+    float ms = 0; hipEventElapsedTime(&ms, p.a, p.b);
+    switch (p.phase) {
+      case 0: ctx->timing.ms_water += ms; ctx->timing.launches_water++; break;
+      case 1: ctx->timing.ms_grid += ms; ctx->timing.launches_grid++; break;
+      case 2: ctx->timing.ms_wind += ms; ctx->timing.launches_wind++; break;
+      default: ctx->timing.ms_freq += ms; ctx->timing.launches_freq++; break;
+    }
+    ctx->evpool.push_back(p.a); ctx->evpool.push_back(p.b);
+  }
+  ctx->pending.clear();
+}
+struct PhaseTimer {
+  smx_ctx* ctx; EvPair p;
+  PhaseTimer(smx_ctx* c, int phase) : ctx(c) { p.a = ev_get(c); p.b = ev_get(c); p.phase = phase; hipEventRecord(p.a, c->stream); }
+  ~PhaseTimer() { hipEventRecord(p.b, ctx->stream); ctx->pending.push_back(p); if (ctx->pending.size() > 512) drain_events(ctx); }
+};
+
+static int reset_pool(smx_ctx* ctx) {
+  // free stack holds every node index; cells empty; counters zero
+  const uint64_t cap = ctx->cfg.pool_capacity;
+  std::vector<uint32_t> fl(cap);
+  for (uint64_t i = 0; i < cap; i++) fl[i] = (uint32_t)(cap - 1 - i);
+  HIPCHK(hipMemcpyAsync(ctx->d.freelist, fl.data(), cap * 4, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t fc = (uint32_t)cap;
+  HIPCHK(hipMemcpyAsync(ctx->d.free_count, &fc, 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" {
+
+const char* smx_last_error(smx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int smx_create(const smx_config* cfg, smx_ctx** out) {
+  if (!cfg || !out || cfg->dimx <= 0 || cfg->dimy <= 0 || cfg->pool_capacity == 0 || cfg->pool_capacity >= 0xFFFFFFFFull) return -2;
+  smx_ctx* ctx = new smx_ctx();
+  ctx->cfg = *cfg;
+  *out = ctx;   // handed out even on failure so the caller can read smx_last_error(); smx_destroy() is safe
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { ctx->err = "no HIP device visible (the soilmx product path has no CPU fallback)"; return -3; }
+  HIPCHK(hipSetDevice(cfg->device));
+  HIPCHK(hipStreamCreate(&ctx->stream));
+  hipDeviceSetLimit(hipLimitStackSize, 16384);   // recursion depth of cascade<->nested particles is bounded by spill (water.h:34)
+  const size_t n = (size_t)cfg->dimx * cfg->dimy;
+  ctx->ncells = n;
+  ctx->nw0 = (n + 63) >> 6; ctx->nw1 = (ctx->nw0 + 63) >> 6; ctx->nw2 = (ctx->nw1 + 63) >> 6;
+  DevState& d = ctx->d;
+  memset(&d, 0, sizeof(d));
+  d.dimx = cfg->dimx; d.dimy = cfg->dimy; d.scale = cfg->scale; d.pool_capacity = cfg->pool_capacity;
+  HIPCHK(hipMalloc(&d.cells, n * sizeof(Sec)));
+  HIPCHK(hipMalloc(&d.pool, cfg->pool_capacity * sizeof(Sec)));
+  HIPCHK(hipMalloc(&d.freelist, cfg->pool_capacity * 4));
+  HIPCHK(hipMalloc(&d.free_count, 64));
+  HIPCHK(hipMalloc(&d.flags, n));
+  HIPCHK(hipMalloc(&d.wfreq, n * 4)); HIPCHK(hipMalloc(&d.wtrack, n * 4)); HIPCHK(hipMalloc(&d.windfreq, n * 4));
+  HIPCHK(hipMalloc(&d.rnd, sizeof(RandState)));
+  HIPCHK(hipMalloc(&d.ctr, C_COUNT * 8));
+  HIPCHK(hipMalloc(&d.active, (ctx->nw0 + 64) * 8)); HIPCHK(hipMalloc(&d.active1, (ctx->nw1 + 64) * 8)); HIPCHK(hipMalloc(&d.active2, (ctx->nw2 + 64) * 8));
+  HIPCHK(hipMalloc(&ctx->d_scratch, 64));
+  HIPCHK(hipMalloc(&ctx->d_soils, 256 * sizeof(SoilP)));
+  d.soils = ctx->d_soils;
+  HIPCHK(hipMemsetAsync(d.wfreq, 0, n * 4, ctx->stream)); HIPCHK(hipMemsetAsync(d.wtrack, 0, n * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(d.windfreq, 0, n * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(d.flags, 0, n, ctx->stream));
+  HIPCHK(hipMemsetAsync(d.ctr, 0, C_COUNT * 8, ctx->stream));
+  {   // all columns empty
+    std::vector<Sec> empty(n);
+    for (size_t i = 0; i < n; i++) { empty[i].size = 0; empty[i].floor = 0; empty[i].sat = 0; empty[i].type = EMPTY; empty[i].prev = NIL; }
+    HIPCHK(hipMemcpyAsync(d.cells, empty.data(), n * sizeof(Sec), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  if (reset_pool(ctx)) return -1;
+  const smx_soil air = {0, 0, 0, 0, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // surface.h:43-49
+  if (smx_set_soils(ctx, &air, 1)) return -1;
+  if (smx_srand(ctx, 1)) return -1;
+  return 0;
+}
+
+void smx_destroy(smx_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  drain_events(ctx);
+  for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
+  DevState& d = ctx->d;
+  hipFree(d.cells); hipFree(d.pool); hipFree(d.freelist); hipFree(d.free_count); hipFree(d.flags);
+  hipFree(d.wfreq); hipFree(d.wtrack); hipFree(d.windfreq); hipFree(d.rnd); hipFree(d.ctr);
+  hipFree(d.active); hipFree(d.active1); hipFree(d.active2); hipFree(ctx->d_scratch); hipFree(ctx->d_soils);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int smx_set_soils(smx_ctx* ctx, const smx_soil* soils, int32_t n) {
+  if (n <= 0 || n > 256) { ctx->err = "smx_set_soils: 1..256 soils"; return -2; }
+  for (int i = 0; i < n; i++)
+    if (soils[i].transports >= (uint32_t)n || soils[i].erodes >= (uint32_t)n || soils[i].cascades >= (uint32_t)n || soils[i].abrades >= (uint32_t)n) {
+      ctx->err = "smx_set_soils: soil index out of range"; return -2;
+    }
+  HIPCHK(hipMemcpyAsync(ctx->d_soils, soils, n * sizeof(SoilP), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->nsoils = n; ctx->d.nsoils = n;
+  return 0;
+}
+int smx_set_scale(smx_ctx* ctx, int32_t scale) { ctx->d.scale = scale; ctx->cfg.scale = scale; return 0; }
+int smx_set_engine(smx_ctx* ctx, int32_t engine) { ctx->cfg.engine = engine; return 0; }
+void* smx_stream(smx_ctx* ctx) { return (void*)ctx->stream; }
+
+int smx_srand(smx_ctx* ctx, uint32_t seed) {   // glibc srandom_r, TYPE_3 (stdlib/random_r.c)
+  RandState r;
+  if (seed == 0) seed = 1;
+  int32_t word = (int32_t)seed;
+  r.ring[0] = (uint32_t)word;
+  for (int i = 1; i < 31; i++) {
+    long hi = word / 127773, lo = word % 127773;
+    word = (int32_t)(16807 * lo - 2836 * hi);
+    if (word < 0) word += 2147483647;
+    r.ring[i] = (uint32_t)word;
+  }
+  uint32_t idx = 34;
+  for (int i = 0; i < 310; i++) { uint32_t v = r.ring[idx % 31] + r.ring[(idx - 3) % 31]; r.ring[idx % 31] = v; idx++; }
+  r.idx = idx; r.calls = 0;
+  HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int smx_rand(smx_ctx* ctx, int32_t* out) {
+  PointOp o{}; o.op = 5;
+  hipLaunchKernelGGL(k_point_op, dim3(1), dim3(64), 0, ctx->stream, ctx->d, o, ctx->d_scratch);
+  double v = 0;
+  HIPCHK(hipMemcpyAsync(&v, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *out = (int32_t)v;
+  return 0;
+}
+
+int smx_rand_advance(smx_ctx* ctx, uint64_t ndraws) {
+  RandState r;
+  HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (uint64_t i = 0; i < ndraws; i++) { uint32_t v = r.ring[r.idx % 31] + r.ring[(r.idx - 3) % 31]; r.ring[r.idx % 31] = v; r.idx++; }
+  r.calls += ndraws;
+  HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int smx_initialize(smx_ctx* ctx, int32_t seed, const smx_layer* layers, int32_t nlayers) {
+  if (nlayers < 0 || nlayers > MAX_LAYERS) { ctx->err = "smx_initialize: too many layers"; return -2; }
+  if (reset_pool(ctx)) return -1;
+  HIPCHK(hipMemsetAsync(ctx->d.ctr + C_LIVE_SECTIONS, 0, 8, ctx->stream));
+  LayersDev L; L.n = nlayers;
+  const int MAXSEED = 10000;
+  for (int l = 0; l < nlayers; l++) {
+    const float f = (float)l / (float)nlayers;                    // layermap.h:183-184
+    const int Z = (int)((float)seed + f * (float)MAXSEED);
+    LayerDev& d = L.l[l];
+    d.type = layers[l].type; d.min = layers[l].min; d.bias = layers[l].bias; d.scale = layers[l].scale;
+    d.noise.seed = 1337; d.noise.octaves = (int)layers[l].octaves; d.noise.frequency = layers[l].frequency;
+    d.noise.lacunarity = layers[l].lacunarity; d.noise.gain = layers[l].gain;
+    float g = d.noise.gain < 0 ? -d.noise.gain : d.noise.gain;    // CalculateFractalBounding (FastNoiseLite.h:473-484)
+    float amp = g, ampFractal = 1.0f;
+    for (int i = 1; i < d.noise.octaves; i++) { ampFractal += amp; amp *= g; }
+    d.noise.bounding = 1 / ampFractal;
+    d.z = (float)(Z % MAXSEED) / 1.0f;                            // vec3(i,j,Z%MAXSEED)/vec3(dim.x,dim.y,1) (:191)
+  }
+  const unsigned nb = (unsigned)((ctx->ncells + 255) / 256);
+  hipLaunchKernelGGL(k_init_terrain, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, L);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int smx_import_columns(smx_ctx* ctx, const uint32_t* count, const uint32_t* type, const double* size,
+                       const double* floor, const double* sat) {
+  const size_t n = ctx->ncells;
+  const uint64_t cap = ctx->cfg.pool_capacity;
+  std::vector<Sec> cells(n);
+  std::vector<uint8_t> flags(n, 0);
+  std::vector<Sec> pool;
+  size_t off = 0, total = 0;
+  for (size_t c = 0; c < n; c++) total += count[c];
+  if (total > cap) { ctx->err = "smx_import_columns: more sections than pool_capacity"; return -4; }
+  pool.reserve(total > n ? total - n + 1 : 1);
+  for (size_t c = 0; c < n; c++) {
+    Sec cell; cell.size = 0; cell.floor = 0; cell.sat = 0; cell.type = EMPTY; cell.prev = NIL;
+    uint32_t pv = NIL;
+    const uint32_t k = count[c];
+    for (uint32_t j = 0; j < k; j++, off++) {
+      Sec r; r.size = size[off]; r.floor = floor[off]; r.sat = sat[off]; r.type = type[off]; r.prev = pv;
+      if (r.sat != 0.0) flags[c] |= F_SAT;
+      if (j == k - 1) cell = r;
+      else { pv = (uint32_t)pool.size(); pool.push_back(r); }
+    }
+    if (cell.type == AIR) flags[c] |= F_AIR;
+    cells[c] = cell;
+  }
+  // node i of `pool` lives at pool index i; the free stack holds the remaining indices
+  const uint64_t used = pool.size();
+  std::vector<uint32_t> fl(cap);
+  uint64_t nf = 0;
+  for (uint64_t i = cap; i-- > used;) fl[nf++] = (uint32_t)i;
+  uint32_t fc = (uint32_t)nf;
+  unsigned long long live = total;
+  HIPCHK(hipMemcpyAsync(ctx->d.cells, cells.data(), n * sizeof(Sec), hipMemcpyHostToDevice, ctx->stream));
+  if (used) HIPCHK(hipMemcpyAsync(ctx->d.pool, pool.data(), used * sizeof(Sec), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d.freelist, fl.data(), cap * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d.free_count, &fc, 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d.flags, flags.data(), n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d.ctr + C_LIVE_SECTIONS, &live, 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int smx_import_frequency(smx_ctx* ctx, const float* wfreq, const float* wtrack, const float* windfreq) {
+  const size_t n = ctx->ncells;
+  if (wfreq) HIPCHK(hipMemcpyAsync(ctx->d.wfreq, wfreq, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (wtrack) HIPCHK(hipMemcpyAsync(ctx->d.wtrack, wtrack, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (windfreq) HIPCHK(hipMemcpyAsync(ctx->d.windfreq, windfreq, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int smx_num_sections(smx_ctx* ctx, uint64_t* out) {
+  unsigned long long live = 0;
+  HIPCHK(hipMemcpyAsync(&live, ctx->d.ctr + C_LIVE_SECTIONS, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *out = live;
+  return 0;
+}
+
+int smx_export_columns(smx_ctx* ctx, uint32_t* count, uint32_t* type, double* size, double* floor, double* sat) {
+  const size_t n = ctx->ncells;
+  const uint64_t cap = ctx->cfg.pool_capacity;
+  std::vector<Sec> cells(n), pool(cap);
+  HIPCHK(hipMemcpyAsync(cells.data(), ctx->d.cells, n * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(pool.data(), ctx->d.pool, cap * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  size_t off = 0;
+  std::vector<const Sec*> col;
+  for (size_t c = 0; c < n; c++) {
+    col.clear();
+    if (cells[c].type != EMPTY) {
+      const Sec* t = &cells[c];
+      while (true) {
+        col.push_back(t);
+        if (t->prev == NIL) break;
+        if (t->prev >= cap || col.size() > cap) { ctx->err = "smx_export_columns: corrupt section chain"; return -5; }
+        t = &pool[t->prev];
+      }
+    }
+    count[c] = (uint32_t)col.size();
+    for (size_t k = col.size(); k-- > 0; off++) {
+      type[off] = col[k]->type; size[off] = col[k]->size; floor[off] = col[k]->floor; sat[off] = col[k]->sat;
+    }
+  }
+  return 0;
+}
+
+int smx_read_frequency(smx_ctx* ctx, float* wfreq, float* wtrack, float* windfreq) {
+  const size_t n = ctx->ncells;
+  if (wfreq) HIPCHK(hipMemcpyAsync(wfreq, ctx->d.wfreq, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (wtrack) HIPCHK(hipMemcpyAsync(wtrack, ctx->d.wtrack, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (windfreq) HIPCHK(hipMemcpyAsync(windfreq, ctx->d.windfreq, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+static int read_plane(smx_ctx* ctx, void* host, size_t bytes, int which) {
+  void* tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, bytes));
+  const unsigned nb = (unsigned)((ctx->ncells + 255) / 256);
+  if (which == 0) hipLaunchKernelGGL(k_heights, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (double*)tmp);
+  else if (which == 1) hipLaunchKernelGGL(k_surface, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (uint32_t*)tmp);
+  else hipLaunchKernelGGL(k_normals, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (float*)tmp);
+  hipError_t e = hipMemcpyAsync(host, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(tmp);
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
+  return 0;
+}
+int smx_read_heights(smx_ctx* ctx, double* out) { return read_plane(ctx, out, ctx->ncells * 8, 0); }
+int smx_read_surface(smx_ctx* ctx, uint32_t* out) { return read_plane(ctx, out, ctx->ncells * 4, 1); }
+int smx_normals(smx_ctx* ctx, float* out3) { return read_plane(ctx, out3, ctx->ncells * 12, 2); }
+
+int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out) {
+  float* dpos = nullptr; double* dout = nullptr;
+  HIPCHK(hipMalloc(&dpos, (size_t)n * 8)); HIPCHK(hipMalloc(&dout, (size_t)n * 8));
+  HIPCHK(hipMemcpyAsync(dpos, pos2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_bilinear, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d, dpos, n, dout);
+  hipError_t e = hipMemcpyAsync(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(dpos); hipFree(dout);
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
+  return 0;
+}
+
+// ---------------- the hot path ----------------
+int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
+  PhaseTimer t(ctx, 0);
+  hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwater);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int smx_grid_pass(smx_ctx* ctx) {
+  PhaseTimer t(ctx, 1);
+  HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, ctx->stream));
+  const unsigned nb = (unsigned)((ctx->ncells + 255) / 256);
+  hipLaunchKernelGGL(k_grid_classify, dim3(nb), dim3(256), 0, ctx->stream, ctx->d);
+  hipLaunchKernelGGL(k_grid_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
+  PhaseTimer t(ctx, 2);
+  hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwind);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int smx_map_frequency(smx_ctx* ctx) {
+  PhaseTimer t(ctx, 3);
+  const size_t n = ctx->ncells, n4 = n / 4;
+  unsigned nb = (unsigned)((n4 + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (nb == 0) nb = 1;
+  hipLaunchKernelGGL(k_map_frequency, dim3(nb), dim3(256), 0, ctx->stream, ctx->d.wfreq, ctx->d.wtrack, n4, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int smx_reset_frequency(smx_ctx* ctx) {
+  PhaseTimer t(ctx, 3);
+  HIPCHK(hipMemsetAsync(ctx->d.wtrack, 0, ctx->ncells * 4, ctx->stream));
+  return 0;
+}
+int smx_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater, int32_t dowind) {   // SoilMachine.cpp:283-329
+  if (dowater) { if (smx_tick_water(ctx, nwater)) return -1; if (smx_grid_pass(ctx)) return -1; }
+  if (dowind) { if (smx_tick_wind(ctx, nwind)) return -1; }
+  if (dowater) { if (smx_map_frequency(ctx)) return -1; if (smx_reset_frequency(ctx)) return -1; }
+  return 0;
+}
+int smx_sync(smx_ctx* ctx) {
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------- point operations ----------------
+static int point_op(smx_ctx* ctx, const PointOp& o, double* out) {
+  hipLaunchKernelGGL(k_point_op, dim3(1), dim3(64), 0, ctx->stream, ctx->d, o, ctx->d_scratch);
+  if (out) HIPCHK(hipMemcpyAsync(out, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+static bool inb(smx_ctx* ctx, int x, int y) {
+  if (x < 0 || y < 0 || x >= ctx->cfg.dimx || y >= ctx->cfg.dimy) { ctx->err = "cell out of bounds"; return false; }
+  return true;
+}
+int smx_add(smx_ctx* ctx, int32_t x, int32_t y, double size, uint32_t type) {
+  if (!inb(ctx, x, y)) return -2;
+  PointOp o{}; o.op = 0; o.x = x; o.y = y; o.a = size; o.type = type; return point_op(ctx, o, nullptr);
+}
+int smx_remove(smx_ctx* ctx, int32_t x, int32_t y, double h, double* remainder) {
+  if (!inb(ctx, x, y)) return -2;
+  PointOp o{}; o.op = 1; o.x = x; o.y = y; o.a = h; double r = 0; int rc = point_op(ctx, o, &r); if (remainder) *remainder = r; return rc;
+}
+int smx_particle_cascade(smx_ctx* ctx, float px, float py, int32_t transferloop) {
+  PointOp o{}; o.op = 2; o.px = px; o.py = py; o.k = transferloop; return point_op(ctx, o, nullptr);
+}
+int smx_water_cascade(smx_ctx* ctx, int32_t x, int32_t y, int32_t spill) {
+  if (!inb(ctx, x, y)) return -2;
+  PointOp o{}; o.op = 3; o.x = x; o.y = y; o.k = spill; return point_op(ctx, o, nullptr);
+}
+int smx_seep(smx_ctx* ctx, int32_t x, int32_t y) {
+  if (!inb(ctx, x, y)) return -2;
+  PointOp o{}; o.op = 4; o.x = x; o.y = y; return point_op(ctx, o, nullptr);
+}
+
+// ---------------- observability ----------------
+int smx_get_counters(smx_ctx* ctx, smx_counters* out) {
+  unsigned long long c[C_COUNT];
+  RandState r;
+  HIPCHK(hipMemcpyAsync(c, ctx->d.ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  memset(out, 0, sizeof(*out));
+  out->steps_water_top = c[C_STEPS_WATER_TOP]; out->steps_water_all = c[C_STEPS_WATER_ALL]; out->steps_wind = c[C_STEPS_WIND];
+  out->nested_particles = c[C_NESTED]; out->floods = c[C_FLOODS]; out->cascade_calls = c[C_CASCADE_CALLS];
+  out->cascade_transfers = c[C_CASCADE_TRANSFERS]; out->wcascade_calls = c[C_WCASCADE_CALLS];
+  out->grid_active_cells = c[C_GRID_ACTIVE]; out->rand_calls = r.calls;
+  out->pool_free = ctx->cfg.pool_capacity - c[C_LIVE_SECTIONS]; out->pool_overflow = c[C_POOL_OVERFLOW];
+  out->spec_rounds = ctx->spec_rounds; out->spec_aborts = ctx->spec_aborts;
+  return 0;
+}
+int smx_get_timing(smx_ctx* ctx, smx_timing* out) {
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  drain_events(ctx);
+  *out = ctx->timing;
+  return 0;
+}
+int smx_timing_reset(smx_ctx* ctx) {
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  drain_events(ctx);
+  memset(&ctx->timing, 0, sizeof(ctx->timing));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Host-side mirror of the reference's interface for the particle-transport hot path.
+
+``Layermap`` mirrors the surface of ``class Layermap`` (source/layermap.h:127-228) that the tick driver
+and the particles use, ``SoilMachine`` mirrors the tick loop of SoilMachine.cpp:283-329 with rendering
+removed. All compute is in the HIP library behind include/soilmx.h; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .snapshot import Snapshot
+from .soilfile import SoilConfig, soils_array, layers_array
+
+
+class SoilmxError(RuntimeError):
+    pass
+
+
+class Layermap:
+    """Device-resident layermap (cells + section pool + frequency planes) behind the C-ABI."""
+
+    def __init__(self, cfg: SoilConfig, dimx: int | None = None, dimy: int | None = None, *, seed: int = 0,
+                 pool: int | None = None, device: int = 0, engine: int = capi.ENGINE_SERIAL, initialize: bool = True):
+        self.L = capi.load()
+        self.cfg = cfg
+        self.dimx = int(dimx if dimx is not None else cfg.SIZEX)
+        self.dimy = int(dimy if dimy is not None else cfg.SIZEY)
+        self.seed = seed
+        self.pool = int(pool if pool is not None else max(8 * self.dimx * self.dimy, 1 << 20))   # POOLSIZE (SoilMachine.cpp:16)
+        c = capi.Config(self.dimx, self.dimy, cfg.SCALE, device, self.pool, engine, 0)
+        h = C.c_void_p()
+        rc = self.L.smx_create(C.byref(c), C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self.L.smx_last_error(h).decode() if h else "smx_create failed"
+            if h:
+                self.L.smx_destroy(h)
+            self.h = None
+            raise SoilmxError(f"smx_create: {msg} (rc={rc})")
+        self._soils = soils_array(cfg)
+        self._chk(self.L.smx_set_soils(self.h, capi.ptr(self._soils), len(self._soils)))
+        self._chk(self.L.smx_srand(self.h, seed))                 # srand(SEED) SoilMachine.cpp:41
+        if initialize:
+            self.initialize(seed)
+
+    # -- plumbing --
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise SoilmxError(self.L.smx_last_error(self.h).decode() + f" (rc={rc})")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.smx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- Layermap API --
+    def initialize(self, seed: int | None = None):
+        """Layermap::initialize (layermap.h:163-216) on the device."""
+        lay = layers_array(self.cfg)
+        self._chk(self.L.smx_initialize(self.h, self.seed if seed is None else seed, capi.ptr(lay), len(lay)))
+
+    def load(self, s: Snapshot, rand_seed: int | None = None):
+        """Import columns / frequency planes; re-seed and fast-forward the rand stream to s.rand_calls."""
+        self._chk(self.L.smx_import_columns(self.h, capi.ptr(s.count), capi.ptr(s.type), capi.ptr(s.size),
+                                            capi.ptr(s.floor), capi.ptr(s.sat)))
+        self._chk(self.L.smx_import_frequency(self.h, capi.ptr(s.wfreq), capi.ptr(s.wtrack), capi.ptr(s.windfreq)))
+        if rand_seed is not None:
+            self._chk(self.L.smx_srand(self.h, rand_seed))
+            self._chk(self.L.smx_rand_advance(self.h, s.rand_calls))
+
+    def snapshot(self) -> Snapshot:
+        ns = C.c_uint64()
+        self._chk(self.L.smx_num_sections(self.h, C.byref(ns)))
+        nc, ns = self.dimx * self.dimy, int(ns.value)
+        count = np.zeros(nc, np.uint32); ty = np.zeros(ns, np.uint32)
+        size = np.zeros(ns); floor = np.zeros(ns); sat = np.zeros(ns)
+        wf = np.zeros(nc, np.float32); wt = np.zeros(nc, np.float32); wi = np.zeros(nc, np.float32)
+        self._chk(self.L.smx_export_columns(self.h, capi.ptr(count), capi.ptr(ty), capi.ptr(size), capi.ptr(floor), capi.ptr(sat)))
+        self._chk(self.L.smx_read_frequency(self.h, capi.ptr(wf), capi.ptr(wt), capi.ptr(wi)))
+        c = self.counters()
+        return Snapshot(self.dimx, self.dimy, self.cfg.SCALE, len(self.cfg.soils), c["rand_calls"], c["pool_free"],
+                        count, ty, size, floor, sat, wf, wt, wi)
+
+    def heights(self) -> np.ndarray:
+        out = np.zeros(self.dimx * self.dimy)
+        self._chk(self.L.smx_read_heights(self.h, capi.ptr(out)))
+        return out
+
+    def surface(self) -> np.ndarray:
+        out = np.zeros(self.dimx * self.dimy, np.uint32)
+        self._chk(self.L.smx_read_surface(self.h, capi.ptr(out)))
+        return out
+
+    def normals(self) -> np.ndarray:
+        out = np.zeros((self.dimx * self.dimy, 3), np.float32)
+        self._chk(self.L.smx_normals(self.h, capi.ptr(out)))
+        return out
+
+    def heights_bilinear(self, pos: np.ndarray) -> np.ndarray:
+        pos = np.ascontiguousarray(pos, np.float32)
+        out = np.zeros(pos.shape[0])
+        self._chk(self.L.smx_heights_bilinear(self.h, capi.ptr(pos), pos.shape[0], capi.ptr(out)))
+        return out
+
+    def add(self, x: int, y: int, size: float, type_: int):
+        self._chk(self.L.smx_add(self.h, x, y, size, type_))
+
+    def remove(self, x: int, y: int, h: float) -> float:
+        r = C.c_double()
+        self._chk(self.L.smx_remove(self.h, x, y, h, C.byref(r)))
+        return r.value
+
+    def counters(self) -> dict:
+        c = capi.Counters()
+        self._chk(self.L.smx_get_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def timing(self) -> dict:
+        t = capi.Timing()
+        self._chk(self.L.smx_get_timing(self.h, C.byref(t)))
+        return t.as_dict()
+
+    def timing_reset(self):
+        self._chk(self.L.smx_timing_reset(self.h))
+
+    def sync(self):
+        self._chk(self.L.smx_sync(self.h))
+
+
+class SoilMachine:
+    """The tick driver of SoilMachine.cpp:283-329 (rendering removed) on top of a device ``Layermap``."""
+
+    def __init__(self, cfg: SoilConfig, size: int | None = None, *, dimx: int | None = None, dimy: int | None = None,
+                 seed: int = 0, nwater: int | None = None, nwind: int | None = None, dowater: bool = True,
+                 dowind: bool = True, **kw):
+        self.cfg = cfg
+        self.map = Layermap(cfg, dimx if dimx is not None else size, dimy if dimy is not None else size, seed=seed, **kw)
+        self.nwater = cfg.NWATER if nwater is None else nwater
+        self.nwind = cfg.NWIND if nwind is None else nwind
+        self.dowater, self.dowind = dowater, dowind
+
+    def tick(self, n: int = 1, sync: bool = False):
+        m = self.map
+        for _ in range(n):
+            m._chk(m.L.smx_tick(m.h, self.nwater, self.nwind, int(self.dowater), int(self.dowind)))
+        if sync:
+            m.sync()
+
+    # phase-by-phase access, as the reference's host loop spells it out
+    def water(self, n=None): self.map._chk(self.map.L.smx_tick_water(self.map.h, self.nwater if n is None else n))
+    def grid_pass(self): self.map._chk(self.map.L.smx_grid_pass(self.map.h))
+    def wind(self, n=None): self.map._chk(self.map.L.smx_tick_wind(self.map.h, self.nwind if n is None else n))
+    def map_frequency(self): self.map._chk(self.map.L.smx_map_frequency(self.map.h))
+    def reset_frequency(self): self.map._chk(self.map.L.smx_reset_frequency(self.map.h))

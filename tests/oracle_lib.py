@@ -93,7 +93,7 @@ class Oracle:
     def __init__(self, cfg: SoilConfig, dimx: int, dimy: int, pool: int | None = None, seed: int = 0):
         self.L = lib()
         self.cfg, self.dimx, self.dimy = cfg, dimx, dimy
-        self.pool = int(pool if pool is not None else max(4 * dimx * dimy, 1 << 16))
+        self.pool = int(pool if pool is not None else max(8 * dimx * dimy, 1 << 20))
         self.h = self.L.so_create(dimx, dimy, cfg.SCALE, self.pool)
         self._soils = soils_array(cfg)
         self.L.so_set_soils(self.h, _p(self._soils), len(self._soils))
@@ -149,12 +149,17 @@ def have_ref() -> bool:
 
 def run_ref(soil: str, seed: int = 0, size: int = 0, ticks: int = 1, nwater: int = -1, nwind: int = -1,
             water: bool = True, wind: bool = True, pool: int | None = None, dump_prefix: str | None = None,
-            dump_at=(), soils_out: str | None = None, lean: bool = False, timeout: float | None = None) -> dict:
+            dump_at=(), soils_out: str | None = None, lean: bool = False, timeout: float | None = None,
+            sizex: int = 0, sizey: int = 0) -> dict:
     """Run oracle/_ref/soil_ref (the reference's own headers, compiled headless) and return its JSON line."""
     cmd = [REF_LEAN_BIN if lean else REF_BIN, "--soil", soil, "--seed", str(seed), "--ticks", str(ticks),
            "--water", str(int(water)), "--wind", str(int(wind))]
     if size:
         cmd += ["--size", str(size)]
+    if sizex:
+        cmd += ["--sizex", str(sizex)]
+    if sizey:
+        cmd += ["--sizey", str(sizey)]
     if nwater >= 0:
         cmd += ["--nwater", str(nwater)]
     if nwind >= 0:
