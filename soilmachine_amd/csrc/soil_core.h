@@ -4,7 +4,7 @@
 //   cells[x*dimy+y]  : one 32-byte Sec record per column = the column's TOP section stored INLINE
 //                      {size, floor, sat : f64; type : u32; prev : u32 index of the section below}
 //                      -> Layermap::height()/surface()/top() (layermap.h:150,417-425) are ONE aligned
-//                         32-byte load, no pointer chase; an empty column has type == EMPTY and
+//                         32-byte record, no pointer chase; an empty column has type == EMPTY and
 //                         size = floor = 0 (height 0.0, surface 0 as the reference returns for NULL).
 //   pool[i]          : the same 32-byte record for BURIED sections (reached through prev), plus a
 //                      free-index stack. Replaces sec / secpool (layermap.h:37-119); node identity is
@@ -12,6 +12,13 @@
 //   flags[cell]      : u8, bit0 = top section is water ("Air"), bit1 = column holds a non-zero
 //                      saturation somewhere (sticky) -> input of the grid-pass classification kernel.
 //   wfreq/wtrack/windfreq[y*dimx+x] : f32 planes (water.h:22-23,345-346; wind.h:25,48).
+//
+// Code structure: NO recursion and no out-of-line calls on the particle path. The reference's mutual
+// recursion WaterParticle::cascade -> nested WaterParticle -> flood -> cascade (water.h:123-283) is an
+// explicit frame stack (`Frame`, depth bounded by the spill budget, water.h:34,125,255,279), so a particle
+// lives in registers for its whole life. All state access goes through an access policy `P`:
+//   SerialPolicy       one walker, reference order, direct access                       (soil_serial.h)
+//   SpecPolicy         optimistic parallel execution with per-cell stamps + undo log    (soil_spec.h)
 //
 // Arithmetic follows SURVEY.md Appendix A exactly (mixed float/double promotions, no FMA: this file
 // must be compiled with -ffp-contract=off). Every function cites the reference lines it implements.
@@ -21,7 +28,6 @@
 
 #ifndef SMX_D
 #define SMX_D __device__ __forceinline__
-#define SMX_DN __device__ __noinline__
 #endif
 
 namespace smx {
@@ -30,6 +36,7 @@ constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;   // cells[c].type of an empty column (dat[c] == NULL)
 constexpr uint32_t AIR = 0;               // soilmap["Air"] (surface.h:53-57); doubles as water
 constexpr uint8_t F_AIR = 1, F_SAT = 2;
+constexpr int MAX_SOILS = 256;
 
 struct alignas(32) Sec {
   double size, floor, sat;
@@ -70,7 +77,6 @@ struct DevState {
 
 struct f2 { float x, y; };
 struct f3 { float x, y, z; };
-struct Pt { int x, y; double h; };
 
 SMX_D f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 SMX_D f3 cross3(f3 x, f3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
@@ -80,27 +86,21 @@ SMX_D f3 normalize3(f3 v) { float s = 1.0f / sqrtf(dot3(v, v)); return {v.x * s,
 SMX_D f2 normalize2(f2 v) { float s = 1.0f / sqrtf(dot2(v, v)); return {v.x * s, v.y * s}; }
 SMX_D float mixd(float x, float y, double a) { return (float)((double)x * (1.0 - a) + (double)y * a); }
 
-// std::sort on <= 16 elements == insertion sort, stable for the strict comparator (SURVEY.md Appx D#5)
-SMX_D void sort_desc(Pt* sn, int num) {
-  for (int i = 1; i < num; i++) {
-    Pt v = sn[i];
-    if (v.h > sn[0].h) {
-      for (int j = i; j > 0; j--) sn[j] = sn[j - 1];
-      sn[0] = v;
-    } else {
-      int j = i;
-      while (v.h > sn[j - 1].h) { sn[j] = sn[j - 1]; j--; }
-      sn[j] = v;
-    }
-  }
-}
+// The 8 neighbours in the order of the reference's table (particle.h:30-39, water.h:155-164):
+// code k -> (dx, dy) = (-1,-1),(-1,0),(-1,1),(0,-1),(0,1),(1,-1),(1,0),(1,1)
+SMX_D int nb_dx(int k) { return (k < 3) ? -1 : (k < 5 ? 0 : 1); }
+SMX_D int nb_dy(int k) { return (k < 3) ? (k - 1) : (k < 5 ? (k == 3 ? -1 : 1) : (k - 6)); }
 
-struct Water {            // WaterParticle (water.h:9-41)
+// In-bounds neighbours of (ix,iy) sorted by height, highest first. std::sort on <= 16 elements is an
+// insertion sort and therefore stable for the strict comparator a.h > b.h.
+// Result: number of neighbours, `codes` = 4-bit neighbour codes, first in the low nibble.
+struct Sorted { int num; uint32_t codes; };
+
+struct Water {            // WaterParticle (water.h:9-41); `param` is re-read from the soil table via `surface`
   f2 pos, speed;
   double volume, sediment, evaprate;
   int spill, ix, iy;
-  f3 n;
-  SoilP param;
+  float friction;         // param.friction after the frequency scaling of move() (water.h:53)
   uint32_t surface, contains;
 };
 struct Wind {             // WindParticle (wind.h:11-46)
@@ -108,79 +108,118 @@ struct Wind {             // WindParticle (wind.h:11-46)
   f3 speed;
   double sediment, height, sheight;
   int ix, iy;
-  f3 n;
   uint32_t surface, contains;
-  SoilP param;
 };
 
-// The exact engine: every method is the sequential reference semantics executed by ONE lane.
-struct Sim {
-  DevState s;
-  bool grid_mode;          // inside the grid pass: newly wet cells must be added to the active bitmap
+// One suspended WaterParticle::cascade invocation (water.h:151-283): centre, remaining spill budget,
+// the sorted neighbour list and the loop index.
+struct Frame { int ix, iy, spill, num, i; uint32_t codes; };
+constexpr int MAX_FRAMES = 24;
 
-  SMX_D Sim(const DevState& st) : s(st), grid_mode(false) {}
+template <class P>
+struct Sim {
+  const DevState& s;
+  const SoilP* soils;      // soil table (LDS copy on the device)
+  P& pol;
+  bool grid_mode = false;  // inside the grid pass: newly wet cells go to the active bitmap
+  bool ab = false;         // speculative execution only: this particle has been aborted
+  // counters live in registers and are flushed once per kernel
+  unsigned long long n_steps_w_top = 0, n_steps_w_all = 0, n_steps_wind = 0, n_nested = 0, n_floods = 0,
+                     n_casc = 0, n_casc_tr = 0, n_wcasc = 0, n_overflow = 0;
+
+  SMX_D Sim(const DevState& st, const SoilP* so, P& p) : s(st), soils(so), pol(p) {}
 
   SMX_D size_t cidx(int x, int y) const { return (size_t)x * s.dimy + y; }   // layermap.h:151
   SMX_D size_t fidx(int x, int y) const { return (size_t)y * s.dimx + x; }   // water.h:53,349
-  SMX_D void count(int which, unsigned long long v = 1) { s.ctr[which] += v; }
 
-  // ---------------- pool: secpool::get / unget (layermap.h:89-111) ----------------
-  // The reference takes a node for EVERY pool.get() (even when add() merges and returns it at once), so
-  // get() fails exactly when live sections == capacity. We keep that rule with a live-section counter.
-  SMX_D bool can_get() {
-    if (s.ctr[C_LIVE_SECTIONS] >= s.pool_capacity) { count(C_POOL_OVERFLOW); return false; }
-    return true;
-  }
-  SMX_D uint32_t node_alloc() {
-    uint32_t n = *s.free_count;
-    if (n == 0) { count(C_POOL_OVERFLOW); return NIL; }   // cannot happen while can_get() guards callers
-    *s.free_count = n - 1;
-    return s.freelist[n - 1];
-  }
-  SMX_D void node_free(uint32_t e) {
-    uint32_t n = *s.free_count;
-    s.freelist[n] = e;
-    *s.free_count = n + 1;
+  SMX_D void flush_counters() {
+    pol.add_counter(s, C_STEPS_WATER_TOP, n_steps_w_top); pol.add_counter(s, C_STEPS_WATER_ALL, n_steps_w_all);
+    pol.add_counter(s, C_STEPS_WIND, n_steps_wind); pol.add_counter(s, C_NESTED, n_nested);
+    pol.add_counter(s, C_FLOODS, n_floods); pol.add_counter(s, C_CASCADE_CALLS, n_casc);
+    pol.add_counter(s, C_CASCADE_TRANSFERS, n_casc_tr); pol.add_counter(s, C_WCASCADE_CALLS, n_wcasc);
+    pol.add_counter(s, C_POOL_OVERFLOW, n_overflow);
+    n_steps_w_top = n_steps_w_all = n_steps_wind = n_nested = n_floods = n_casc = n_casc_tr = n_wcasc = n_overflow = 0;
   }
 
-  // ---------------- queries ----------------
-  SMX_D double height(int x, int y) const {                 // Layermap::height(ivec2) layermap.h:422-425
-    const Sec& c = s.cells[cidx(x, y)];
+  // ---------------- cell access (every access announces itself to the policy first) ----------------
+  SMX_D Sec& cell(int x, int y) {
+    const size_t c = cidx(x, y);
+    if (!pol.touch(s, c)) ab = true;
+    return s.cells[c];
+  }
+  SMX_D double height(int x, int y) {                       // Layermap::height(ivec2) layermap.h:422-425
+    const Sec& c = cell(x, y);
     return c.floor + c.size;
   }
-  SMX_D uint32_t surface(int x, int y) const {              // Layermap::surface layermap.h:417-420
-    uint32_t t = s.cells[cidx(x, y)].type;
+  SMX_D uint32_t surface(int x, int y) {                    // Layermap::surface layermap.h:417-420
+    const uint32_t t = cell(x, y).type;
     return t == EMPTY ? 0u : t;
   }
-  SMX_D double height_bilinear(f2 pos) const {              // Layermap::height(vec2) layermap.h:427-439
+  SMX_D double height_bilinear(f2 pos) {                    // Layermap::height(vec2) layermap.h:427-439
     double h = 0.0;
-    float fx = floorf(pos.x), fy = floorf(pos.y);
-    int px = (int)fx, py = (int)fy;
-    float wx = pos.x - fx, wy = pos.y - fy;
-    h += (1.0 - wx) * (1.0 - wy) * height(px, py);
-    h += (1.0 - wx) * wy * height(px + 1, py);              // crossed weights as in the reference (:434-435)
-    h += wx * (1.0 - wy) * height(px, py + 1);
-    h += wx * wy * height(px + 1, py + 1);                  // wx*wy is a FLOAT product (:436)
+    const float fx = floorf(pos.x), fy = floorf(pos.y);
+    const int px = (int)fx, py = (int)fy;
+    const float wx = pos.x - fx, wy = pos.y - fy;
+    const double h00 = height(px, py), h10 = height(px + 1, py), h01 = height(px, py + 1), h11 = height(px + 1, py + 1);
+    h += (1.0 - wx) * (1.0 - wy) * h00;
+    h += (1.0 - wx) * wy * h10;                             // crossed weights as in the reference (:434-435)
+    h += wx * (1.0 - wy) * h01;
+    h += wx * wy * h11;                                     // wx*wy is a FLOAT product (:436)
     return h;
   }
-  SMX_D f3 normal(int x, int y) const {                     // Layermap::normal(ivec2) layermap.h:341-377
+  SMX_D f3 normal(int x, int y) {                           // Layermap::normal(ivec2) layermap.h:341-377
     const int SC = s.scale;
-    f3 n = {0.f, 0.f, 0.f};
-    f3 p = {(float)x, (float)(SC * height(x, y)), (float)y};
-    int k = 0;
     const bool xm = x > 0, xp = x < s.dimx - 1, ym = y > 0, yp = y < s.dimy - 1;
-    f3 bm = {0, 0, 0}, bp = {0, 0, 0}, cm = {0, 0, 0}, cp = {0, 0, 0};
-    if (xm) bm = {(float)(x - 1), (float)(SC * height(x - 1, y)), (float)y};
-    if (xp) bp = {(float)(x + 1), (float)(SC * height(x + 1, y)), (float)y};
-    if (ym) cm = {(float)x, (float)(SC * height(x, y - 1)), (float)(y - 1)};
-    if (yp) cp = {(float)x, (float)(SC * height(x, y + 1)), (float)(y + 1)};
+    const double h0 = height(x, y);
+    const double hxm = xm ? height(x - 1, y) : 0.0, hxp = xp ? height(x + 1, y) : 0.0;
+    const double hym = ym ? height(x, y - 1) : 0.0, hyp = yp ? height(x, y + 1) : 0.0;
+    f3 n = {0.f, 0.f, 0.f};
+    const f3 p = {(float)x, (float)(SC * h0), (float)y};
+    const f3 bm = {(float)(x - 1), (float)(SC * hxm), (float)y}, bp = {(float)(x + 1), (float)(SC * hxp), (float)y};
+    const f3 cm = {(float)x, (float)(SC * hym), (float)(y - 1)}, cp = {(float)x, (float)(SC * hyp), (float)(y + 1)};
+    int k = 0;
     if (xm && ym) { f3 v = cross3(sub3(cm, p), sub3(bm, p)); n.x += v.x; n.y += v.y; n.z += v.z; k++; }
     if (xm && yp) { f3 v = cross3(sub3(cp, p), sub3(bm, p)); n.x -= v.x; n.y -= v.y; n.z -= v.z; k++; }
     if (xp && ym) { f3 v = cross3(sub3(cm, p), sub3(bp, p)); n.x -= v.x; n.y -= v.y; n.z -= v.z; k++; }
     if (xp && yp) { f3 v = cross3(sub3(cp, p), sub3(bp, p)); n.x += v.x; n.y += v.y; n.z += v.z; k++; }
-    float kf = (float)k;
-    f3 q = {n.x / kf, n.y / kf, n.z / kf};
+    const float kf = (float)k;
+    const f3 q = {n.x / kf, n.y / kf, n.z / kf};
     return normalize3(q);
+  }
+
+  // Stable descending sort of the <= 8 in-bounds neighbours by height == the reference's std::sort (an
+  // insertion sort for n <= 16): ties keep neighbour-table order, i.e. the order is
+  // the total order (h desc, code asc). Done as a 19-comparator sorting network on registers; out-of-bounds
+  // slots carry h = -inf and sort to the end (heights are >= 0).
+  SMX_D Sorted sorted_neighbours(int ix, int iy) {          // particle.h:43-60 == water.h:168-185
+    double h[8]; int code[8]; int num = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
+      const bool in = !(nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0);
+      h[k] = in ? height(nx, ny) : -INFINITY;
+      code[k] = k;
+      num += in ? 1 : 0;
+    }
+#define SMX_CE(i, j)                                                                             \
+    {                                                                                            \
+      const bool sw = (h[j] > h[i]) || (h[j] == h[i] && code[j] < code[i]);                      \
+      const double hi = sw ? h[j] : h[i], hj = sw ? h[i] : h[j];                                 \
+      const int ci = sw ? code[j] : code[i], cj = sw ? code[i] : code[j];                        \
+      h[i] = hi; h[j] = hj; code[i] = ci; code[j] = cj;                                          \
+    }
+    SMX_CE(0, 1) SMX_CE(2, 3) SMX_CE(4, 5) SMX_CE(6, 7)
+    SMX_CE(0, 2) SMX_CE(1, 3) SMX_CE(4, 6) SMX_CE(5, 7)
+    SMX_CE(1, 2) SMX_CE(5, 6) SMX_CE(0, 4) SMX_CE(3, 7)
+    SMX_CE(1, 5) SMX_CE(2, 6)
+    SMX_CE(1, 4) SMX_CE(3, 6)
+    SMX_CE(2, 4) SMX_CE(3, 5)
+    SMX_CE(3, 4)
+#undef SMX_CE
+    Sorted r; r.num = num; r.codes = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.codes |= (uint32_t)code[i] << (4 * i);
+    return r;
   }
 
   // ---------------- wet bookkeeping for the grid pass ----------------
@@ -217,187 +256,153 @@ struct Sim {
     return n;
   }
   SMX_D void on_air_top(int x, int y) {                     // column (x,y) now has a water top
-    size_t c = cidx(x, y);
-    s.flags[c] |= F_AIR;
+    pol.set_flag(s, cidx(x, y), F_AIR);
     if (grid_mode)
       for (int dx = -1; dx <= 1; dx++)
         for (int dy = -1; dy <= 1; dy++) {
-          int nx = x + dx, ny = y + dy;
+          const int nx = x + dx, ny = y + dy;
           if (nx < 0 || ny < 0 || nx >= s.dimx || ny >= s.dimy) continue;
           mark_active(cidx(nx, ny));
         }
   }
   SMX_D void on_sat(int x, int y) {                         // a saturation in column (x,y) was written
-    size_t c = cidx(x, y);
-    s.flags[c] |= F_SAT;
-    if (grid_mode) mark_active(c);
+    pol.set_flag(s, cidx(x, y), F_SAT);
+    if (grid_mode) mark_active(cidx(x, y));
   }
-  SMX_D void sync_air_flag(int x, int y) {                  // after any change of the top section's type
-    size_t c = cidx(x, y);
-    if (s.cells[c].type == AIR) on_air_top(x, y);
-    else s.flags[c] &= (uint8_t)~F_AIR;
+  SMX_D void sync_air_flag(int x, int y, uint32_t type) {   // after any change of the top section's type
+    if (type == AIR) on_air_top(x, y);
+    else pol.clear_flag(s, cidx(x, y), F_AIR);
   }
 
   // ---------------- mutation primitives ----------------
-  SMX_D void pop_top(Sec& cell) {                           // dat = E->prev; pool.unget(E)
-    uint32_t pv = cell.prev;
+  SMX_D void pop_top(Sec& c) {                              // dat = E->prev; pool.unget(E)
+    const uint32_t pv = c.prev;
     if (pv == NIL) {
-      cell.size = 0.0; cell.floor = 0.0; cell.sat = 0.0; cell.type = EMPTY; cell.prev = NIL;
+      c.size = 0.0; c.floor = 0.0; c.sat = 0.0; c.type = EMPTY; c.prev = NIL;
     } else {
-      cell = s.pool[pv];
-      node_free(pv);
+      c = s.pool[pv];
+      pol.node_free(s, pv);
     }
-    s.ctr[C_LIVE_SECTIONS]--;
+    pol.live_add(s, -1);
   }
-  // add the section {size, type, sat} on top of column (x,y): Layermap::add (layermap.h:230-307).
-  // `fresh` == the section came from pool.get() (counts against the pool); the water re-add of the swap
-  // path re-uses the popped water section.
-  SMX_D void add_sec(int x, int y, double size, uint32_t type, double sat, bool fresh) {
-    if (fresh) {
-      if (!can_get()) return;                               // pool.get() == NULL -> add(NULL) ignored (:233)
-      s.ctr[C_LIVE_SECTIONS]++;                             // the node E now exists
-    }
-    if (size <= 0) { s.ctr[C_LIVE_SECTIONS]--; return; }    // :237-240 unget(E)
-    Sec& cell = s.cells[cidx(x, y)];
-    if (cell.type == EMPTY) {                               // :243-246
-      cell.size = size; cell.floor = 0.0; cell.sat = sat; cell.type = type; cell.prev = NIL;
-      sync_air_flag(x, y);
-      if (sat != 0.0) on_sat(x, y);
+  // the tail of Layermap::add once the incoming section is known to be kept apart from a water top:
+  // empty column -> place (:243-246); same type -> elongate (:249-253); else push (:302-305)
+  SMX_D void place(int x, int y, Sec& c, double size, uint32_t type, double sat) {
+    if (c.type == EMPTY) {
+      c.size = size; c.floor = 0.0; c.sat = sat; c.type = type; c.prev = NIL;
+    } else if (c.type == type) {
+      c.size += size;
+      pol.live_add(s, -1);
       return;
+    } else {
+      const uint32_t nd = pol.node_alloc(s);
+      if (nd == NIL) { n_overflow++; pol.live_add(s, -1); return; }
+      const double h = c.floor + c.size;                    // E->floor = height(pos)
+      s.pool[nd] = c;
+      c.size = size; c.floor = h; c.sat = sat; c.type = type; c.prev = nd;
     }
-    if (cell.type == type) {                                // :249-253 elongate, unget(E)
-      cell.size += size;
-      s.ctr[C_LIVE_SECTIONS]--;
-      return;
-    }
-    if (cell.type == AIR) {                                 // :258-275 water stays on top
-      double wsize = cell.size, wsat = cell.sat;
-      uint32_t pv = cell.prev;                              // dat = top->prev (water section kept aside)
-      if (pv == NIL) { cell.size = 0.0; cell.floor = 0.0; cell.sat = 0.0; cell.type = EMPTY; cell.prev = NIL; }
-      else { cell = s.pool[pv]; node_free(pv); }
-      add_sec_nofresh(x, y, size, type, sat);               // add(pos, E)
-      add_sec_nofresh(x, y, wsize, AIR, wsat);              // add(pos, top)
-      return;
-    }
-    // :302-305 push on top: the old top becomes a buried pool node
-    uint32_t nd = node_alloc();
-    if (nd == NIL) { s.ctr[C_LIVE_SECTIONS]--; return; }
-    double h = cell.floor + cell.size;
-    s.pool[nd] = cell;
-    cell.size = size; cell.floor = h; cell.sat = sat; cell.type = type; cell.prev = nd;
-    sync_air_flag(x, y);
+    sync_air_flag(x, y, type);
     if (sat != 0.0) on_sat(x, y);
   }
-  // same as add_sec(..., fresh=false) but never recurses into the swap path twice (E != Air there)
-  SMX_D void add_sec_nofresh(int x, int y, double size, uint32_t type, double sat) {
-    if (size <= 0) { s.ctr[C_LIVE_SECTIONS]--; return; }
-    Sec& cell = s.cells[cidx(x, y)];
-    if (cell.type == EMPTY) {
-      cell.size = size; cell.floor = 0.0; cell.sat = sat; cell.type = type; cell.prev = NIL;
-      sync_air_flag(x, y);
-      if (sat != 0.0) on_sat(x, y);
+  // Layermap::add(pos, pool.get(size, type)) (layermap.h:230-307 + :89-103)
+  SMX_D void add(int x, int y, double size, uint32_t type) {
+    if (ab) return;
+    Sec& c = cell(x, y);
+    if (ab) return;
+    // pool.get(): the reference takes a node for EVERY get (even if add() merges and returns it at once),
+    // so get() fails exactly when live sections == capacity; add(NULL) is ignored (:233)
+    if (!pol.can_get(s)) { n_overflow++; return; }
+    pol.live_add(s, +1);
+    if (size <= 0) { pol.live_add(s, -1); return; }         // :237-240 unget(E)
+    if (c.type != EMPTY && c.type != type && c.type == AIR) {   // :258-275 water stays on top
+      const double wsize = c.size, wsat = c.sat;
+      const uint32_t pv = c.prev;                           // dat = top->prev (the water section is kept aside)
+      if (pv == NIL) { c.size = 0.0; c.floor = 0.0; c.sat = 0.0; c.type = EMPTY; c.prev = NIL; }
+      else { c = s.pool[pv]; pol.node_free(s, pv); }
+      place(x, y, c, size, type, 0.0);                      // add(pos, E)      (E != Air here)
+      if (wsize <= 0) { pol.live_add(s, -1); sync_air_flag(x, y, c.type); return; }
+      place(x, y, c, wsize, AIR, wsat);                     // add(pos, top)
       return;
     }
-    if (cell.type == type) { cell.size += size; s.ctr[C_LIVE_SECTIONS]--; return; }
-    uint32_t nd = node_alloc();
-    if (nd == NIL) { s.ctr[C_LIVE_SECTIONS]--; return; }
-    double h = cell.floor + cell.size;
-    s.pool[nd] = cell;
-    cell.size = size; cell.floor = h; cell.sat = sat; cell.type = type; cell.prev = nd;
-    sync_air_flag(x, y);
-    if (sat != 0.0) on_sat(x, y);
+    place(x, y, c, size, type, 0.0);
   }
-  SMX_D void add(int x, int y, double size, uint32_t type) { add_sec(x, y, size, type, 0.0, true); }
-
-  // Layermap::remove (layermap.h:310-339); *popped (optional) tells the caller that the top section went away
+  // Layermap::remove (layermap.h:310-339); *popped tells the caller that the top section went away
   SMX_D double remove(int x, int y, double h, bool* popped = nullptr) {
-    Sec& cell = s.cells[cidx(x, y)];
     if (popped) *popped = false;
-    if (cell.type == EMPTY) return 0.0;
-    if (cell.size <= 0.0) { pop_top(cell); sync_air_flag(x, y); if (popped) *popped = true; return 0.0; }
+    if (ab) return 0.0;
+    Sec& c = cell(x, y);
+    if (ab) return 0.0;
+    if (c.type == EMPTY) return 0.0;
+    if (c.size <= 0.0) { pop_top(c); sync_air_flag(x, y, c.type); if (popped) *popped = true; return 0.0; }
     if (h <= 0.0) return 0.0;
-    double diff = h - cell.size;
-    cell.size -= h;
-    if (diff >= 0.0) { pop_top(cell); sync_air_flag(x, y); if (popped) *popped = true; return diff; }
+    const double diff = h - c.size;
+    c.size -= h;
+    if (diff >= 0.0) { pop_top(c); sync_air_flag(x, y, c.type); if (popped) *popped = true; return diff; }
     return 0.0;
   }
 
-  // ---------------- glibc rand() ----------------
-  SMX_D int rand_() {
-    RandState& r = *s.rnd;
-    uint32_t i = r.idx;
-    uint32_t v = r.ring[i % 31] + r.ring[(i - 3) % 31];
-    r.ring[i % 31] = v;
-    r.idx = i + 1;
-    r.calls++;
-    return (int)(v >> 1);
-  }
-
   // ---------------- Particle::cascade particle.h:24-101 ----------------
-  SMX_DN void particle_cascade(f2 pos, int transferloop) {
-    count(C_CASCADE_CALLS);
+  // LOOP: remaining recursion budget (transferloop). Water uses 0, wind 1 (wind.h:112,126,129).
+  template <int LOOP>
+  SMX_D void particle_cascade(f2 pos) {
+    n_casc++;
     const int ix = (int)roundf(pos.x), iy = (int)roundf(pos.y);
-    Pt sn[8];
-    int num = 0;
-    for (int dx = -1; dx <= 1; dx++)
-      for (int dy = -1; dy <= 1; dy++) {
-        if (dx == 0 && dy == 0) continue;
-        int nx = ix + dx, ny = iy + dy;
-        if (nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0) continue;
-        sn[num].x = nx; sn[num].y = ny; sn[num].h = height(nx, ny); num++;
-      }
-    sort_desc(sn, num);
+    const Sorted sn = sorted_neighbours(ix, iy);
+    if (ab) return;
     const double sc = (double)(float)s.scale, d80 = (double)80.0f;
-    for (int i = 0; i < num; i++) {
-      const int nx = sn[i].x, ny = sn[i].y;
-      float diff = (float)((height(ix, iy) - height(nx, ny)) * sc / d80);
+    int transferloop = LOOP;
+    for (int i = 0; i < sn.num; i++) {
+      const int k = (sn.codes >> (4 * i)) & 15;
+      const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
+      const float diff = (float)((height(ix, iy) - height(nx, ny)) * sc / d80);
       if (diff == 0) continue;
       const int tx = (diff > 0) ? ix : nx, ty = (diff > 0) ? iy : ny;
       const int bx = (diff > 0) ? nx : ix, by = (diff > 0) ? ny : iy;
-      const uint32_t type = surface(tx, ty);
-      const SoilP& param = s.soils[type];
-      float excess = fabsf(diff) - param.maxdiff;
+      const Sec& T = cell(tx, ty);
+      const uint32_t type = (T.type == EMPTY) ? 0u : T.type;
+      const float excess = fabsf(diff) - soils[type].maxdiff;
       if (excess <= 0) continue;
-      float transfer = param.settling * excess / 2.0f;
+      float transfer = soils[type].settling * excess / 2.0f;
       bool recascade = false;
-      const double tsize = s.cells[cidx(tx, ty)].size;
+      const double tsize = T.size;
       if ((double)transfer > tsize) transfer = (float)tsize;
-      const uint32_t casc = param.cascades;
+      const uint32_t casc = soils[type].cascades;
+      if (ab) return;
       if (remove(tx, ty, (double)transfer) != 0) recascade = true;
       add(bx, by, (double)transfer, casc);
-      count(C_CASCADE_TRANSFERS);
-      if (recascade && transferloop > 0) particle_cascade(f2{(float)nx, (float)ny}, --transferloop);
+      n_casc_tr++;
+      if constexpr (LOOP > 0) {
+        if (recascade && transferloop > 0) { --transferloop; particle_cascade<0>(f2{(float)nx, (float)ny}); }
+      }
+      if (ab) return;
     }
   }
 
   // ---------------- WaterParticle water.h:9-368 ----------------
-  SMX_D void water_ctor(Water& p) {                          // water.h:11-19 (g++: 1st draw -> y, 2nd -> x)
-    int ry = rand_() % s.dimy;
-    int rx = rand_() % s.dimx;
+  SMX_D void water_init(Water& p, int rx, int ry) {          // water.h:11-19 (caller supplies the two draws)
     p.pos = {(float)rx, (float)ry};
     p.speed = {0.f, 0.f};
     p.volume = 1.0; p.sediment = 0.0; p.evaprate = 0.001; p.spill = 3;
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    p.n = {0.f, 0.f, 0.f};
     p.surface = surface(p.ix, p.iy);
-    p.param = s.soils[p.surface];
-    p.contains = p.param.transports;
+    p.friction = soils[p.surface].friction;
+    p.contains = soils[p.surface].transports;
   }
   SMX_D bool water_move(Water& p) {                          // water.h:43-73
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    p.n = normal(p.ix, p.iy);
+    const f3 n = normal(p.ix, p.iy);
     p.surface = surface(p.ix, p.iy);
-    p.param = s.soils[p.surface];
+    if (ab) return false;
     p.evaprate = 0.01;
     const size_t fi = fidx(p.ix, p.iy);
     s.wtrack[fi] = (float)((double)s.wtrack[fi] + p.volume);            // updatefrequency :348-351
     const float fr = s.wfreq[fi];
-    p.param.friction = p.param.friction * (1.0f - fr);
+    p.friction = soils[p.surface].friction * (1.0f - fr);
     p.evaprate = p.evaprate * (double)(1.0f - 0.2f * fr);
-    const f2 nxz = {p.n.x, p.n.z};
-    const f2 scaled = {nxz.x * p.param.friction, nxz.y * p.param.friction};
+    const f2 nxz = {n.x, n.z};
+    const f2 scaled = {nxz.x * p.friction, nxz.y * p.friction};
     if ((double)sqrtf(dot2(scaled, scaled)) < 1E-5) return false;
-    const float a = p.param.friction;                                    // mix(nxz, speed, friction)
+    const float a = p.friction;                                          // mix(nxz, speed, friction)
     p.speed = {nxz.x * (1.0f - a) + p.speed.x * a, nxz.y * (1.0f - a) + p.speed.y * a};
     const f2 nn = normalize2(p.speed);
     const float s2 = sqrtf(2.0f);
@@ -411,122 +416,55 @@ struct Sim {
     return true;
   }
   SMX_D bool water_interact(Water& p) {                      // water.h:75-121
-    double c_eq = p.param.solubility * (height(p.ix, p.iy) - height_bilinear(p.pos)) * (double)s.scale / 80.0;
+    const SoilP& param = soils[p.surface];
+    double c_eq = param.solubility * (height(p.ix, p.iy) - height_bilinear(p.pos)) * (double)s.scale / 80.0;
+    if (ab) return false;
     if (c_eq < 0.0) c_eq = 0.0;
     if (c_eq > 1.0) c_eq = 1.0;
     const size_t fi = fidx(p.ix, p.iy);
-    if ((double)(s.soils[p.contains].erosionrate) < s.wfreq[fi]) p.contains = s.soils[p.contains].erodes;
+    if ((double)(soils[p.contains].erosionrate) < s.wfreq[fi]) p.contains = soils[p.contains].erodes;
     const double cdiff = c_eq - p.sediment;
     if (cdiff > 0) {
-      p.sediment += p.param.equrate * cdiff;
-      p.contains = s.soils[surface(p.ix, p.iy)].transports;
-      double diff = remove(p.ix, p.iy, p.param.equrate * cdiff * p.volume);
+      p.sediment += param.equrate * cdiff;
+      p.contains = soils[surface(p.ix, p.iy)].transports;
+      double diff = remove(p.ix, p.iy, param.equrate * cdiff * p.volume);
       while (fabs(diff) > 1E-8) diff = remove(p.ix, p.iy, diff);
     } else if (cdiff < 0) {
-      p.sediment += s.soils[p.contains].equrate * cdiff;
-      add(p.ix, p.iy, -s.soils[p.contains].equrate * cdiff * p.volume, p.contains);
+      p.sediment += soils[p.contains].equrate * cdiff;
+      add(p.ix, p.iy, -soils[p.contains].equrate * cdiff * p.volume, p.contains);
     }
-    particle_cascade(p.pos, 0);
+    particle_cascade<0>(p.pos);
+    if (ab) return false;
     p.sediment /= (1.0 - p.evaprate);
     if (p.sediment > 1.0) p.sediment = 1.0;
     p.volume *= (1.0 - p.evaprate);
     return (p.volume > 0.01);
   }
-  SMX_DN bool water_flood(Water& p) {                        // water.h:123-145 (always returns false)
-    if (p.volume < 0.01 || p.spill-- <= 0) return false;
-    count(C_FLOODS);
-    p.ix = (int)p.pos.x; p.iy = (int)p.pos.y;               // truncation (:128)
-    add(p.ix, p.iy, p.sediment * s.soils[p.contains].equrate, p.contains);
-    particle_cascade(p.pos, 0);
-    add(p.ix, p.iy, p.volume * 0.015, AIR);                 // volumeFactor = 0.015 (:370)
-    seep(p.ix, p.iy);
-    water_cascade(p.ix, p.iy, p.spill);
-    return false;
-  }
-  SMX_DN void water_run(Water& p, bool toplevel) {           // SoilMachine.cpp:292-296 / water.h:258-262
-    while (true) {
-      while (true) {
-        if (!water_move(p)) break;
-        count(C_STEPS_WATER_ALL);
-        if (toplevel) count(C_STEPS_WATER_TOP);
-        if (!water_interact(p)) break;
-      }
-      if (!water_flood(p)) break;
-    }
-  }
-  SMX_DN void water_cascade(int ix, int iy, int spill) {     // WaterParticle::cascade water.h:151-283
-    count(C_WCASCADE_CALLS);
-    Pt sn[8];
-    int num = 0;
-    for (int dx = -1; dx <= 1; dx++)
-      for (int dy = -1; dy <= 1; dy++) {
-        if (dx == 0 && dy == 0) continue;
-        int nx = ix + dx, ny = iy + dy;
-        if (nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0) continue;
-        sn[num].x = nx; sn[num].y = ny; sn[num].h = height(nx, ny); num++;
-      }
-    sort_desc(sn, num);
-    for (int i = 0; i < num; i++) {
-      const int nx = sn[i].x, ny = sn[i].y;
-      const Sec& A = s.cells[cidx(ix, iy)];
-      const Sec& B = s.cells[cidx(nx, ny)];
-      const double whA = A.size, whB = B.size, fA = A.floor, fB = B.floor;   // 0 for empty columns
-      const double diff = (fA + whA - fB - whB) * (double)s.scale / 80.0;
-      if (diff == 0) continue;
-      const Sec& T = (diff > 0) ? A : B;
-      const int tx = (diff > 0) ? ix : nx, ty = (diff > 0) ? iy : ny;
-      const int bx = (diff > 0) ? nx : ix, by = (diff > 0) ? ny : iy;
-      if (T.type != AIR) continue;                          // (EMPTY != AIR: the reference cannot get here with NULL)
-      double transfer = fabs(diff) / 2.0;
-      const double wh = T.size;
-      transfer = (wh < transfer) ? wh : transfer;
-      if (transfer <= 0) continue;
-      bool recascade = false;
-      if (transfer == wh) {
-        remove(tx, ty, transfer);
-        count(C_NESTED);
-        Water q;
-        water_ctor(q);
-        const f2 d = {(float)bx - (float)tx, (float)by - (float)ty};
-        const f2 dn = normalize2(d);
-        const float s2 = sqrtf(2.0f);
-        q.speed = {s2 * dn.x, s2 * dn.y};
-        q.pos = {(float)tx, (float)ty};
-        q.spill = spill;
-        q.volume = transfer / 0.015;
-        water_run(q, false);
-      } else {
-        if (remove(tx, ty, transfer) != 0) recascade = true;
-        if (transfer > 0) recascade = true;
-        add(bx, by, transfer, AIR);
-        Sec& R = s.cells[cidx(bx, by)];
-        if (R.type != EMPTY) { R.sat = 1.0f; on_sat(bx, by); }
-      }
-      if (recascade && spill > 0) water_cascade(nx, ny, --spill);
-    }
-  }
-  SMX_DN void seep(int ix, int iy) {                         // WaterParticle::seep(vec2,..) water.h:285-333
-    Sec& cell = s.cells[cidx(ix, iy)];
-    if (cell.type == EMPTY) return;
+  SMX_D void seep(int ix, int iy) {                          // WaterParticle::seep(vec2,..) water.h:285-333
+    Sec& top = cell(ix, iy);
+    if (ab) return;
+    if (top.type == EMPTY) return;
     // walk top -> bottom; `t`/`pv` are either the inline cell record or pool nodes
-    Sec* t = &cell;
-    while (t != nullptr && t->prev != NIL) {
-      uint32_t pvi = t->prev;
+    Sec* t = &top;
+    while (t->prev != NIL) {
+      const uint32_t pvi = t->prev;
       Sec* pv = &s.pool[pvi];
-      const SoilP& param = s.soils[t->type];
-      const SoilP& nparam = s.soils[pv->type];
+      const SoilP& param = soils[t->type];
+      const SoilP& nparam = soils[pv->type];
       const double vol = t->size * t->sat * param.porosity;
       const double nevol = pv->size * (1.0 - pv->sat) * nparam.porosity;
       const double seepage = 1.0;
       const double transfer = (vol < nevol) ? vol : nevol;
       if (transfer > 0) {
+        pol.pre_write_node(s, pvi);
+        if (t != &top) pol.pre_write_node(s, (uint32_t)(t - s.pool));
         if (t->type == AIR) {
           // map.remove(ipos, ..) acts on the COLUMN top; if it pops, the node below the top moves into
           // the inline cell record: redirect pv when that node is the one we hold.
-          const uint32_t below_top = cell.prev;
+          const uint32_t below_top = top.prev;
           bool popped = false;
           remove(ix, iy, seepage * transfer, &popped);
-          if (popped && below_top == pvi) pv = &cell;
+          if (popped && below_top == pvi) pv = &top;
         } else {
           t->sat -= (seepage * transfer) / (t->size * param.porosity);
         }
@@ -536,28 +474,113 @@ struct Sim {
       t = pv;
     }
   }
+  // water.h:123-145 up to (and excluding) the WaterParticle::cascade call; true = cascade must follow
+  SMX_D bool water_flood_prelude(Water& p) {
+    if (p.volume < 0.01 || p.spill-- <= 0) return false;
+    n_floods++;
+    p.ix = (int)p.pos.x; p.iy = (int)p.pos.y;               // truncation (:128)
+    add(p.ix, p.iy, p.sediment * soils[p.contains].equrate, p.contains);
+    particle_cascade<0>(p.pos);
+    add(p.ix, p.iy, p.volume * 0.015, AIR);                 // volumeFactor = 0.015 (:370)
+    seep(p.ix, p.iy);
+    return !ab;
+  }
+  SMX_D void push_frame(Frame* st, int& depth, int ix, int iy, int spill) {   // entry of WaterParticle::cascade
+    n_wcasc++;
+    const Sorted sn = sorted_neighbours(ix, iy);
+    if (depth >= MAX_FRAMES) { n_overflow++; return; }      // unreachable: depth is bounded by the spill budget
+    Frame& f = st[depth++];
+    f.ix = ix; f.iy = iy; f.spill = spill; f.num = sn.num; f.i = 0; f.codes = sn.codes;
+  }
+  // Runs one WaterParticle to completion INCLUDING everything it spawns (SoilMachine.cpp:292-296, water.h:258-262),
+  // then drains the cascade frame stack. `start_with_particle` = false: only drain the frames already pushed.
+  SMX_D void water_drive(Water p, bool toplevel, bool start_with_particle, Frame* st, int& depth) {
+    bool have = start_with_particle;
+    while (true) {
+      if (have) {
+        while (true) {                                      // while(move && interact);
+          if (!water_move(p)) break;
+          n_steps_w_all++;
+          if (toplevel) n_steps_w_top++;
+          if (!water_interact(p)) break;
+        }
+        if (ab) return;
+        if (water_flood_prelude(p)) push_frame(st, depth, p.ix, p.iy, p.spill);   // :140
+        if (ab) return;
+        have = false;
+      }
+      if (depth == 0) return;
+      Frame& f = st[depth - 1];
+      if (f.i >= f.num) { depth--; continue; }
+      const int k = (f.codes >> (4 * f.i)) & 15;
+      f.i++;
+      const int ix = f.ix, iy = f.iy;
+      const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
+      const Sec& A = cell(ix, iy);
+      const Sec& B = cell(nx, ny);
+      if (ab) return;
+      const double whA = A.size, whB = B.size, fA = A.floor, fB = B.floor;   // 0 for empty columns (:194-214)
+      const double diff = (fA + whA - fB - whB) * (double)s.scale / 80.0;
+      if (diff == 0) continue;
+      const Sec& T = (diff > 0) ? A : B;
+      const int tx = (diff > 0) ? ix : nx, ty = (diff > 0) ? iy : ny;
+      const int bx = (diff > 0) ? nx : ix, by = (diff > 0) ? ny : iy;
+      if (T.type != AIR) continue;                          // :229 (EMPTY != AIR; the reference cannot reach here with NULL)
+      double transfer = fabs(diff) / 2.0;
+      const double wh = T.size;
+      transfer = (wh < transfer) ? wh : transfer;
+      if (transfer <= 0) continue;
+      if (transfer == wh) {                                 // :246-264 the whole water section leaves: nested particle
+        remove(tx, ty, transfer);
+        n_nested++;
+        int ry, rx;
+        pol.rand2(s, ry, rx);                               // 1st draw -> y, 2nd -> x (g++ evaluation order)
+        ry %= s.dimy; rx %= s.dimx;
+        water_init(p, rx, ry);
+        const f2 d = {(float)bx - (float)tx, (float)by - (float)ty};
+        const f2 dn = normalize2(d);
+        const float s2 = sqrtf(2.0f);
+        p.speed = {s2 * dn.x, s2 * dn.y};
+        p.pos = {(float)tx, (float)ty};
+        p.spill = f.spill;
+        p.volume = transfer / 0.015;
+        toplevel = false;
+        have = true;
+        if (ab) return;
+      } else {                                              // :266-276
+        bool recascade = false;
+        if (remove(tx, ty, transfer) != 0) recascade = true;
+        if (transfer > 0) recascade = true;
+        add(bx, by, transfer, AIR);
+        Sec& R = cell(bx, by);
+        if (ab) return;
+        if (R.type != EMPTY) { R.sat = 1.0f; on_sat(bx, by); }
+        if (recascade && f.spill > 0) {                     // :278-279 cascade(npos, --spill)
+          const int sp = --f.spill;
+          push_frame(st, depth, nx, ny, sp);
+        }
+        if (ab) return;
+      }
+    }
+  }
 
   // ---------------- WindParticle wind.h:11-138 ----------------
-  SMX_D void wind_ctor(Wind& p) {                            // wind.h:13-22
-    int ry = rand_() % s.dimy;
-    int rx = rand_() % s.dimx;
+  SMX_D void wind_init(Wind& p, int rx, int ry) {            // wind.h:13-22
     p.pos = {(float)rx, (float)ry};
     p.speed = {-2.f, 0.f, 1.f};
     p.sediment = 0.0; p.height = 0.0; p.sheight = 0.0;
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    p.n = {0.f, 0.f, 0.f};
     p.surface = surface(p.ix, p.iy);
-    p.param = s.soils[p.surface];
-    p.contains = p.param.transports;
+    p.contains = soils[p.surface].transports;
   }
   SMX_D bool wind_move(Wind& p) {                            // wind.h:54-92
     const f3 pspeed = {-2.f, 0.f, 1.f};
     const double gravity = 0.25, winddominance = 0.2, windfriction = 0.8;
-    if (s.soils[p.contains].suspension == 0.0) return false;
+    if (soils[p.contains].suspension == 0.0) return false;
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    p.n = normal(p.ix, p.iy);
+    const f3 n = normal(p.ix, p.iy);
     p.surface = surface(p.ix, p.iy);
-    p.param = s.soils[p.surface];
+    if (ab) return false;
     const size_t fi = fidx(p.ix, p.iy);
     s.windfreq[fi] = (float)(0.5 * s.windfreq[fi] + 0.5f);              // wind.h:49-52
     p.sheight = height(p.ix, p.iy) * (float)s.scale / 80.0f;
@@ -565,7 +588,7 @@ struct Sim {
     if (p.height > p.sheight) {
       p.speed.y = (float)(p.speed.y - gravity);
     } else {
-      const f3 c = cross3(cross3(p.speed, p.n), p.n);
+      const f3 c = cross3(cross3(p.speed, n), n);
       p.speed = {mixd(p.speed.x, c.x, windfriction), mixd(p.speed.y, c.y, windfriction), mixd(p.speed.z, c.z, windfriction)};
     }
     p.speed = {mixd(p.speed.x, pspeed.x, winddominance), mixd(p.speed.y, pspeed.y, winddominance),
@@ -578,26 +601,30 @@ struct Sim {
   }
   SMX_D bool wind_interact(Wind& p) {                        // wind.h:94-136
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-    if (p.height <= height_bilinear(p.pos) * (float)s.scale / 80.0f) {
-      if (p.param.transports == p.contains) {
+    const SoilP& param = soils[p.surface];
+    const double hb = height_bilinear(p.pos);
+    if (ab) return false;
+    if (p.height <= hb * (float)s.scale / 80.0f) {
+      if (param.transports == p.contains) {
         const double force = sqrtf(dot3(p.speed, p.speed)) * (height(nx, ny) - p.height) * (float)s.scale / 80.0f * (1.0f - p.sediment);
-        const double diff = remove(p.ix, p.iy, p.param.suspension * force);
-        p.sediment += (p.param.suspension * force - diff);
-        particle_cascade(f2{(float)p.ix, (float)p.iy}, 1);
+        if (ab) return false;
+        const double diff = remove(p.ix, p.iy, param.suspension * force);
+        p.sediment += (param.suspension * force - diff);
+        particle_cascade<1>(f2{(float)p.ix, (float)p.iy});
       }
-    } else if (p.param.suspension > 0.0) {
-      p.sediment -= s.soils[p.contains].suspension * p.sediment;
-      add(nx, ny, 0.5f * s.soils[p.contains].suspension * p.sediment, p.contains);
-      add(p.ix, p.iy, 0.5f * s.soils[p.contains].suspension * p.sediment, p.contains);
-      particle_cascade(f2{(float)p.ix, (float)p.iy}, 1);
-      particle_cascade(f2{(float)nx, (float)ny}, 1);
+    } else if (param.suspension > 0.0) {
+      p.sediment -= soils[p.contains].suspension * p.sediment;
+      add(nx, ny, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
+      add(p.ix, p.iy, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
+      particle_cascade<1>(f2{(float)p.ix, (float)p.iy});
+      particle_cascade<1>(f2{(float)nx, (float)ny});
     }
-    return true;
+    return !ab;
   }
-  SMX_D void wind_run(Wind& p) {
+  SMX_D void wind_run(Wind& p) {                             // SoilMachine.cpp:305-306
     while (true) {
       if (!wind_move(p)) break;
-      count(C_STEPS_WIND);
+      n_steps_wind++;
       if (!wind_interact(p)) break;
     }
   }

@@ -1,0 +1,39 @@
+// soil_serial.h -- access policy of the exact SERIAL engine: one walker, reference order, direct access.
+#pragma once
+#include "soil_core.h"
+
+namespace smx {
+
+struct SerialPolicy {
+  unsigned long long live;       // live sections, cached in a register for the kernel's lifetime
+  uint32_t nfree;                // entries on the free-node stack
+  SMX_D explicit SerialPolicy(const DevState& s) : live(s.ctr[C_LIVE_SECTIONS]), nfree(*s.free_count) {}
+  SMX_D void finish(const DevState& s) { s.ctr[C_LIVE_SECTIONS] = live; *s.free_count = nfree; }
+
+  SMX_D bool touch(const DevState&, size_t) { return true; }
+  SMX_D void pre_write_node(const DevState&, uint32_t) {}
+  SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (!(v & f)) s.flags[c] = v | f; }
+  SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (v & f) s.flags[c] = v & (uint8_t)~f; }
+  // secpool::get / unget (layermap.h:89-111): get() fails exactly when live sections == capacity
+  SMX_D bool can_get(const DevState& s) const { return live < s.pool_capacity; }
+  SMX_D void live_add(const DevState&, int d) { live += (long long)d; }
+  SMX_D uint32_t node_alloc(const DevState& s) {
+    if (nfree == 0) return NIL;
+    nfree--;
+    return s.freelist[nfree];
+  }
+  SMX_D void node_free(const DevState& s, uint32_t e) { s.freelist[nfree] = e; nfree++; }
+  SMX_D int rand1(const DevState& s) {          // glibc rand()
+    RandState& r = *s.rnd;
+    const uint32_t i = r.idx;
+    const uint32_t v = r.ring[i % 31] + r.ring[(i - 3) % 31];
+    r.ring[i % 31] = v;
+    r.idx = i + 1;
+    r.calls++;
+    return (int)(v >> 1);
+  }
+  SMX_D void rand2(const DevState& s, int& first, int& second) { first = rand1(s); second = rand1(s); }
+  SMX_D void add_counter(const DevState& s, int which, unsigned long long v) { if (v) s.ctr[which] += v; }
+};
+
+}  // namespace smx

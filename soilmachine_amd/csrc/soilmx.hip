@@ -21,6 +21,7 @@
 
 #include "../../include/soilmx.h"
 #include "soil_core.h"
+#include "soil_serial.h"
 #include "soil_noise.h"
 
 using namespace smx;
@@ -31,24 +32,45 @@ static_assert(sizeof(Sec) == 32, "Sec must be 32 bytes");
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+// soil table -> LDS (<= 14 KB); every lane helps, then lane 0 walks
+#define SMX_LOAD_SOILS(sh)                                                                          \
+  __shared__ SoilP sh[MAX_SOILS];                                                                   \
+  for (uint32_t i_ = threadIdx.x; i_ < s.nsoils * (sizeof(SoilP) / 4); i_ += blockDim.x)            \
+    reinterpret_cast<uint32_t*>(sh)[i_] = reinterpret_cast<const uint32_t*>(s.soils)[i_];           \
+  __syncthreads();
+
 __global__ void __launch_bounds__(64) k_water_serial(DevState s, int n) {
+  SMX_LOAD_SOILS(sh)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Sim sim(s);
-  for (int i = 0; i < n; i++) {
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, sh, pol);
+  Frame st[MAX_FRAMES];
+  int depth = 0;
+  for (int i = 0; i < n; i++) {                            // SoilMachine.cpp:288-298
+    int ry, rx;
+    pol.rand2(s, ry, rx);                                  // water.h:13, g++ order: 1st draw -> y, 2nd -> x
     Water p;
-    sim.water_ctor(p);
-    sim.water_run(p, true);
+    sim.water_init(p, rx % s.dimx, ry % s.dimy);
+    sim.water_drive(p, true, true, st, depth);
   }
+  sim.flush_counters();
+  pol.finish(s);
 }
 
 __global__ void __launch_bounds__(64) k_wind_serial(DevState s, int n) {
+  SMX_LOAD_SOILS(sh)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Sim sim(s);
-  for (int i = 0; i < n; i++) {
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, sh, pol);
+  for (int i = 0; i < n; i++) {                            // SoilMachine.cpp:304-307
+    int ry, rx;
+    pol.rand2(s, ry, rx);                                  // wind.h:15
     Wind p;
-    sim.wind_ctor(p);
+    sim.wind_init(p, rx % s.dimx, ry % s.dimy);
     sim.wind_run(p);
   }
+  sim.flush_counters();
+  pol.finish(s);
 }
 
 // One thread per cell, 256 consecutive cells (cell order) per block = 4 level-0 bitmap words.
@@ -80,22 +102,32 @@ __global__ void __launch_bounds__(256) k_grid_classify(DevState s) {
 }
 
 __global__ void __launch_bounds__(64) k_grid_serial(DevState s) {
+  SMX_LOAD_SOILS(sh)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Sim sim(s);
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, sh, pol);
   sim.grid_mode = true;
+  Frame st[MAX_FRAMES];
+  int depth = 0;
   const size_t n = (size_t)s.dimx * s.dimy;
   size_t c = sim.next_active(0);
   unsigned long long visited = 0;
+  Water dummy;
+  dummy.pos = {0.f, 0.f}; dummy.speed = {0.f, 0.f}; dummy.volume = 0.0; dummy.sediment = 0.0; dummy.evaprate = 0.0;
+  dummy.spill = 0; dummy.ix = dummy.iy = 0; dummy.friction = 0.f; dummy.surface = dummy.contains = 0;
   while (c < n) {
     const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
-    sim.seep(x, y);                          // water.h:339
-    sim.water_cascade(x, y, 3);              // water.h:340
+    sim.seep(x, y);                                        // water.h:339
+    sim.push_frame(st, depth, x, y, 3);                    // water.h:340 WaterParticle::cascade(ivec2(x,y), .., 3)
+    sim.water_drive(dummy, false, false, st, depth);
     visited++;
     c = sim.next_active(c + 1);
   }
   // every non-active cell still "calls" WaterParticle::cascade once in the reference (counter parity)
-  s.ctr[C_WCASCADE_CALLS] += n - visited;
-  s.ctr[C_GRID_ACTIVE] += visited;
+  sim.n_wcasc += n - visited;
+  sim.flush_counters();
+  pol.add_counter(s, C_GRID_ACTIVE, visited);
+  pol.finish(s);
 }
 
 __global__ void __launch_bounds__(256) k_map_frequency(float* __restrict__ freq, const float* __restrict__ track, size_t n4, size_t n) {
@@ -183,30 +215,41 @@ __global__ void __launch_bounds__(256) k_normals(DevState s, float* __restrict__
   const size_t n = (size_t)s.dimx * s.dimy;
   const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= n) return;
-  Sim sim(s);
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, s.soils, pol);
   f3 v = sim.normal((int)(c / s.dimy), (int)(c % s.dimy));
   out[3 * c] = v.x; out[3 * c + 1] = v.y; out[3 * c + 2] = v.z;
 }
 __global__ void __launch_bounds__(256) k_bilinear(DevState s, const float* __restrict__ pos, int n, double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  Sim sim(s);
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, s.soils, pol);
   out[i] = sim.height_bilinear(f2{pos[2 * i], pos[2 * i + 1]});
 }
 
 // single-operation kernels behind the point API (host-driven Layermap::add/remove etc.)
 struct PointOp { int op; int x, y; double a; uint32_t type; float px, py; int k; };
 __global__ void __launch_bounds__(64) k_point_op(DevState s, PointOp o, double* out) {
+  SMX_LOAD_SOILS(sh)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Sim sim(s);
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, sh, pol);
+  Frame st[MAX_FRAMES];
+  int depth = 0;
+  Water dummy;
+  dummy.pos = {0.f, 0.f}; dummy.speed = {0.f, 0.f}; dummy.volume = 0.0; dummy.sediment = 0.0; dummy.evaprate = 0.0;
+  dummy.spill = 0; dummy.ix = dummy.iy = 0; dummy.friction = 0.f; dummy.surface = dummy.contains = 0;
   switch (o.op) {
     case 0: sim.add(o.x, o.y, o.a, o.type); break;
     case 1: *out = sim.remove(o.x, o.y, o.a); break;
-    case 2: sim.particle_cascade(f2{o.px, o.py}, o.k); break;
-    case 3: sim.water_cascade(o.x, o.y, o.k); break;
+    case 2: if (o.k > 0) sim.template particle_cascade<1>(f2{o.px, o.py}); else sim.template particle_cascade<0>(f2{o.px, o.py}); break;
+    case 3: sim.push_frame(st, depth, o.x, o.y, o.k); sim.water_drive(dummy, false, false, st, depth); break;
     case 4: sim.seep(o.x, o.y); break;
-    case 5: *out = (double)sim.rand_(); break;
+    case 5: *out = (double)pol.rand1(s); break;
   }
+  sim.flush_counters();
+  pol.finish(s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,196 @@
+// hostsim -- TEST-ONLY host build of the DEVICE sources (soilmachine_amd/csrc/soil_core.h + policies).
+//
+// The GPU is only reachable through short, metered gpurun calls, so the kernel logic (state machine of the
+// recursion-free water cascade, column primitives, speculative protocol) is unit-tested here by compiling the
+// very same headers with g++ and running the "kernels" as plain loops. The product never loads this library:
+// it lives under tests/, is built by tests/hostsim_lib.py, and soilmachine_amd/ has no reference to it.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#define SMX_D inline
+#include "../../soilmachine_amd/csrc/soil_core.h"
+#include "../../soilmachine_amd/csrc/soil_serial.h"
+
+using namespace smx;
+
+struct hs_ctx {
+  DevState d;
+  std::vector<Sec> cells, pool;
+  std::vector<uint32_t> freelist;
+  uint32_t free_count;
+  std::vector<uint8_t> flags;
+  std::vector<float> wfreq, wtrack, windfreq;
+  std::vector<SoilP> soils;
+  RandState rnd;
+  unsigned long long ctr[C_COUNT];
+  std::vector<unsigned long long> a0, a1, a2;
+  size_t n;
+};
+
+static void rebind(hs_ctx* c) {
+  c->d.cells = c->cells.data(); c->d.pool = c->pool.data(); c->d.freelist = c->freelist.data();
+  c->d.free_count = &c->free_count; c->d.flags = c->flags.data();
+  c->d.wfreq = c->wfreq.data(); c->d.wtrack = c->wtrack.data(); c->d.windfreq = c->windfreq.data();
+  c->d.soils = c->soils.data(); c->d.nsoils = (uint32_t)c->soils.size(); c->d.rnd = &c->rnd; c->d.ctr = c->ctr;
+  c->d.active = c->a0.data(); c->d.active1 = c->a1.data(); c->d.active2 = c->a2.data();
+}
+
+extern "C" {
+
+hs_ctx* hs_create(int dimx, int dimy, int scale, uint64_t cap) {
+  hs_ctx* c = new hs_ctx();
+  memset(&c->d, 0, sizeof(c->d));
+  c->d.dimx = dimx; c->d.dimy = dimy; c->d.scale = scale; c->d.pool_capacity = cap;
+  c->n = (size_t)dimx * dimy;
+  c->cells.resize(c->n); c->pool.resize(cap); c->freelist.resize(cap); c->flags.assign(c->n, 0);
+  for (size_t i = 0; i < c->n; i++) { Sec& s = c->cells[i]; s.size = s.floor = s.sat = 0; s.type = EMPTY; s.prev = NIL; }
+  for (uint64_t i = 0; i < cap; i++) c->freelist[i] = (uint32_t)(cap - 1 - i);
+  c->free_count = (uint32_t)cap;
+  c->wfreq.assign(c->n, 0); c->wtrack.assign(c->n, 0); c->windfreq.assign(c->n, 0);
+  memset(c->ctr, 0, sizeof(c->ctr));
+  size_t nw0 = (c->n + 63) >> 6, nw1 = (nw0 + 63) >> 6, nw2 = (nw1 + 63) >> 6;
+  c->a0.assign(nw0 + 64, 0); c->a1.assign(nw1 + 64, 0); c->a2.assign(nw2 + 64, 0);
+  c->soils.resize(1);
+  memset(&c->soils[0], 0, sizeof(SoilP)); c->soils[0].porosity = 1.0f;
+  rebind(c);
+  return c;
+}
+void hs_destroy(hs_ctx* c) { delete c; }
+void hs_set_soils(hs_ctx* c, const SoilP* s, int n) { c->soils.assign(s, s + n); rebind(c); }
+void hs_srand(hs_ctx* c, unsigned seed) {
+  RandState& r = c->rnd;
+  if (seed == 0) seed = 1;
+  int32_t word = (int32_t)seed;
+  r.ring[0] = (uint32_t)word;
+  for (int i = 1; i < 31; i++) {
+    long hi = word / 127773, lo = word % 127773;
+    word = (int32_t)(16807 * lo - 2836 * hi);
+    if (word < 0) word += 2147483647;
+    r.ring[i] = (uint32_t)word;
+  }
+  uint32_t idx = 34;
+  for (int i = 0; i < 310; i++) { uint32_t v = r.ring[idx % 31] + r.ring[(idx - 3) % 31]; r.ring[idx % 31] = v; idx++; }
+  r.idx = idx; r.calls = 0;
+}
+void hs_rand_advance(hs_ctx* c, uint64_t nd) {
+  RandState& r = c->rnd;
+  for (uint64_t i = 0; i < nd; i++) { uint32_t v = r.ring[r.idx % 31] + r.ring[(r.idx - 3) % 31]; r.ring[r.idx % 31] = v; r.idx++; }
+  r.calls += nd;
+}
+int hs_import(hs_ctx* c, const uint32_t* count, const uint32_t* type, const double* size, const double* floor,
+              const double* sat, const float* wfreq, const float* wtrack, const float* windfreq) {
+  size_t off = 0; uint32_t used = 0; unsigned long long live = 0;
+  for (size_t i = 0; i < c->n; i++) {
+    Sec cell; cell.size = cell.floor = cell.sat = 0; cell.type = EMPTY; cell.prev = NIL;
+    uint32_t pv = NIL; c->flags[i] = 0;
+    for (uint32_t j = 0; j < count[i]; j++, off++, live++) {
+      Sec r; r.size = size[off]; r.floor = floor[off]; r.sat = sat[off]; r.type = type[off]; r.prev = pv;
+      if (r.sat != 0.0) c->flags[i] |= F_SAT;
+      if (j == count[i] - 1) cell = r; else { pv = used; c->pool[used++] = r; }
+    }
+    if (cell.type == AIR) c->flags[i] |= F_AIR;
+    c->cells[i] = cell;
+  }
+  uint64_t cap = c->d.pool_capacity; uint32_t nf = 0;
+  for (uint64_t i = cap; i-- > used;) c->freelist[nf++] = (uint32_t)i;
+  c->free_count = nf; c->ctr[C_LIVE_SECTIONS] = live;
+  if (wfreq) c->wfreq.assign(wfreq, wfreq + c->n);
+  if (wtrack) c->wtrack.assign(wtrack, wtrack + c->n);
+  if (windfreq) c->windfreq.assign(windfreq, windfreq + c->n);
+  rebind(c);
+  return 0;
+}
+uint64_t hs_num_sections(hs_ctx* c) { return c->ctr[C_LIVE_SECTIONS]; }
+void hs_export(hs_ctx* c, uint32_t* count, uint32_t* type, double* size, double* floor, double* sat,
+               float* wfreq, float* wtrack, float* windfreq) {
+  size_t off = 0; std::vector<const Sec*> col;
+  for (size_t i = 0; i < c->n; i++) {
+    col.clear();
+    if (c->cells[i].type != EMPTY) { const Sec* t = &c->cells[i]; while (true) { col.push_back(t); if (t->prev == NIL) break; t = &c->pool[t->prev]; } }
+    count[i] = (uint32_t)col.size();
+    for (size_t k = col.size(); k-- > 0; off++) { type[off] = col[k]->type; size[off] = col[k]->size; floor[off] = col[k]->floor; sat[off] = col[k]->sat; }
+  }
+  memcpy(wfreq, c->wfreq.data(), c->n * 4); memcpy(wtrack, c->wtrack.data(), c->n * 4); memcpy(windfreq, c->windfreq.data(), c->n * 4);
+}
+void hs_counters(hs_ctx* c, unsigned long long* out, uint64_t* rand_calls) { memcpy(out, c->ctr, sizeof(c->ctr)); *rand_calls = c->rnd.calls; }
+
+// ---- the "kernels" (bodies mirror soilmx.hip; keep in sync) ----
+void hs_water(hs_ctx* c, int n) {
+  const DevState& s = c->d;
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, s.soils, pol);
+  Frame st[MAX_FRAMES]; int depth = 0;
+  for (int i = 0; i < n; i++) {
+    int ry, rx; pol.rand2(s, ry, rx);
+    Water p; sim.water_init(p, rx % s.dimx, ry % s.dimy);
+    sim.water_drive(p, true, true, st, depth);
+  }
+  sim.flush_counters(); pol.finish(s);
+}
+void hs_wind(hs_ctx* c, int n) {
+  const DevState& s = c->d;
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, s.soils, pol);
+  for (int i = 0; i < n; i++) {
+    int ry, rx; pol.rand2(s, ry, rx);
+    Wind p; sim.wind_init(p, rx % s.dimx, ry % s.dimy);
+    sim.wind_run(p);
+  }
+  sim.flush_counters(); pol.finish(s);
+}
+void hs_grid(hs_ctx* c) {
+  const DevState& s = c->d;
+  const size_t n = c->n;
+  std::fill(c->a0.begin(), c->a0.end(), 0); std::fill(c->a1.begin(), c->a1.end(), 0); std::fill(c->a2.begin(), c->a2.end(), 0);
+  for (size_t cc = 0; cc < n; cc++) {                       // k_grid_classify
+    const int x = (int)(cc / s.dimy), y = (int)(cc % s.dimy);
+    bool act = (s.flags[cc] & F_SAT) != 0;
+    for (int dx = -1; dx <= 1 && !act; dx++) for (int dy = -1; dy <= 1; dy++) {
+      int nx = x + dx, ny = y + dy; if (nx < 0 || ny < 0 || nx >= s.dimx || ny >= s.dimy) continue;
+      if (s.flags[(size_t)nx * s.dimy + ny] & F_AIR) { act = true; break; }
+    }
+    if (act) { c->a0[cc >> 6] |= 1ull << (cc & 63); c->a1[cc >> 12] |= 1ull << ((cc >> 6) & 63); c->a2[cc >> 18] |= 1ull << ((cc >> 12) & 63); }
+  }
+  SerialPolicy pol(s);
+  Sim<SerialPolicy> sim(s, s.soils, pol);
+  sim.grid_mode = true;
+  Frame st[MAX_FRAMES]; int depth = 0;
+  size_t cc = sim.next_active(0);
+  unsigned long long visited = 0;
+  Water dummy; memset(&dummy, 0, sizeof(dummy));
+  while (cc < n) {
+    const int x = (int)(cc / s.dimy), y = (int)(cc % s.dimy);
+    sim.seep(x, y);
+    sim.push_frame(st, depth, x, y, 3);
+    sim.water_drive(dummy, false, false, st, depth);
+    visited++;
+    cc = sim.next_active(cc + 1);
+  }
+  sim.n_wcasc += n - visited;
+  sim.flush_counters();
+  pol.add_counter(s, C_GRID_ACTIVE, visited);
+  pol.finish(s);
+}
+void hs_freq(hs_ctx* c) {
+  const float lrate = 0.01f, K = 50.0f;
+  for (size_t i = 0; i < c->n; i++) c->wfreq[i] = (1.0f - lrate) * c->wfreq[i] + lrate * K * c->wtrack[i] / (1.0f + K * c->wtrack[i]);
+  std::fill(c->wtrack.begin(), c->wtrack.end(), 0.0f);
+}
+void hs_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind) {
+  if (dowater) { hs_water(c, nwater); hs_grid(c); }
+  if (dowind) hs_wind(c, nwind);
+  if (dowater) hs_freq(c);
+}
+void hs_add(hs_ctx* c, int x, int y, double size, uint32_t type) {
+  const DevState& s = c->d; SerialPolicy pol(s); Sim<SerialPolicy> sim(s, s.soils, pol);
+  sim.add(x, y, size, type); sim.flush_counters(); pol.finish(s);
+}
+double hs_remove(hs_ctx* c, int x, int y, double h) {
+  const DevState& s = c->d; SerialPolicy pol(s); Sim<SerialPolicy> sim(s, s.soils, pol);
+  double r = sim.remove(x, y, h); sim.flush_counters(); pol.finish(s); return r;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""ctypes wrapper of tests/hostsim (the device sources compiled for the host -- TEST INFRASTRUCTURE ONLY)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from soilmachine_amd.snapshot import Snapshot
+from soilmachine_amd.soilfile import soils_array
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libhostsim.so")
+SRC = [os.path.join(HERE, "hostsim.cpp")] + [os.path.join(ROOT, "soilmachine_amd", "csrc", f)
+                                              for f in ("soil_core.h", "soil_serial.h", "soil_spec.h")]
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [p for p in SRC if os.path.exists(p)]
+        if not os.path.exists(LIB) or any(os.path.getmtime(p) > os.path.getmtime(LIB) for p in srcs):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB, SRC[0]])
+        L = C.CDLL(LIB)
+        vp = C.c_void_p
+        L.hs_create.restype = vp
+        L.hs_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64]
+        L.hs_destroy.argtypes = [vp]
+        L.hs_set_soils.argtypes = [vp, vp, C.c_int]
+        L.hs_srand.argtypes = [vp, C.c_uint]
+        L.hs_rand_advance.argtypes = [vp, C.c_uint64]
+        L.hs_import.argtypes = [vp] + [vp] * 8
+        L.hs_num_sections.argtypes = [vp]; L.hs_num_sections.restype = C.c_uint64
+        L.hs_export.argtypes = [vp] + [vp] * 8
+        L.hs_counters.argtypes = [vp, vp, vp]
+        for f in ("hs_water", "hs_wind"):
+            getattr(L, f).argtypes = [vp, C.c_int]
+        for f in ("hs_grid", "hs_freq"):
+            getattr(L, f).argtypes = [vp]
+        L.hs_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.hs_add.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_uint32]
+        L.hs_remove.argtypes = [vp, C.c_int, C.c_int, C.c_double]; L.hs_remove.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+CTR = ["steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
+       "cascade_transfers", "wcascade_calls", "grid_active_cells", "pool_overflow", "live_sections"]
+
+
+class HostSim:
+    def __init__(self, cfg, dimx, dimy, pool=None, seed=0):
+        self.L = lib()
+        self.cfg, self.dimx, self.dimy = cfg, dimx, dimy
+        self.pool = int(pool if pool is not None else max(8 * dimx * dimy, 1 << 20))
+        self.h = self.L.hs_create(dimx, dimy, cfg.SCALE, self.pool)
+        self._soils = soils_array(cfg)
+        self.L.hs_set_soils(self.h, _p(self._soils), len(self._soils))
+        self.L.hs_srand(self.h, seed)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.hs_destroy(self.h); self.h = None
+
+    def load(self, s: Snapshot, advance_rand=True):
+        self.L.hs_import(self.h, _p(s.count), _p(s.type), _p(s.size), _p(s.floor), _p(s.sat), _p(s.wfreq), _p(s.wtrack), _p(s.windfreq))
+        if advance_rand:
+            self.L.hs_rand_advance(self.h, s.rand_calls)
+
+    def counters(self):
+        a = np.zeros(len(CTR), np.uint64); rc = C.c_uint64()
+        self.L.hs_counters(self.h, _p(a), C.byref(rc))
+        d = {k: int(v) for k, v in zip(CTR, a)}
+        d["rand_calls"] = int(rc.value)
+        d["pool_free"] = self.pool - d["live_sections"]
+        return d
+
+    def snapshot(self) -> Snapshot:
+        nc, ns = self.dimx * self.dimy, int(self.L.hs_num_sections(self.h))
+        count = np.zeros(nc, np.uint32); ty = np.zeros(ns, np.uint32)
+        size = np.zeros(ns); floor = np.zeros(ns); sat = np.zeros(ns)
+        wf = np.zeros(nc, np.float32); wt = np.zeros(nc, np.float32); wi = np.zeros(nc, np.float32)
+        self.L.hs_export(self.h, _p(count), _p(ty), _p(size), _p(floor), _p(sat), _p(wf), _p(wt), _p(wi))
+        c = self.counters()
+        return Snapshot(self.dimx, self.dimy, self.cfg.SCALE, len(self.cfg.soils), c["rand_calls"], c["pool_free"],
+                        count, ty, size, floor, sat, wf, wt, wi)
+
+    def tick(self, nwater, nwind, dowater=True, dowind=True):
+        self.L.hs_tick(self.h, nwater, nwind, int(dowater), int(dowind))
