@@ -29,7 +29,9 @@ class Counters(C.Structure):
         "spec_rounds", "spec_aborts")] + [("reserved", C.c_uint64 * 2)]
 
     def as_dict(self) -> dict:
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        d["spec_fallbacks"], d["spec_executed"] = int(self.reserved[0]), int(self.reserved[1])
+        return d
 
 
 class Timing(C.Structure):

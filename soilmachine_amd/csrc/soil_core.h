@@ -307,6 +307,7 @@ struct Sim {
   // Layermap::add(pos, pool.get(size, type)) (layermap.h:230-307 + :89-103)
   SMX_D void add(int x, int y, double size, uint32_t type) {
     if (ab) return;
+    if constexpr (P::READ_ONLY) { (void)cell(x, y); return; }   // scout: footprint only, never writes
     Sec& c = cell(x, y);
     if (ab) return;
     // pool.get(): the reference takes a node for EVERY get (even if add() merges and returns it at once),
@@ -330,6 +331,7 @@ struct Sim {
   SMX_D double remove(int x, int y, double h, bool* popped = nullptr) {
     if (popped) *popped = false;
     if (ab) return 0.0;
+    if constexpr (P::READ_ONLY) { (void)cell(x, y); return 0.0; }
     Sec& c = cell(x, y);
     if (ab) return 0.0;
     if (c.type == EMPTY) return 0.0;
@@ -395,7 +397,8 @@ struct Sim {
     if (ab) return false;
     p.evaprate = 0.01;
     const size_t fi = fidx(p.ix, p.iy);
-    s.wtrack[fi] = (float)((double)s.wtrack[fi] + p.volume);            // updatefrequency :348-351
+    if constexpr (!P::READ_ONLY)
+      s.wtrack[fi] = (float)((double)s.wtrack[fi] + p.volume);          // updatefrequency :348-351
     const float fr = s.wfreq[fi];
     p.friction = soils[p.surface].friction * (1.0f - fr);
     p.evaprate = p.evaprate * (double)(1.0f - 0.2f * fr);
@@ -505,6 +508,16 @@ struct Sim {
           if (!water_interact(p)) break;
         }
         if (ab) return;
+        if constexpr (P::READ_ONLY) {                       // scout: claim where a flood would act, then stop
+          const int fx = (int)p.pos.x, fy = (int)p.pos.y;
+          for (int dx = -2; dx <= 2; dx++)
+            for (int dy = -2; dy <= 2; dy++) {
+              const int nx = fx + dx, ny = fy + dy;
+              if (nx < 0 || ny < 0 || nx >= s.dimx || ny >= s.dimy) continue;
+              (void)cell(nx, ny);
+            }
+          return;
+        }
         if (water_flood_prelude(p)) push_frame(st, depth, p.ix, p.iy, p.spill);   // :140
         if (ab) return;
         have = false;
@@ -582,7 +595,8 @@ struct Sim {
     p.surface = surface(p.ix, p.iy);
     if (ab) return false;
     const size_t fi = fidx(p.ix, p.iy);
-    s.windfreq[fi] = (float)(0.5 * s.windfreq[fi] + 0.5f);              // wind.h:49-52
+    if constexpr (!P::READ_ONLY)
+      s.windfreq[fi] = (float)(0.5 * s.windfreq[fi] + 0.5f);            // wind.h:49-52
     p.sheight = height(p.ix, p.iy) * (float)s.scale / 80.0f;
     if (p.height < p.sheight) p.height = p.sheight;
     if (p.height > p.sheight) {

@@ -1,0 +1,561 @@
+// soil_spec.h -- the SPECULATIVE exact engine: particles of one phase run concurrently IN PLACE, yet the
+// result is bit-identical to the reference's sequential order (SoilMachine.cpp:287-307).
+//
+// Idea (DESIGN.md "Speculative engine"): the reference is sequential because particle i+1 sees what particle i
+// wrote. Two particles commute exactly when their cell footprints are disjoint, and footprints are thin curves,
+// so at 4096^2 the conflict DAG of a 1000-particle phase is ~20 levels deep (oracle/soil_oracle.cpp so_dep_*).
+// We execute level by level without knowing the levels in advance:
+//   * stamp[cell]  : id+1 of the last particle that touched the cell in this phase (0 = nobody). Touching a
+//                    cell = winning a CAS on its stamp; the first touch snapshots everything the particle may
+//                    change there (32-byte top-section record, track / frequency floats, flag byte) into the
+//                    particle's undo log. Within one kernel a cell's data is only ever accessed by the ONE
+//                    particle that holds its stamp -> plain loads/stores, visibility by kernel boundaries only.
+//   * forwarding   : a particle may take over a cell from a LOWER particle that finished in an EARLIER round
+//                    (it then sees that particle's writes, as the sequential order demands) and records the
+//                    dependency; it must never read a cell last touched by a HIGHER particle -> it flags that
+//                    particle (kill) and gives up for this round.
+//   * claim[cell]  : lowest still-pending particle that is expected to need the cell (from a read-only scout
+//                    run and from the footprint of its previous attempts). A particle yields at cells claimed
+//                    by a lower pending particle, so the lower id always wins a conflict (deterministic
+//                    reservations) and every round completes one full level of the conflict DAG.
+//   * boundary     : between rounds one workgroup computes the kill closure (flags, dependencies, rand()
+//                    offsets), rolls killed particles back in DESCENDING id order, commits the finished
+//                    prefix and rebuilds the pending list.
+//   * rand()       : spawn draws are the phase's stream at offset 2*(id + nested particles of lower ids); the
+//                    nested count of unfinished lower particles is speculated to be 0 and validated at every
+//                    boundary.
+// Progress: the lowest pending particle can only be stopped by higher particles, which yield to its claims;
+// the host falls back to the serial walker if the committed prefix stalls.
+#pragma once
+#include "soil_core.h"
+
+#ifdef SMX_HOSTSIM
+#define SMX_A_LOAD(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define SMX_A_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define SMX_A_ADD(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define SMX_A_MIN(p, v) smx::host_atomic_min((p), (v))
+namespace smx {
+inline uint32_t host_atomic_min(uint32_t* p, uint32_t v) {
+  uint32_t o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return o;
+}
+inline uint32_t host_atomic_cas(uint32_t* p, uint32_t expected, uint32_t desired) {
+  __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return expected;
+}
+}  // namespace smx
+#define SMX_A_CAS(p, e, d) smx::host_atomic_cas((p), (e), (d))
+#else
+#define SMX_A_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SMX_A_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SMX_A_ADD(p, v) atomicAdd((p), (v))
+#define SMX_A_MIN(p, v) atomicMin((p), (v))
+#define SMX_A_CAS(p, e, d) atomicCAS((p), (e), (d))
+#endif
+
+namespace smx {
+
+constexpr uint32_t ST_PENDING = 0, ST_DONE_NEW = 1, ST_DONE_OLD = 2, ST_COMMITTED = 3;
+constexpr uint32_t POISON = 0xFFFFFFFEu;      // stamp of a cell released by a particle that aborted in this round
+constexpr uint32_t NOCLAIM = 0xFFFFFFFFu;
+constexpr uint32_t NODE_ENTRY = 0x80000000u;  // log entry describes pool node (cell & 0x7fffffff), not a cell
+constexpr int LOG_CHUNK = 512;                // log entries per arena chunk
+constexpr int MAX_CHUNKS = 1024;              // chunks per particle (524288 touched cells)
+constexpr int MAX_DEPS = 28;
+constexpr int MAX_NODELOG = 2048;             // node allocations / frees per particle attempt
+constexpr int SPEC_NCTR = 9;
+constexpr uint32_t SCOUT_CAP = 16384;         // cells one scouted footprint can hold (longer ones are truncated)
+
+struct alignas(64) SpecLog {                  // undo record of one touched cell (or one modified pool node)
+  uint32_t cell, prev;                        // cell index, stamp value it replaced
+  Sec rec;                                    // the 32-byte record at first touch
+  float wtrack, windfreq;
+  uint32_t flags, pad;
+};
+
+struct SpecPart {                             // one particle of the phase
+  uint32_t status, kill, aborted, fail_cell;
+  uint32_t noff, nested, nlog, nchunks;
+  uint32_t ndeps, dep_overflow, nalloc, nfree;
+  uint32_t overflow, attempts, rolled, pad;
+  long long live_delta;
+  unsigned long long ctr[SPEC_NCTR];
+  uint32_t deps[MAX_DEPS];
+};
+
+enum SpecCtrl { SC_NPENDING = 0, SC_BASE, SC_N, SC_NESTED_COMMITTED, SC_NODE_CURSOR, SC_NRECLAIM, SC_NFREE_START,
+                SC_ROUNDS, SC_ABORTS, SC_KILLS, SC_RECLAIM_LOST, SC_CHUNK_CURSOR, SC_SKIPPED, SC_EXECUTED, SC_COUNT = 16 };
+
+struct SpecShared {
+  uint32_t* stamp;
+  uint32_t* claim;
+  SpecPart* part;
+  uint32_t* chunk_tab;      // [n][MAX_CHUNKS]
+  SpecLog* arena;
+  uint32_t arena_chunks;
+  uint32_t* alloc_log;      // [n][MAX_NODELOG]
+  uint32_t* free_log;       // [n][MAX_NODELOG]
+  uint32_t* pending;        // ids of the particles to run this round
+  uint32_t* ctrl;           // SpecCtrl
+  int* draws;               // the phase's rand() stream, peeked ahead
+  uint32_t ndraws;
+  uint32_t* reclaim;        // pool nodes that return to the free stack at phase end
+  uint32_t reclaim_cap;
+  uint32_t* scout_cells;    // [n][SCOUT_CAP] cells of the read-only scout run (predicted footprint)
+  uint32_t* scout_len;      // [n]
+};
+
+SMX_D SpecLog* spec_entry(const SpecShared& sh, uint32_t pid, uint32_t k) {
+  const uint32_t cid = sh.chunk_tab[(size_t)pid * MAX_CHUNKS + k / LOG_CHUNK];
+  return sh.arena + (size_t)cid * LOG_CHUNK + (k % LOG_CHUNK);
+}
+SMX_D size_t spec_fidx(const DevState& s, size_t c) {        // cell order -> frequency order
+  const size_t x = c / (size_t)s.dimy, y = c - x * (size_t)s.dimy;
+  return y * (size_t)s.dimx + x;
+}
+
+// ---------------- read-only scout: records the predicted footprint of a particle ----------------
+struct ScoutPolicy {
+  static constexpr bool READ_ONLY = true;
+  const SpecShared& sh;
+  uint32_t pid, len = 0;
+  uint32_t* out;
+  size_t last = ~(size_t)0, last2 = ~(size_t)0;
+  SMX_D ScoutPolicy(const SpecShared& sh_, uint32_t p) : sh(sh_), pid(p), out(sh_.scout_cells + (size_t)p * SCOUT_CAP) {}
+  SMX_D bool touch(const DevState&, size_t c) {
+    if (c != last && c != last2) { last2 = last; last = c; if (len < SCOUT_CAP) out[len++] = (uint32_t)c; }
+    return true;
+  }
+  SMX_D void finish() { sh.scout_len[pid] = len; }
+  SMX_D void pre_write_node(const DevState&, uint32_t) {}
+  SMX_D void set_flag(const DevState&, size_t, uint8_t) {}
+  SMX_D void clear_flag(const DevState&, size_t, uint8_t) {}
+  SMX_D bool can_get(const DevState&) const { return true; }
+  SMX_D void live_add(const DevState&, int) {}
+  SMX_D uint32_t node_alloc(const DevState&) { return NIL; }
+  SMX_D void node_free(const DevState&, uint32_t) {}
+  SMX_D void rand2(const DevState&, int& a, int& b) { a = 0; b = 0; }
+  SMX_D void add_counter(const DevState&, int, unsigned long long) {}
+};
+
+// ---------------- in-place speculative execution ----------------
+struct SpecPolicy {
+  static constexpr bool READ_ONLY = false;
+  const SpecShared& sh;
+  uint32_t pid, me;
+  SpecPart* part;
+  uint32_t nlog = 0, nchunks, ndeps = 0, dep_overflow = 0, nalloc = 0, nfree = 0, nested_drawn = 0, overflow = 0;
+  uint32_t fail_cell = NOCLAIM;
+  long long live_delta = 0;
+  unsigned long long ctr[SPEC_NCTR];
+  size_t last = ~(size_t)0;
+
+  SMX_D SpecPolicy(const SpecShared& sh_, uint32_t p) : sh(sh_), pid(p), me(p + 1), part(sh_.part + p) {
+    nchunks = part->nchunks;
+    for (int i = 0; i < SPEC_NCTR; i++) ctr[i] = 0;
+  }
+
+  SMX_D SpecLog* append(uint32_t cellkey, uint32_t prev) {
+    const uint32_t k = nlog;
+    const uint32_t ch = k / LOG_CHUNK;
+    if (ch >= nchunks) {
+      if (ch >= (uint32_t)MAX_CHUNKS) { overflow = 1; return nullptr; }
+      const uint32_t cid = SMX_A_ADD(&sh.ctrl[SC_CHUNK_CURSOR], 1u);
+      if (cid >= sh.arena_chunks) { overflow = 1; return nullptr; }
+      sh.chunk_tab[(size_t)pid * MAX_CHUNKS + ch] = cid;
+      nchunks = ch + 1;
+    }
+    nlog = k + 1;
+    SpecLog* e = spec_entry(sh, pid, k);
+    e->cell = cellkey; e->prev = prev;
+    return e;
+  }
+
+  SMX_D bool touch(const DevState& s, size_t c) {
+    if (c == last) return true;
+    uint32_t v = SMX_A_LOAD(&sh.stamp[c]);
+    if (v == me) { last = c; return true; }
+    while (true) {
+      if (v == POISON) { fail_cell = (uint32_t)c; return false; }
+      if (v > me) {                                         // a later particle got here first: it must be undone
+        SMX_A_STORE(&sh.part[v - 1].kill, 1u);
+        fail_cell = (uint32_t)c;
+        return false;
+      }
+      bool dep = false;
+      if (v != 0) {                                         // last touched by a lower particle
+        const uint32_t st = SMX_A_LOAD(&sh.part[v - 1].status);
+        if (st == ST_PENDING || st == ST_DONE_NEW) { fail_cell = (uint32_t)c; return false; }   // still running this round
+        dep = (st == ST_DONE_OLD);
+      }
+      if (SMX_A_LOAD(&sh.claim[c]) < pid) { fail_cell = (uint32_t)c; return false; }   // yield to a lower pending particle
+      const uint32_t old = SMX_A_CAS(&sh.stamp[c], v, me);
+      if (old != v) { v = old; continue; }
+      SpecLog* e = append((uint32_t)c, v);
+      if (!e) { SMX_A_STORE(&sh.stamp[c], v); fail_cell = (uint32_t)c; return false; }
+      const size_t fi = spec_fidx(s, c);
+      e->rec = s.cells[c]; e->wtrack = s.wtrack[fi]; e->windfreq = s.windfreq[fi]; e->flags = s.flags[c];
+      if (dep) {
+        bool have = false;
+        for (uint32_t i = 0; i < ndeps; i++) have |= (part->deps[i] == v - 1);
+        if (!have) { if (ndeps < (uint32_t)MAX_DEPS) part->deps[ndeps++] = v - 1; else dep_overflow = 1; }
+      }
+      last = c;
+      return true;
+    }
+  }
+  SMX_D void pre_write_node(const DevState& s, uint32_t node) {
+    SpecLog* e = append(NODE_ENTRY | node, 0);
+    if (e) e->rec = s.pool[node];
+  }
+  SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (!(v & f)) s.flags[c] = v | f; }
+  SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (v & f) s.flags[c] = v & (uint8_t)~f; }
+  SMX_D bool can_get(const DevState&) const { return true; }   // the host only starts a speculative phase with pool headroom
+  SMX_D void live_add(const DevState&, int d) { live_delta += d; }
+  SMX_D uint32_t node_alloc(const DevState& s) {
+    if (nalloc >= (uint32_t)MAX_NODELOG) { overflow = 1; return NIL; }
+    const uint32_t cur = SMX_A_ADD(&sh.ctrl[SC_NODE_CURSOR], 1u);
+    const uint32_t nstart = sh.ctrl[SC_NFREE_START];
+    if (cur >= nstart) { overflow = 1; return NIL; }
+    const uint32_t nd = s.freelist[nstart - 1 - cur];
+    sh.alloc_log[(size_t)pid * MAX_NODELOG + nalloc++] = nd;
+    return nd;
+  }
+  SMX_D void node_free(const DevState&, uint32_t e) {       // deferred: the node keeps its content until the phase ends
+    if (nfree >= (uint32_t)MAX_NODELOG) { overflow = 1; return; }
+    sh.free_log[(size_t)pid * MAX_NODELOG + nfree++] = e;
+  }
+  SMX_D void rand2(const DevState&, int& first, int& second) {   // draws of a NESTED particle (water.h:251)
+    const uint32_t k = 2u * pid + 2u * part->noff + 2u + 2u * nested_drawn;
+    nested_drawn++;
+    if (k + 1 >= sh.ndraws) { overflow = 1; first = second = 0; return; }
+    first = sh.draws[k]; second = sh.draws[k + 1];
+  }
+  SMX_D void spawn_draws(int& first, int& second) const {
+    const uint32_t k = 2u * pid + 2u * part->noff;
+    first = sh.draws[k]; second = sh.draws[k + 1];
+  }
+  SMX_D void add_counter(const DevState&, int which, unsigned long long v) { if (which < SPEC_NCTR) ctr[which] += v; }
+
+  SMX_D void reclaim_nodes(const uint32_t* list, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t k = SMX_A_ADD(&sh.ctrl[SC_NRECLAIM], 1u);
+      if (k < sh.reclaim_cap) sh.reclaim[k] = list[i]; else SMX_A_ADD(&sh.ctrl[SC_RECLAIM_LOST], 1u);
+    }
+  }
+  // the particle aborted: undo its writes now (it still holds every cell it touched), then poison those cells
+  SMX_D void self_rollback(const DevState& s) {
+    for (uint32_t k = nlog; k-- > 0;) {
+      const SpecLog* e = spec_entry(sh, pid, k);
+      if (e->cell & NODE_ENTRY) { s.pool[e->cell & ~NODE_ENTRY] = e->rec; continue; }
+      const size_t c = e->cell, fi = spec_fidx(s, c);
+      s.cells[c] = e->rec; s.wtrack[fi] = e->wtrack; s.windfreq[fi] = e->windfreq; s.flags[c] = (uint8_t)e->flags;
+      SMX_A_STORE(&sh.stamp[c], POISON);
+    }
+    reclaim_nodes(sh.alloc_log + (size_t)pid * MAX_NODELOG, nalloc);
+    part->nlog = nlog; part->nchunks = nchunks; part->fail_cell = fail_cell; part->overflow = overflow;
+    part->ndeps = 0; part->dep_overflow = 0; part->nalloc = 0; part->nfree = 0; part->nested = 0;
+    part->aborted = 1; part->attempts++;
+    SMX_A_ADD(&sh.ctrl[SC_ABORTS], 1u);
+  }
+  SMX_D void finish_done(const DevState&) {
+    part->nlog = nlog; part->nchunks = nchunks; part->ndeps = ndeps; part->dep_overflow = dep_overflow;
+    part->nalloc = nalloc; part->nfree = nfree; part->nested = nested_drawn; part->live_delta = live_delta;
+    part->overflow = overflow; part->fail_cell = NOCLAIM; part->aborted = 0; part->attempts++;
+    for (int i = 0; i < SPEC_NCTR; i++) part->ctr[i] = ctr[i];
+    SMX_A_STORE(&part->status, ST_DONE_NEW);
+  }
+};
+
+// ---------------- round boundary (ONE workgroup; everything it reads was written by earlier kernels) --------
+// 1. kill closure over the window [base, end): kill flags set by lower particles, log/node overflows, dependencies
+//    on killed particles, wrong rand() offsets (nested particles of lower ids).
+// 2. roll killed particles back (data + stamps) and release the stamps of particles that aborted by themselves,
+//    in DESCENDING id order (a cell taken over from a lower tentative particle must be unwound top-down).
+// 3. DONE_NEW -> DONE_OLD, commit the finished prefix, rebuild the pending list with fresh rand offsets.
+// Written for a TEAM of `nt` threads (thread `tid`); `sync` is the team barrier. The scalar passes run on
+// thread 0 over the staged arrays in `w` (LDS on the device).
+constexpr uint32_t SPEC_WINDOW = 4096;        // particles one boundary pass looks at (ids base .. base+window)
+struct SpecWork {                             // staged per-particle state, index = pid - base
+  uint8_t st[SPEC_WINDOW], kl[SPEC_WINDOW], ab[SPEC_WINDOW], dov[SPEC_WINDOW];
+  uint16_t nested[SPEC_WINDOW];               // <= SPEC_MAXNEST
+  uint32_t noff[SPEC_WINDOW];
+  uint16_t list[SPEC_WINDOW];                 // particles that need a rollback / stamp release (descending)
+  uint32_t nlist, changed, base, end;
+};
+
+template <class SyncF>
+SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork& w, uint32_t tid, uint32_t nt, SyncF sync) {
+  uint32_t* ctrl = sh.ctrl;
+  const uint32_t n = ctrl[SC_N];
+  if (tid == 0) { w.base = ctrl[SC_BASE]; w.end = (n - w.base > SPEC_WINDOW) ? w.base + SPEC_WINDOW : n; }
+  sync();
+  const uint32_t base = w.base, end = w.end, cnt = end - base;
+  for (uint32_t i = tid; i < cnt; i += nt) {
+    const SpecPart& q = sh.part[base + i];
+    w.st[i] = (uint8_t)q.status; w.kl[i] = (uint8_t)((q.kill != 0) || (q.overflow != 0 && q.status != ST_PENDING));
+    w.ab[i] = (uint8_t)q.aborted; w.dov[i] = (uint8_t)q.dep_overflow; w.nested[i] = (uint16_t)q.nested; w.noff[i] = q.noff;
+  }
+  sync();
+  // ---- 1. kill closure
+  while (true) {
+    if (tid == 0) w.changed = 0;
+    sync();
+    for (uint32_t i = tid; i < cnt; i += nt) {             // dependencies (always lower ids)
+      if ((w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD) && !w.kl[i]) {
+        const SpecPart& q = sh.part[base + i];
+        bool bad = false;
+        for (uint32_t k = 0; k < q.ndeps; k++) { const uint32_t d = q.deps[k]; if (d >= base && w.kl[d - base]) { bad = true; break; } }
+        if (bad) { w.kl[i] = 1; w.changed = 1; }
+      }
+    }
+    sync();
+    if (tid == 0) {                                        // rand() offsets + dependency-list overflows, in id order
+      uint32_t nest = ctrl[SC_NESTED_COMMITTED];
+      bool any = false;
+      for (uint32_t i = 0; i < cnt; i++) {
+        if (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD) {
+          if (!w.kl[i] && ((w.dov[i] && any) || w.noff[i] != nest)) { w.kl[i] = 1; w.changed = 1; }
+          if (w.kl[i]) any = true; else nest += w.nested[i];
+        }
+      }
+    }
+    sync();
+    if (!w.changed) break;
+  }
+  // ---- 2. rollback list, highest id first
+  if (tid == 0) {
+    uint32_t m = 0;
+    for (uint32_t i = cnt; i-- > 0;) {
+      const bool done = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD);
+      if ((done && w.kl[i]) || (!done && w.ab[i])) w.list[m++] = (uint16_t)i;
+    }
+    w.nlist = m;
+  }
+  sync();
+  for (uint32_t j = 0; j < w.nlist; j++) {
+    const uint32_t i = w.list[j], p = base + i;
+    SpecPart& q = sh.part[p];
+    const bool done = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD);
+    const uint32_t nl = q.nlog;
+    if (done) {                                            // killed: restore data and stamps
+      // duplicate NODE entries must be unwound newest-first: thread 0 handles node entries, cells are unique
+      for (uint32_t k = tid; k < nl; k += nt) {
+        const SpecLog* e = spec_entry(sh, p, k);
+        if (e->cell & NODE_ENTRY) continue;
+        const size_t c = e->cell, fi = spec_fidx(s, c);
+        s.cells[c] = e->rec; s.wtrack[fi] = e->wtrack; s.windfreq[fi] = e->windfreq; s.flags[c] = (uint8_t)e->flags;
+        sh.stamp[c] = e->prev;
+      }
+      if (tid == 0) {
+        for (uint32_t k = nl; k-- > 0;) {
+          const SpecLog* e = spec_entry(sh, p, k);
+          if (e->cell & NODE_ENTRY) s.pool[e->cell & ~NODE_ENTRY] = e->rec;
+        }
+        for (uint32_t k = 0; k < q.nalloc; k++) {
+          const uint32_t r = ctrl[SC_NRECLAIM]++;
+          if (r < sh.reclaim_cap) sh.reclaim[r] = sh.alloc_log[(size_t)p * MAX_NODELOG + k]; else ctrl[SC_RECLAIM_LOST]++;
+        }
+        q.rolled = 1; q.nalloc = 0; q.nfree = 0; q.ndeps = 0; q.dep_overflow = 0; q.nested = 0; q.overflow = 0;
+        ctrl[SC_KILLS]++;
+        w.st[i] = ST_PENDING; w.nested[i] = 0;
+      }
+    } else {                                               // aborted by itself: data already restored, release stamps
+      for (uint32_t k = tid; k < nl; k += nt) {
+        const SpecLog* e = spec_entry(sh, p, k);
+        if (e->cell & NODE_ENTRY) continue;
+        sh.stamp[e->cell] = e->prev;
+      }
+    }
+    sync();
+  }
+  // ---- 3. promote, commit the finished prefix, pending list
+  if (tid == 0) {
+    uint32_t b = 0;                                        // number of particles committed now
+    for (uint32_t i = 0; i < cnt; i++) if (w.st[i] == ST_DONE_NEW) w.st[i] = ST_DONE_OLD;
+    while (b < cnt && w.st[b] == ST_DONE_OLD) {
+      SpecPart& q = sh.part[base + b];
+      w.st[b] = ST_COMMITTED;
+      for (int k = 0; k < SPEC_NCTR; k++) s.ctr[k] += q.ctr[k];
+      s.ctr[C_LIVE_SECTIONS] += (unsigned long long)q.live_delta;
+      ctrl[SC_NESTED_COMMITTED] += q.nested;
+      for (uint32_t k = 0; k < q.nfree; k++) {
+        const uint32_t r = ctrl[SC_NRECLAIM]++;
+        if (r < sh.reclaim_cap) sh.reclaim[r] = sh.free_log[(size_t)(base + b) * MAX_NODELOG + k]; else ctrl[SC_RECLAIM_LOST]++;
+      }
+      b++;
+    }
+    uint32_t np = 0, nest = ctrl[SC_NESTED_COMMITTED];
+    for (uint32_t i = b; i < cnt; i++) {
+      if (w.st[i] == ST_PENDING) { w.noff[i] = nest; sh.pending[np++] = base + i; }
+      else nest += w.nested[i];
+    }
+    // particles beyond the window become eligible as the window slides: they keep noff from the last in-window state
+    const uint32_t newbase = base + b;
+    const uint32_t newend = (n - newbase > SPEC_WINDOW) ? newbase + SPEC_WINDOW : n;
+    for (uint32_t p = end; p < newend; p++) { sh.part[p].noff = nest; sh.pending[np++] = p; }
+    ctrl[SC_BASE] = newbase;
+    ctrl[SC_NPENDING] = np;
+    ctrl[SC_ROUNDS]++;
+  }
+  sync();
+  for (uint32_t i = tid; i < cnt; i += nt) {
+    SpecPart& q = sh.part[base + i];
+    q.status = w.st[i]; q.kill = 0; q.aborted = 0; q.noff = w.noff[i];
+  }
+  sync();
+}
+
+// give up speculation: undo every tentative particle so that the state equals "particles [0, base) executed"
+SMX_D void spec_abandon(const DevState& s, const SpecShared& sh) {
+  uint32_t* ctrl = sh.ctrl;
+  const uint32_t n = ctrl[SC_N], base = ctrl[SC_BASE];
+  for (uint32_t p = base; p < n; p++) if (sh.part[p].status == ST_DONE_OLD || sh.part[p].status == ST_DONE_NEW) sh.part[p].kill = 1;
+  for (uint32_t p = n; p-- > base;) {
+    SpecPart& q = sh.part[p];
+    if (q.kill) {
+      for (uint32_t k = q.nlog; k-- > 0;) {
+        const SpecLog* e = spec_entry(sh, p, k);
+        if (e->cell & NODE_ENTRY) { s.pool[e->cell & ~NODE_ENTRY] = e->rec; continue; }
+        const size_t c = e->cell, fi = spec_fidx(s, c);
+        s.cells[c] = e->rec; s.wtrack[fi] = e->wtrack; s.windfreq[fi] = e->windfreq; s.flags[c] = (uint8_t)e->flags;
+      }
+      for (uint32_t i = 0; i < q.nalloc; i++) {
+        const uint32_t k = ctrl[SC_NRECLAIM]++;
+        if (k < sh.reclaim_cap) sh.reclaim[k] = sh.alloc_log[(size_t)p * MAX_NODELOG + i]; else ctrl[SC_RECLAIM_LOST]++;
+      }
+      q.status = ST_PENDING; q.kill = 0;
+    }
+  }
+}
+
+// phase end: the free-node stack = what the bump allocator did not consume + the reclaimed nodes
+SMX_D void spec_finish_pool(const DevState& s, const SpecShared& sh) {
+  uint32_t* ctrl = sh.ctrl;
+  const uint32_t nstart = ctrl[SC_NFREE_START];
+  uint32_t used = ctrl[SC_NODE_CURSOR];
+  if (used > nstart) used = nstart;
+  uint32_t nf = nstart - used;
+  uint32_t nr = ctrl[SC_NRECLAIM];
+  if (nr > sh.reclaim_cap) nr = sh.reclaim_cap;
+  for (uint32_t i = 0; i < nr; i++) s.freelist[nf++] = sh.reclaim[i];
+  *s.free_count = nf;
+}
+
+}  // namespace smx
+
+// ------------------------------------------------------------------------------------------------
+// kernel bodies shared by the HIP kernels (soilmx.hip) and the host-side unit-test build (tests/hostsim)
+// ------------------------------------------------------------------------------------------------
+namespace smx {
+
+constexpr uint32_t SPEC_MAXNEST = 512;        // nested particles one speculative phase can absorb (else: serial fallback)
+
+// phase start (team of nt threads): thread 0 peeks the rand() stream ahead and resets the control block,
+// everybody resets the per-particle records. The speculative engine needs pool headroom (SpecPolicy::can_get
+// never refuses): without it the phase is flagged (SC_N = 0) and the host runs the serial walker instead.
+SMX_D void spec_begin_team(const DevState& s, const SpecShared& sh, uint32_t n, uint32_t tid, uint32_t nt) {
+  if (tid == 0) {
+    RandState r = *s.rnd;                     // copy: the global stream is only advanced when the phase ends
+    for (uint32_t k = 0; k < sh.ndraws; k++) {
+      const uint32_t i = r.idx;
+      const uint32_t v = r.ring[i % 31] + r.ring[(i - 3) % 31];
+      r.ring[i % 31] = v; r.idx = i + 1;
+      sh.draws[k] = (int)(v >> 1);
+    }
+    for (int i = 0; i < SC_COUNT; i++) sh.ctrl[i] = 0;
+    const unsigned long long live = s.ctr[C_LIVE_SECTIONS];
+    const bool room = live + 65536ull + 64ull * n < s.pool_capacity && *s.free_count > 65536u + 64u * n;
+    sh.ctrl[SC_N] = room ? n : 0; sh.ctrl[SC_NPENDING] = room ? ((n > SPEC_WINDOW) ? SPEC_WINDOW : n) : 0;
+    sh.ctrl[SC_NFREE_START] = *s.free_count;
+  }
+  for (uint32_t p = tid; p < n; p += nt) {
+    SpecPart& q = sh.part[p];
+    q.status = ST_PENDING; q.kill = 0; q.aborted = 0; q.fail_cell = NOCLAIM; q.noff = 0; q.nested = 0; q.nlog = 0;
+    q.nchunks = 0; q.ndeps = 0; q.dep_overflow = 0; q.nalloc = 0; q.nfree = 0; q.overflow = 0; q.attempts = 0; q.rolled = 0;
+    q.live_delta = 0;
+    sh.pending[p] = p;
+    sh.scout_len[p] = 0;
+  }
+}
+SMX_D void spec_begin(const DevState& s, const SpecShared& sh, uint32_t n) { spec_begin_team(s, sh, n, 0u, 1u); }
+// phase end (ONE thread): consume the draws the phase used, rebuild the free-node stack
+SMX_D void spec_end(const DevState& s, const SpecShared& sh, uint32_t nparticles_done, uint32_t nested_done) {
+  RandState& r = *s.rnd;
+  const uint64_t nd = 2ull * nparticles_done + 2ull * nested_done;
+  for (uint64_t k = 0; k < nd; k++) {
+    const uint32_t i = r.idx;
+    const uint32_t v = r.ring[i % 31] + r.ring[(i - 3) % 31];
+    r.ring[i % 31] = v; r.idx = i + 1;
+  }
+  r.calls += nd;
+  spec_finish_pool(s, sh);
+}
+
+// A pending particle's predicted footprint = cells of its scout run + cells its previous attempt really touched +
+// the cell that attempt failed at. spec_claim_one publishes it (claim[c] = min pending id); spec_blocked asks
+// whether a LOWER pending particle wants any of those cells -- then this particle sits the round out.
+template <class F>
+SMX_D void spec_for_footprint(const SpecShared& sh, uint32_t pid, F f) {
+  const SpecPart& q = sh.part[pid];
+  const uint32_t sl = sh.scout_len[pid];
+  const uint32_t* sc = sh.scout_cells + (size_t)pid * SCOUT_CAP;
+  for (uint32_t k = 0; k < sl; k++) if (!f(sc[k])) return;
+  if (q.attempts != 0) {
+    for (uint32_t k = 0; k < q.nlog; k++) {
+      const SpecLog* e = spec_entry(sh, pid, k);
+      if (e->cell & NODE_ENTRY) continue;
+      if (!f(e->cell)) return;
+    }
+    if (q.fail_cell != NOCLAIM) f(q.fail_cell);
+  }
+}
+SMX_D void spec_claim_one(const SpecShared& sh, uint32_t pid) {
+  spec_for_footprint(sh, pid, [&](uint32_t c) { if (SMX_A_LOAD(&sh.claim[c]) > pid) SMX_A_MIN(&sh.claim[c], pid); return true; });
+}
+SMX_D bool spec_blocked(const SpecShared& sh, uint32_t pid) {
+  bool blocked = false;
+  spec_for_footprint(sh, pid, [&](uint32_t c) { if (SMX_A_LOAD(&sh.claim[c]) < pid) { blocked = true; return false; } return true; });
+  return blocked;
+}
+
+// round 0 only: the read-only trajectory of every particle on the phase's initial state
+template <bool WIND>
+SMX_D void spec_scout_one(const DevState& s, const SoilP* soils, const SpecShared& sh, uint32_t pid) {
+  ScoutPolicy pol(sh, pid);
+  Sim<ScoutPolicy> sim(s, soils, pol);
+  const uint32_t k = 2u * pid + 2u * sh.part[pid].noff;
+  const int ry = sh.draws[k] % s.dimy, rx = sh.draws[k + 1] % s.dimx;
+  if constexpr (WIND) {
+    Wind p; sim.wind_init(p, rx, ry); sim.wind_run(p);
+  } else {
+    Frame st[1]; int depth = 0;               // the scout never pushes frames (it stops before the flood)
+    Water p; sim.water_init(p, rx, ry); sim.water_drive(p, true, true, st, depth);
+  }
+  pol.finish();
+}
+
+template <bool WIND>
+SMX_D void spec_exec_one(const DevState& s, const SoilP* soils, const SpecShared& sh, uint32_t pid) {
+  if (spec_blocked(sh, pid)) { SMX_A_ADD(&sh.ctrl[SC_SKIPPED], 1u); return; }
+  SMX_A_ADD(&sh.ctrl[SC_EXECUTED], 1u);
+  SpecPolicy pol(sh, pid);
+  Sim<SpecPolicy> sim(s, soils, pol);
+  int d1, d2;
+  pol.spawn_draws(d1, d2);                    // 1st draw -> y, 2nd -> x (water.h:13, wind.h:15 under g++)
+  const int ry = d1 % s.dimy, rx = d2 % s.dimx;
+  if constexpr (WIND) {
+    Wind p; sim.wind_init(p, rx, ry);
+    if (!sim.ab) sim.wind_run(p);
+  } else {
+    Frame st[MAX_FRAMES]; int depth = 0;
+    Water p; sim.water_init(p, rx, ry);
+    if (!sim.ab) sim.water_drive(p, true, true, st, depth);
+  }
+  if (sim.ab || pol.overflow) { pol.self_rollback(s); return; }
+  sim.flush_counters();
+  pol.finish_done(s);
+}
+
+}  // namespace smx

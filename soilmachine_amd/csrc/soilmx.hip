@@ -22,6 +22,7 @@
 #include "../../include/soilmx.h"
 #include "soil_core.h"
 #include "soil_serial.h"
+#include "soil_spec.h"
 #include "soil_noise.h"
 
 using namespace smx;
@@ -128,6 +129,47 @@ __global__ void __launch_bounds__(64) k_grid_serial(DevState s) {
   sim.flush_counters();
   pol.add_counter(s, C_GRID_ACTIVE, visited);
   pol.finish(s);
+}
+
+// ---------------- speculative engine kernels (protocol: soil_spec.h) ----------------
+// SPEC_LANES particles per wave: each lane walks one particle; fewer lanes per wave = less divergence
+// serialisation and more CUs in play (a phase has only ~10^3 particles, the chip has 256 CUs).
+constexpr int SPEC_LANES = 16;
+
+__global__ void __launch_bounds__(256) k_spec_begin(DevState s, SpecShared sh, uint32_t n) {
+  spec_begin_team(s, sh, n, threadIdx.x, blockDim.x);
+}
+template <bool WIND>
+__global__ void __launch_bounds__(64) k_spec_scout(DevState s, SpecShared sh) {
+  SMX_LOAD_SOILS(soils_sh)
+  const uint32_t n = sh.ctrl[SC_N];
+  const uint32_t pid = blockIdx.x * SPEC_LANES + threadIdx.x;
+  if (threadIdx.x >= SPEC_LANES || pid >= n) return;
+  spec_scout_one<WIND>(s, soils_sh, sh, pid);
+}
+__global__ void __launch_bounds__(64) k_spec_claim(SpecShared sh) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= sh.ctrl[SC_NPENDING]) return;
+  spec_claim_one(sh, sh.pending[i]);
+}
+template <bool WIND>
+__global__ void __launch_bounds__(64) k_spec_exec(DevState s, SpecShared sh) {
+  SMX_LOAD_SOILS(soils_sh)
+  const uint32_t i = blockIdx.x * SPEC_LANES + threadIdx.x;
+  if (threadIdx.x >= SPEC_LANES || i >= sh.ctrl[SC_NPENDING]) return;
+  spec_exec_one<WIND>(s, soils_sh, sh, sh.pending[i]);
+}
+__global__ void __launch_bounds__(256) k_spec_boundary(DevState s, SpecShared sh) {
+  __shared__ SpecWork w;
+  spec_boundary_team(s, sh, w, threadIdx.x, blockDim.x, []() { __syncthreads(); });
+}
+__global__ void __launch_bounds__(64) k_spec_abandon(DevState s, SpecShared sh) {
+  if (threadIdx.x == 0) spec_abandon(s, sh);
+}
+__global__ void __launch_bounds__(64) k_spec_end(DevState s, SpecShared sh, uint32_t whole_phase) {
+  if (threadIdx.x != 0) return;
+  const uint32_t done = whole_phase ? sh.ctrl[SC_N] : sh.ctrl[SC_BASE];
+  spec_end(s, sh, done, sh.ctrl[SC_NESTED_COMMITTED]);
 }
 
 __global__ void __launch_bounds__(256) k_map_frequency(float* __restrict__ freq, const float* __restrict__ track, size_t n4, size_t n) {
@@ -269,7 +311,10 @@ struct smx_ctx {
   std::vector<EvPair> pending;
   std::vector<hipEvent_t> evpool;
   smx_timing timing{};
-  uint64_t spec_rounds = 0, spec_aborts = 0;
+  uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0;
+  SpecShared sh{};                    // speculative engine buffers (allocated on first use)
+  uint32_t spec_cap = 0;              // particles the buffers are sized for
+  uint32_t* h_ctrl = nullptr;         // pinned host copy of the control block
 };
 
 #define HIPCHK(call)                                                                                  \
@@ -322,7 +367,7 @@ extern "C" {
 const char* smx_last_error(smx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int smx_create(const smx_config* cfg, smx_ctx** out) {
-  if (!cfg || !out || cfg->dimx <= 0 || cfg->dimy <= 0 || cfg->pool_capacity == 0 || cfg->pool_capacity >= 0xFFFFFFFFull) return -2;
+  if (!cfg || !out || cfg->dimx <= 0 || cfg->dimy <= 0 || cfg->pool_capacity == 0 || cfg->pool_capacity >= 0x7FFFFFFFull) return -2;
   smx_ctx* ctx = new smx_ctx();
   ctx->cfg = *cfg;
   *out = ctx;   // handed out even on failure so the caller can read smx_last_error(); smx_destroy() is safe
@@ -375,6 +420,14 @@ void smx_destroy(smx_ctx* ctx) {
   hipFree(d.cells); hipFree(d.pool); hipFree(d.freelist); hipFree(d.free_count); hipFree(d.flags);
   hipFree(d.wfreq); hipFree(d.wtrack); hipFree(d.windfreq); hipFree(d.rnd); hipFree(d.ctr);
   hipFree(d.active); hipFree(d.active1); hipFree(d.active2); hipFree(ctx->d_scratch); hipFree(ctx->d_soils);
+  if (ctx->sh.stamp) {
+    SpecShared& sh = ctx->sh;
+    hipFree(sh.stamp); hipFree(sh.claim); hipFree(sh.ctrl); hipFree(sh.reclaim); hipHostFree(ctx->h_ctrl);
+    if (ctx->spec_cap) {
+      hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
+      hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len);
+    }
+  }
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -583,9 +636,81 @@ int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out
   return 0;
 }
 
+// ---------------- speculative engine: host driver ----------------
+static int spec_alloc(smx_ctx* ctx, uint32_t n) {
+  if (ctx->spec_cap >= n) return 0;
+  SpecShared& sh = ctx->sh;
+  if (ctx->spec_cap) {
+    hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
+    hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len);
+  } else {
+    HIPCHK(hipMalloc(&sh.stamp, ctx->ncells * 4)); HIPCHK(hipMalloc(&sh.claim, ctx->ncells * 4));
+    HIPCHK(hipMalloc(&sh.ctrl, SC_COUNT * 4));
+    sh.reclaim_cap = 1u << 22; HIPCHK(hipMalloc(&sh.reclaim, (size_t)sh.reclaim_cap * 4));
+    HIPCHK(hipHostMalloc(&ctx->h_ctrl, SC_COUNT * 4));
+  }
+  const uint32_t cap = n < 1024 ? 1024 : n;
+  HIPCHK(hipMalloc(&sh.part, (size_t)cap * sizeof(SpecPart)));
+  HIPCHK(hipMalloc(&sh.chunk_tab, (size_t)cap * MAX_CHUNKS * 4));
+  sh.arena_chunks = cap * 32u < 16384u ? 16384u : cap * 32u;
+  HIPCHK(hipMalloc(&sh.arena, (size_t)sh.arena_chunks * LOG_CHUNK * sizeof(SpecLog)));
+  HIPCHK(hipMalloc(&sh.alloc_log, (size_t)cap * MAX_NODELOG * 4)); HIPCHK(hipMalloc(&sh.free_log, (size_t)cap * MAX_NODELOG * 4));
+  HIPCHK(hipMalloc(&sh.pending, (size_t)cap * 4));
+  sh.ndraws = 2 * cap + 2 * SPEC_MAXNEST; HIPCHK(hipMalloc(&sh.draws, (size_t)sh.ndraws * 4));
+  HIPCHK(hipMalloc(&sh.scout_cells, (size_t)cap * SCOUT_CAP * 4)); HIPCHK(hipMalloc(&sh.scout_len, (size_t)cap * 4));
+  ctx->spec_cap = cap;
+  return 0;
+}
+
+// One particle phase (SoilMachine.cpp:287-298 or :303-307) with the speculative engine; falls back to the serial
+// walker for whatever the speculation could not commit. Results are bit-identical either way.
+static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
+  if (n <= 0) return 0;
+  if (spec_alloc(ctx, (uint32_t)n)) return -1;
+  const SpecShared& sh = ctx->sh;
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemsetAsync(sh.stamp, 0, ctx->ncells * 4, st));
+  hipLaunchKernelGGL(k_spec_begin, dim3(1), dim3(256), 0, st, ctx->d, sh, (uint32_t)n);
+  if (!wind) hipLaunchKernelGGL(k_spec_scout<false>, dim3((n + SPEC_LANES - 1) / SPEC_LANES), dim3(64), 0, st, ctx->d, sh);
+  uint32_t np = (uint32_t)n > SPEC_WINDOW ? SPEC_WINDOW : (uint32_t)n, last_base = 0, stall = 0;
+  bool fallback = false;
+  for (int round = 0;; round++) {
+    HIPCHK(hipMemsetAsync(sh.claim, 0xFF, ctx->ncells * 4, st));
+    hipLaunchKernelGGL(k_spec_claim, dim3((np + 63) / 64), dim3(64), 0, st, sh);
+    if (wind) hipLaunchKernelGGL(k_spec_exec<true>, dim3((np + SPEC_LANES - 1) / SPEC_LANES), dim3(64), 0, st, ctx->d, sh);
+    else hipLaunchKernelGGL(k_spec_exec<false>, dim3((np + SPEC_LANES - 1) / SPEC_LANES), dim3(64), 0, st, ctx->d, sh);
+    hipLaunchKernelGGL(k_spec_boundary, dim3(1), dim3(256), 0, st, ctx->d, sh);
+    HIPCHK(hipMemcpyAsync(ctx->h_ctrl, sh.ctrl, SC_COUNT * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t* c = ctx->h_ctrl;
+    if (c[SC_N] == 0) { fallback = true; break; }                       // no pool headroom: nothing was executed
+    if (c[SC_BASE] == (uint32_t)n) break;
+    np = c[SC_NPENDING];
+    if (c[SC_BASE] == last_base) stall++; else { stall = 0; last_base = c[SC_BASE]; }
+    if (np == 0 || stall >= 8 || c[SC_NESTED_COMMITTED] + 64 > SPEC_MAXNEST || round > 100000) { fallback = true; break; }
+  }
+  const uint32_t* c = ctx->h_ctrl;
+  ctx->spec_rounds += c[SC_ROUNDS]; ctx->spec_aborts += c[SC_ABORTS]; ctx->spec_kills += c[SC_KILLS]; ctx->spec_executed += c[SC_EXECUTED];
+  if (fallback) {
+    ctx->spec_fallbacks++;
+    const uint32_t base = (c[SC_N] == 0) ? 0u : c[SC_BASE];
+    if (c[SC_N] != 0) {
+      hipLaunchKernelGGL(k_spec_abandon, dim3(1), dim3(64), 0, st, ctx->d, sh);
+      hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(64), 0, st, ctx->d, sh, 0u);
+    }
+    if (wind) hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, st, ctx->d, n - (int)base);
+    else hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, st, ctx->d, n - (int)base);
+  } else {
+    hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(64), 0, st, ctx->d, sh, 1u);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // ---------------- the hot path ----------------
 int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   PhaseTimer t(ctx, 0);
+  if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwater, false);
   hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwater);
   HIPCHK(hipGetLastError());
   return 0;
@@ -602,6 +727,7 @@ int smx_grid_pass(smx_ctx* ctx) {
 }
 int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
   PhaseTimer t(ctx, 2);
+  if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwind, true);
   hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwind);
   HIPCHK(hipGetLastError());
   return 0;
@@ -678,6 +804,7 @@ int smx_get_counters(smx_ctx* ctx, smx_counters* out) {
   out->grid_active_cells = c[C_GRID_ACTIVE]; out->rand_calls = r.calls;
   out->pool_free = ctx->cfg.pool_capacity - c[C_LIVE_SECTIONS]; out->pool_overflow = c[C_POOL_OVERFLOW];
   out->spec_rounds = ctx->spec_rounds; out->spec_aborts = ctx->spec_aborts;
+  out->reserved[0] = ctx->spec_fallbacks; out->reserved[1] = ctx->spec_executed;
   return 0;
 }
 int smx_get_timing(smx_ctx* ctx, smx_timing* out) {

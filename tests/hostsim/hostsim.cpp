@@ -11,8 +11,13 @@
 #include <vector>
 
 #define SMX_D inline
+#define SMX_HOSTSIM 1
 #include "../../soilmachine_amd/csrc/soil_core.h"
 #include "../../soilmachine_amd/csrc/soil_serial.h"
+#include "../../soilmachine_amd/csrc/soil_spec.h"
+#include <thread>
+#include <algorithm>
+#include <random>
 
 using namespace smx;
 
@@ -193,4 +198,80 @@ double hs_remove(hs_ctx* c, int x, int y, double h) {
   double r = sim.remove(x, y, h); sim.flush_counters(); pol.finish(s); return r;
 }
 
+
+}  // extern "C" (serial engine)
+
+// ---------------- speculative engine, emulated: "kernels" = groups of std::threads over the same memory ----------
+struct SpecBuffers {
+  std::vector<uint32_t> stamp, claim, chunk_tab, alloc_log, free_log, pending, ctrl, reclaim, scout_cells, scout_len;
+  std::vector<SpecPart> part;
+  std::vector<SpecLog> arena;
+  std::vector<int> draws;
+  SpecShared sh;
+};
+static void spec_setup(hs_ctx* c, SpecBuffers& b, uint32_t n) {
+  b.stamp.assign(c->n, 0); b.claim.assign(c->n, NOCLAIM);
+  b.part.resize(n); b.chunk_tab.assign((size_t)n * MAX_CHUNKS, 0);
+  const uint32_t arena_chunks = std::max<uint32_t>(4096, n * 64);
+  b.arena.resize((size_t)arena_chunks * LOG_CHUNK);
+  b.alloc_log.assign((size_t)n * MAX_NODELOG, 0); b.free_log.assign((size_t)n * MAX_NODELOG, 0);
+  b.pending.assign(n, 0); b.ctrl.assign(SC_COUNT, 0); b.reclaim.assign(1 << 20, 0);
+  b.draws.assign(2 * n + 2 * SPEC_MAXNEST, 0);
+  b.scout_cells.assign((size_t)n * SCOUT_CAP, 0); b.scout_len.assign(n, 0);
+  SpecShared& sh = b.sh;
+  sh.stamp = b.stamp.data(); sh.claim = b.claim.data(); sh.part = b.part.data(); sh.chunk_tab = b.chunk_tab.data();
+  sh.arena = b.arena.data(); sh.arena_chunks = arena_chunks; sh.alloc_log = b.alloc_log.data(); sh.free_log = b.free_log.data();
+  sh.pending = b.pending.data(); sh.ctrl = b.ctrl.data(); sh.draws = b.draws.data(); sh.ndraws = (uint32_t)b.draws.size();
+  sh.reclaim = b.reclaim.data(); sh.reclaim_cap = (uint32_t)b.reclaim.size();
+  sh.scout_cells = b.scout_cells.data(); sh.scout_len = b.scout_len.data();
+}
+template <class F> static void parallel_for(uint32_t n, int nthreads, F f, unsigned shuffle_seed) {
+  std::vector<uint32_t> order(n);
+  for (uint32_t i = 0; i < n; i++) order[i] = i;
+  if (shuffle_seed) { std::mt19937 g(shuffle_seed); std::shuffle(order.begin(), order.end(), g); }
+  if (nthreads <= 1) { for (uint32_t i : order) f(i); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++)
+    th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nthreads) f(order[i]); });
+  for (auto& t : th) t.join();
+}
+template <bool WIND>
+static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) {
+  if (n == 0) return 0;
+  const DevState& s = c->d;
+  SpecBuffers b; spec_setup(c, b, n);
+  const SpecShared& sh = b.sh;
+  spec_begin(s, sh, n);
+  uint32_t last_base = 0, stall = 0; int fell_back = 0;
+  if (scout) parallel_for(n, nthreads, [&](uint32_t i) { spec_scout_one<WIND>(s, s.soils, sh, i); }, shuffle ? shuffle + 1 : 0);
+  while (true) {
+    std::fill(b.claim.begin(), b.claim.end(), NOCLAIM);
+    const uint32_t np = sh.ctrl[SC_NPENDING];
+    parallel_for(np, nthreads, [&](uint32_t i) { spec_claim_one(sh, sh.pending[i]); }, shuffle ? shuffle + 1 : 0);
+    parallel_for(np, nthreads, [&](uint32_t i) { spec_exec_one<WIND>(s, s.soils, sh, sh.pending[i]); }, shuffle ? shuffle + 2 + sh.ctrl[SC_ROUNDS] : 0);
+    { static SpecWork* w = new SpecWork(); spec_boundary_team(s, sh, *w, 0u, 1u, []() {}); }
+    if (sh.ctrl[SC_NPENDING] == 0 && sh.ctrl[SC_BASE] == n) break;
+    if (sh.ctrl[SC_BASE] == last_base) stall++; else { stall = 0; last_base = sh.ctrl[SC_BASE]; }
+    if (stall >= 8 || sh.ctrl[SC_NESTED_COMMITTED] > SPEC_MAXNEST - 64) { fell_back = 1; break; }
+  }
+  if (stats) { stats[0] = sh.ctrl[SC_ROUNDS]; stats[1] = sh.ctrl[SC_ABORTS]; stats[2] = sh.ctrl[SC_KILLS]; stats[3] = (uint32_t)fell_back; stats[4] = sh.ctrl[SC_EXECUTED]; }
+  if (fell_back) {
+    spec_abandon(s, sh);
+    const uint32_t base = sh.ctrl[SC_BASE];
+    spec_end(s, sh, base, sh.ctrl[SC_NESTED_COMMITTED]);
+    if (WIND) hs_wind(c, (int)(n - base)); else hs_water(c, (int)(n - base));
+    return 1;
+  }
+  spec_end(s, sh, n, sh.ctrl[SC_NESTED_COMMITTED]);
+  return 0;
+}
+extern "C" {
+int hs_spec_water(hs_ctx* c, int n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) { return spec_phase<false>(c, (uint32_t)n, nthreads, scout, shuffle, stats); }
+int hs_spec_wind(hs_ctx* c, int n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) { return spec_phase<true>(c, (uint32_t)n, nthreads, scout, shuffle, stats); }
+void hs_spec_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int nthreads, int scout, unsigned shuffle, uint32_t* stats) {
+  uint32_t st[8] = {0};
+  if (dowater) { hs_spec_water(c, nwater, nthreads, scout, shuffle, st); if (stats) for (int i = 0; i < 5; i++) stats[i] += st[i]; hs_grid(c); }
+  if (dowind) { hs_spec_wind(c, nwind, nthreads, 0, shuffle, st); if (stats) for (int i = 0; i < 5; i++) stats[5 + i] += st[i]; }
+  if (dowater) hs_freq(c);
+}
 }  // extern "C"

@@ -23,7 +23,7 @@ def lib():
     if _lib is None:
         srcs = [p for p in SRC if os.path.exists(p)]
         if not os.path.exists(LIB) or any(os.path.getmtime(p) > os.path.getmtime(LIB) for p in srcs):
-            subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB, SRC[0]])
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", "-o", LIB, SRC[0]])
         L = C.CDLL(LIB)
         vp = C.c_void_p
         L.hs_create.restype = vp
@@ -43,6 +43,9 @@ def lib():
         L.hs_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.hs_add.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_uint32]
         L.hs_remove.argtypes = [vp, C.c_int, C.c_int, C.c_double]; L.hs_remove.restype = C.c_double
+        L.hs_spec_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, vp]
+        L.hs_spec_water.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint, vp]
+        L.hs_spec_wind.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint, vp]
         _lib = L
     return _lib
 
@@ -94,3 +97,10 @@ class HostSim:
 
     def tick(self, nwater, nwind, dowater=True, dowind=True):
         self.L.hs_tick(self.h, nwater, nwind, int(dowater), int(dowind))
+
+    def spec_tick(self, nwater, nwind, dowater=True, dowind=True, nthreads=8, scout=1, shuffle=0):
+        """One tick with the speculative engine emulated by `nthreads` host threads.
+        Returns stats: [rounds, aborts, kills, fell_back, reclaim_lost] for water then wind."""
+        st = np.zeros(10, np.uint32)
+        self.L.hs_spec_tick(self.h, nwater, nwind, int(dowater), int(dowind), nthreads, scout, shuffle, _p(st))
+        return st

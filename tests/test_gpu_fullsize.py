@@ -46,7 +46,8 @@ def test_1024_default_5_ticks_reference_digest():
 def test_4096_multilayer_one_tick_bit_exact_and_invariants():
     cfg = load_cfg("rockgravelpebblessand.soil")
     n = 4096
-    sm = SoilMachine(cfg, n, seed=0, pool=3 * n * n)
+    from soilmachine_amd import capi
+    sm = SoilMachine(cfg, n, seed=0, pool=3 * n * n, engine=capi.ENGINE_SPECULATIVE)
     o = Oracle(cfg, n, n, seed=0, pool=3 * n * n)
     o.initialize()
     s0 = sm.map.snapshot()

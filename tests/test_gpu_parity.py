@@ -12,7 +12,7 @@ from soilmachine_amd.snapshot import compare
 
 pytestmark = pytest.mark.gpu
 DIG = digests()
-ENGINES = [capi.ENGINE_SERIAL]
+ENGINES = [capi.ENGINE_SERIAL, capi.ENGINE_SPECULATIVE]
 
 
 def bits(a):
@@ -156,10 +156,11 @@ def test_ticks_reproduce_reference_digests(case, engine):
 
 
 @pytest.mark.slow
-def test_lakes_and_nested_particles_100_ticks():
+@pytest.mark.parametrize("engine", ENGINES)
+def test_lakes_and_nested_particles_100_ticks(engine):
     d = DIG["default256_t100"]
     cfg = load_cfg(d["soil"])
-    sm = SoilMachine(cfg, 256, seed=0, nwater=d["nwater"], nwind=0, dowind=False)
+    sm = SoilMachine(cfg, 256, seed=0, nwater=d["nwater"], nwind=0, dowind=False, engine=engine)
     sm.tick(100, sync=True)
     s = sm.map.snapshot()
     g = s.digest()
@@ -168,11 +169,12 @@ def test_lakes_and_nested_particles_100_ticks():
     assert c["nested_particles"] > 100000 and c["grid_active_cells"] > 0
 
 
-def test_phase_by_phase_equals_tick_and_oracle():
+@pytest.mark.parametrize("engine", ENGINES)
+def test_phase_by_phase_equals_tick_and_oracle(engine):
     cfg = load_cfg("rocksand.soil")
     n = 80
-    a = SoilMachine(cfg, n, seed=4, nwater=120, nwind=80)
-    b = SoilMachine(cfg, n, seed=4, nwater=120, nwind=80)
+    a = SoilMachine(cfg, n, seed=4, nwater=120, nwind=80, engine=engine)
+    b = SoilMachine(cfg, n, seed=4, nwater=120, nwind=80, engine=engine)
     o = Oracle(cfg, n, n, seed=4)
     o.initialize()
     for _ in range(4):
@@ -216,3 +218,23 @@ def test_pool_exhaustion_is_reported_not_silent():
     assert not compare(m.snapshot(), o.snapshot())
     assert m.counters()["pool_overflow"] == o.counters()["pool_overflow"]
     assert m.counters()["pool_free"] == o.counters()["pool_free"]
+
+
+def test_speculative_engine_statistics_and_exactness_1024():
+    """The speculative engine really runs speculatively (rounds > 0, most particles commit without a serial
+    fallback) and lands on the same bits as the oracle on a map big enough to have parallelism."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 1024
+    sm = SoilMachine(cfg, n, seed=0, engine=capi.ENGINE_SPECULATIVE)
+    o = Oracle(cfg, n, n, seed=0)
+    o.initialize()
+    sm.tick(2, sync=True)
+    for _ in range(2):
+        o.tick(cfg.NWATER, cfg.NWIND, True, True)
+    assert not compare(sm.map.snapshot(), o.snapshot())
+    c = sm.map.counters()
+    assert c["spec_rounds"] > 0
+    oc = o.counters()
+    for k in ("steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
+              "cascade_transfers", "rand_calls"):
+        assert oc[k] == c[k], k
