@@ -102,6 +102,8 @@ struct Water {            // WaterParticle (water.h:9-41); `param` is re-read fr
   int spill, ix, iy;
   float friction;         // param.friction after the frequency scaling of move() (water.h:53)
   uint32_t surface, contains;
+  double csize, cfloor;   // view of the column at ipos taken by move() (nothing writes it before interact())
+  uint32_t ctype;
 };
 struct Wind {             // WindParticle (wind.h:11-46)
   f2 pos;
@@ -109,6 +111,8 @@ struct Wind {             // WindParticle (wind.h:11-46)
   double sediment, height, sheight;
   int ix, iy;
   uint32_t surface, contains;
+  double csize, cfloor;   // view of the column at ipos taken by move()
+  uint32_t ctype;
 };
 
 // One suspended WaterParticle::cascade invocation (water.h:151-283): centre, remaining spill budget,
@@ -155,52 +159,75 @@ struct Sim {
     const uint32_t t = cell(x, y).type;
     return t == EMPTY ? 0u : t;
   }
+  // ---- batched access: announce N cells to the policy at once, then load their (size, floor, type) views with
+  // all loads in flight together. One memory round trip per batch instead of one per cell: the exact engines
+  // are latency-bound (DESIGN.md "Per-step latency"), so the step is organised as three batches.
+  struct View { double size, floor; uint32_t type; };
+  SMX_D static double vh(const View& v) { return v.floor + v.size; }
+  SMX_D static uint32_t vsurf(const View& v) { return v.type == EMPTY ? 0u : v.type; }
+  SMX_D View load_view(size_t c) const {
+    const Sec& r = s.cells[c];
+    View v; v.size = r.size; v.floor = r.floor; v.type = r.type;
+    return v;
+  }
+  template <int N>
+  SMX_D void batch(const size_t (&c)[N], View (&v)[N]) {
+    if (!pol.template touch_batch<N>(s, c)) ab = true;
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = load_view(c[i]);
+  }
+
   SMX_D double height_bilinear(f2 pos) {                    // Layermap::height(vec2) layermap.h:427-439
     double h = 0.0;
     const float fx = floorf(pos.x), fy = floorf(pos.y);
     const int px = (int)fx, py = (int)fy;
     const float wx = pos.x - fx, wy = pos.y - fy;
-    const double h00 = height(px, py), h10 = height(px + 1, py), h01 = height(px, py + 1), h11 = height(px + 1, py + 1);
+    const size_t c00 = cidx(px, py);
+    const size_t cc[4] = {c00, c00 + (size_t)s.dimy, c00 + 1, c00 + (size_t)s.dimy + 1};
+    View v[4];
+    batch<4>(cc, v);
+    const double h00 = vh(v[0]), h10 = vh(v[1]), h01 = vh(v[2]), h11 = vh(v[3]);
     h += (1.0 - wx) * (1.0 - wy) * h00;
     h += (1.0 - wx) * wy * h10;                             // crossed weights as in the reference (:434-435)
     h += wx * (1.0 - wy) * h01;
     h += wx * wy * h11;                                     // wx*wy is a FLOAT product (:436)
     return h;
   }
-  SMX_D f3 normal(int x, int y) {                           // Layermap::normal(ivec2) layermap.h:341-377
+  // Layermap::normal(ivec2) layermap.h:341-377; also hands back the centre cell's view (height / surface of ipos)
+  SMX_D f3 normal(int x, int y, View& centre) {
     const int SC = s.scale;
     const bool xm = x > 0, xp = x < s.dimx - 1, ym = y > 0, yp = y < s.dimy - 1;
-    const double h0 = height(x, y);
-    const double hxm = xm ? height(x - 1, y) : 0.0, hxp = xp ? height(x + 1, y) : 0.0;
-    const double hym = ym ? height(x, y - 1) : 0.0, hyp = yp ? height(x, y + 1) : 0.0;
+    const size_t c0 = cidx(x, y);
+    const size_t cc[5] = {c0, xm ? c0 - (size_t)s.dimy : c0, xp ? c0 + (size_t)s.dimy : c0, ym ? c0 - 1 : c0, yp ? c0 + 1 : c0};
+    View v[5];
+    batch<5>(cc, v);
+    centre = v[0];
+    const double h0 = vh(v[0]);
+    const double hxm = xm ? vh(v[1]) : 0.0, hxp = xp ? vh(v[2]) : 0.0;
+    const double hym = ym ? vh(v[3]) : 0.0, hyp = yp ? vh(v[4]) : 0.0;
     f3 n = {0.f, 0.f, 0.f};
     const f3 p = {(float)x, (float)(SC * h0), (float)y};
     const f3 bm = {(float)(x - 1), (float)(SC * hxm), (float)y}, bp = {(float)(x + 1), (float)(SC * hxp), (float)y};
     const f3 cm = {(float)x, (float)(SC * hym), (float)(y - 1)}, cp = {(float)x, (float)(SC * hyp), (float)(y + 1)};
     int k = 0;
-    if (xm && ym) { f3 v = cross3(sub3(cm, p), sub3(bm, p)); n.x += v.x; n.y += v.y; n.z += v.z; k++; }
-    if (xm && yp) { f3 v = cross3(sub3(cp, p), sub3(bm, p)); n.x -= v.x; n.y -= v.y; n.z -= v.z; k++; }
-    if (xp && ym) { f3 v = cross3(sub3(cm, p), sub3(bp, p)); n.x -= v.x; n.y -= v.y; n.z -= v.z; k++; }
-    if (xp && yp) { f3 v = cross3(sub3(cp, p), sub3(bp, p)); n.x += v.x; n.y += v.y; n.z += v.z; k++; }
+    if (xm && ym) { f3 w = cross3(sub3(cm, p), sub3(bm, p)); n.x += w.x; n.y += w.y; n.z += w.z; k++; }
+    if (xm && yp) { f3 w = cross3(sub3(cp, p), sub3(bm, p)); n.x -= w.x; n.y -= w.y; n.z -= w.z; k++; }
+    if (xp && ym) { f3 w = cross3(sub3(cm, p), sub3(bp, p)); n.x -= w.x; n.y -= w.y; n.z -= w.z; k++; }
+    if (xp && yp) { f3 w = cross3(sub3(cp, p), sub3(bp, p)); n.x += w.x; n.y += w.y; n.z += w.z; k++; }
     const float kf = (float)k;
     const f3 q = {n.x / kf, n.y / kf, n.z / kf};
     return normalize3(q);
   }
+  SMX_D f3 normal(int x, int y) { View c; return normal(x, y, c); }
 
   // Stable descending sort of the <= 8 in-bounds neighbours by height == the reference's std::sort (an
   // insertion sort for n <= 16): ties keep neighbour-table order, i.e. the order is
   // the total order (h desc, code asc). Done as a 19-comparator sorting network on registers; out-of-bounds
   // slots carry h = -inf and sort to the end (heights are >= 0).
-  SMX_D Sorted sorted_neighbours(int ix, int iy) {          // particle.h:43-60 == water.h:168-185
-    double h[8]; int code[8]; int num = 0;
+  SMX_D static Sorted sort8(double (&h)[8]) {
+    int code[8]; int num = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
-      const bool in = !(nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0);
-      h[k] = in ? height(nx, ny) : -INFINITY;
-      code[k] = k;
-      num += in ? 1 : 0;
-    }
+    for (int k = 0; k < 8; k++) { code[k] = k; num += (h[k] > -INFINITY) ? 1 : 0; }
 #define SMX_CE(i, j)                                                                             \
     {                                                                                            \
       const bool sw = (h[j] > h[i]) || (h[j] == h[i] && code[j] < code[i]);                      \
@@ -220,6 +247,27 @@ struct Sim {
 #pragma unroll
     for (int i = 0; i < 8; i++) r.codes |= (uint32_t)code[i] << (4 * i);
     return r;
+  }
+  // the 3x3 block around (ix,iy): cells[k] / views[k] for neighbour code k (out-of-bounds -> the centre cell,
+  // flagged by inb[k] = false), index 8 = centre
+  SMX_D void block3x3(int ix, int iy, size_t (&cc)[9], bool (&inb)[8], View (&v)[9]) {
+    const size_t c0 = cidx(ix, iy);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
+      inb[k] = !(nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0);
+      cc[k] = inb[k] ? cidx(nx, ny) : c0;
+    }
+    cc[8] = c0;
+    batch<9>(cc, v);
+  }
+  SMX_D Sorted sorted_neighbours(int ix, int iy) {          // particle.h:43-60 == water.h:168-185
+    size_t cc[9]; bool inb[8]; View v[9];
+    block3x3(ix, iy, cc, inb, v);
+    double h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = inb[k] ? vh(v[k]) : -INFINITY;   // heights are >= 0: out-of-bounds slots sort last
+    return sort8(h);
   }
 
   // ---------------- wet bookkeeping for the grid pass ----------------
@@ -305,10 +353,11 @@ struct Sim {
     if (sat != 0.0) on_sat(x, y);
   }
   // Layermap::add(pos, pool.get(size, type)) (layermap.h:230-307 + :89-103)
-  SMX_D void add(int x, int y, double size, uint32_t type) {
+  // `owned`: the caller has already announced this cell to the policy in the current step
+  SMX_D void add(int x, int y, double size, uint32_t type, bool owned = false) {
     if (ab) return;
-    if constexpr (P::READ_ONLY) { (void)cell(x, y); return; }   // scout: footprint only, never writes
-    Sec& c = cell(x, y);
+    if constexpr (P::READ_ONLY) { if (!owned) (void)cell(x, y); return; }   // scout: footprint only, never writes
+    Sec& c = owned ? s.cells[cidx(x, y)] : cell(x, y);
     if (ab) return;
     // pool.get(): the reference takes a node for EVERY get (even if add() merges and returns it at once),
     // so get() fails exactly when live sections == capacity; add(NULL) is ignored (:233)
@@ -328,11 +377,11 @@ struct Sim {
     place(x, y, c, size, type, 0.0);
   }
   // Layermap::remove (layermap.h:310-339); *popped tells the caller that the top section went away
-  SMX_D double remove(int x, int y, double h, bool* popped = nullptr) {
+  SMX_D double remove(int x, int y, double h, bool* popped = nullptr, bool owned = false) {
     if (popped) *popped = false;
     if (ab) return 0.0;
-    if constexpr (P::READ_ONLY) { (void)cell(x, y); return 0.0; }
-    Sec& c = cell(x, y);
+    if constexpr (P::READ_ONLY) { if (!owned) (void)cell(x, y); return 0.0; }
+    Sec& c = owned ? s.cells[cidx(x, y)] : cell(x, y);
     if (ab) return 0.0;
     if (c.type == EMPTY) return 0.0;
     if (c.size <= 0.0) { pop_top(c); sync_air_flag(x, y, c.type); if (popped) *popped = true; return 0.0; }
@@ -343,40 +392,93 @@ struct Sim {
     return 0.0;
   }
 
+  // ---- Layermap::remove / add on a cell whose view is already in registers (and which is owned). The common
+  // cases touch only the `size` field: one 8-byte store, no load. Anything structural (pop, push, water swap,
+  // empty column) goes through the generic primitives and the view is re-loaded. Bit-identical by construction:
+  // the fast branches are exactly the generic code paths with the loads removed.
+  SMX_D double remove_v(int x, int y, size_t c, View& v, double h) {
+    if (ab) return 0.0;
+    if constexpr (P::READ_ONLY) return 0.0;
+    if (v.type != EMPTY && v.size > 0.0) {
+      if (h <= 0.0) return 0.0;                             // layermap.h:325
+      if (h < v.size) {                                     // :328-337 with diff < 0: shrink, nothing pops
+        v.size -= h;
+        s.cells[c].size = v.size;
+        return 0.0;
+      }
+    }
+    const double r = remove(x, y, h, nullptr, true);
+    v = load_view(c);
+    return r;
+  }
+  SMX_D void add_v(int x, int y, size_t c, View& v, double size, uint32_t type) {
+    if (ab) return;
+    if constexpr (P::READ_ONLY) return;
+    if (v.type == type && v.type != EMPTY && size > 0 && pol.can_get(s)) {   // layermap.h:249-253 elongate (pool.get + unget: net 0)
+      v.size += size;
+      s.cells[c].size = v.size;
+      return;
+    }
+    add(x, y, size, type, true);
+    v = load_view(c);
+  }
+
   // ---------------- Particle::cascade particle.h:24-101 ----------------
   // LOOP: remaining recursion budget (transferloop). Water uses 0, wind 1 (wind.h:112,126,129).
+  // The 3x3 block is fetched as ONE batch; the neighbour loop then runs on register views: a transfer only
+  // changes the centre and the current neighbour, and every neighbour is visited once, so the views stay exact.
   template <int LOOP>
   SMX_D void particle_cascade(f2 pos) {
     n_casc++;
     const int ix = (int)roundf(pos.x), iy = (int)roundf(pos.y);
-    const Sorted sn = sorted_neighbours(ix, iy);
+    size_t cc[9]; bool inb[8]; View v[9];
+    block3x3(ix, iy, cc, inb, v);
     if (ab) return;
+    double hs[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) hs[k] = inb[k] ? vh(v[k]) : -INFINITY;
+    const Sorted sn = sort8(hs);
     const double sc = (double)(float)s.scale, d80 = (double)80.0f;
     int transferloop = LOOP;
+    View ctr = v[8];
     for (int i = 0; i < sn.num; i++) {
       const int k = (sn.codes >> (4 * i)) & 15;
+      View nb = v[0]; size_t cn = cc[0];
+#pragma unroll
+      for (int j = 1; j < 8; j++) if (k == j) { nb = v[j]; cn = cc[j]; }
       const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
-      const float diff = (float)((height(ix, iy) - height(nx, ny)) * sc / d80);
+      const float diff = (float)((vh(ctr) - vh(nb)) * sc / d80);
       if (diff == 0) continue;
-      const int tx = (diff > 0) ? ix : nx, ty = (diff > 0) ? iy : ny;
-      const int bx = (diff > 0) ? nx : ix, by = (diff > 0) ? ny : iy;
-      const Sec& T = cell(tx, ty);
-      const uint32_t type = (T.type == EMPTY) ? 0u : T.type;
+      const bool down = diff > 0;                           // centre is the higher column
+      const View& T = down ? ctr : nb;
+      const uint32_t type = vsurf(T);
       const float excess = fabsf(diff) - soils[type].maxdiff;
       if (excess <= 0) continue;
       float transfer = soils[type].settling * excess / 2.0f;
-      bool recascade = false;
       const double tsize = T.size;
       if ((double)transfer > tsize) transfer = (float)tsize;
       const uint32_t casc = soils[type].cascades;
-      if (ab) return;
-      if (remove(tx, ty, (double)transfer) != 0) recascade = true;
-      add(bx, by, (double)transfer, casc);
-      n_casc_tr++;
-      if constexpr (LOOP > 0) {
-        if (recascade && transferloop > 0) { --transferloop; particle_cascade<0>(f2{(float)nx, (float)ny}); }
+      bool recascade = false;
+      if (down) {
+        if (remove_v(ix, iy, cc[8], ctr, (double)transfer) != 0) recascade = true;
+        add_v(nx, ny, cn, nb, (double)transfer, casc);
+      } else {
+        if (remove_v(nx, ny, cn, nb, (double)transfer) != 0) recascade = true;
+        add_v(ix, iy, cc[8], ctr, (double)transfer, casc);
       }
+      n_casc_tr++;
       if (ab) return;
+      if constexpr (LOOP > 0) {
+        if (recascade && transferloop > 0) {
+          --transferloop;
+          particle_cascade<0>(f2{(float)nx, (float)ny});
+          if (ab) return;
+          // the nested cascade may have moved material in this block: refresh every view (cells are owned)
+#pragma unroll
+          for (int j = 0; j < 9; j++) v[j] = load_view(cc[j]);
+          ctr = v[8];
+        }
+      }
     }
   }
 
@@ -392,14 +494,16 @@ struct Sim {
   }
   SMX_D bool water_move(Water& p) {                          // water.h:43-73
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    const f3 n = normal(p.ix, p.iy);
-    p.surface = surface(p.ix, p.iy);
+    View cv;
+    const f3 n = normal(p.ix, p.iy, cv);                     // batch A: plus-stencil
+    p.csize = cv.size; p.cfloor = cv.floor; p.ctype = cv.type;
+    p.surface = vsurf(cv);
     if (ab) return false;
     p.evaprate = 0.01;
     const size_t fi = fidx(p.ix, p.iy);
+    const float fr = s.wfreq[fi];
     if constexpr (!P::READ_ONLY)
       s.wtrack[fi] = (float)((double)s.wtrack[fi] + p.volume);          // updatefrequency :348-351
-    const float fr = s.wfreq[fi];
     p.friction = soils[p.surface].friction * (1.0f - fr);
     p.evaprate = p.evaprate * (double)(1.0f - 0.2f * fr);
     const f2 nxz = {n.x, n.z};
@@ -420,23 +524,26 @@ struct Sim {
   }
   SMX_D bool water_interact(Water& p) {                      // water.h:75-121
     const SoilP& param = soils[p.surface];
-    double c_eq = param.solubility * (height(p.ix, p.iy) - height_bilinear(p.pos)) * (double)s.scale / 80.0;
+    View cv; cv.size = p.csize; cv.floor = p.cfloor; cv.type = p.ctype;   // height(ipos): unchanged since move()
+    const double hb = height_bilinear(p.pos);                // batch B: the 2x2 block under the new position
+    double c_eq = param.solubility * (vh(cv) - hb) * (double)s.scale / 80.0;
     if (ab) return false;
     if (c_eq < 0.0) c_eq = 0.0;
     if (c_eq > 1.0) c_eq = 1.0;
     const size_t fi = fidx(p.ix, p.iy);
     if ((double)(soils[p.contains].erosionrate) < s.wfreq[fi]) p.contains = soils[p.contains].erodes;
     const double cdiff = c_eq - p.sediment;
+    const size_t cc = cidx(p.ix, p.iy);
     if (cdiff > 0) {
       p.sediment += param.equrate * cdiff;
-      p.contains = soils[surface(p.ix, p.iy)].transports;
-      double diff = remove(p.ix, p.iy, param.equrate * cdiff * p.volume);
-      while (fabs(diff) > 1E-8) diff = remove(p.ix, p.iy, diff);
+      p.contains = soils[vsurf(cv)].transports;              // soils[map.surface(ipos)].transports (:94)
+      double diff = remove_v(p.ix, p.iy, cc, cv, param.equrate * cdiff * p.volume);
+      while (fabs(diff) > 1E-8) diff = remove_v(p.ix, p.iy, cc, cv, diff);
     } else if (cdiff < 0) {
       p.sediment += soils[p.contains].equrate * cdiff;
-      add(p.ix, p.iy, -soils[p.contains].equrate * cdiff * p.volume, p.contains);
+      add_v(p.ix, p.iy, cc, cv, -soils[p.contains].equrate * cdiff * p.volume, p.contains);
     }
-    particle_cascade<0>(p.pos);
+    particle_cascade<0>(p.pos);                              // batch C: the 3x3 block around the new position
     if (ab) return false;
     p.sediment /= (1.0 - p.evaprate);
     if (p.sediment > 1.0) p.sediment = 1.0;
@@ -591,13 +698,15 @@ struct Sim {
     const double gravity = 0.25, winddominance = 0.2, windfriction = 0.8;
     if (soils[p.contains].suspension == 0.0) return false;
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    const f3 n = normal(p.ix, p.iy);
-    p.surface = surface(p.ix, p.iy);
+    View cv;
+    const f3 n = normal(p.ix, p.iy, cv);                     // batch A
+    p.csize = cv.size; p.cfloor = cv.floor; p.ctype = cv.type;
+    p.surface = vsurf(cv);
     if (ab) return false;
     const size_t fi = fidx(p.ix, p.iy);
     if constexpr (!P::READ_ONLY)
       s.windfreq[fi] = (float)(0.5 * s.windfreq[fi] + 0.5f);            // wind.h:49-52
-    p.sheight = height(p.ix, p.iy) * (float)s.scale / 80.0f;
+    p.sheight = vh(cv) * (float)s.scale / 80.0f;
     if (p.height < p.sheight) p.height = p.sheight;
     if (p.height > p.sheight) {
       p.speed.y = (float)(p.speed.y - gravity);
@@ -616,20 +725,37 @@ struct Sim {
   SMX_D bool wind_interact(Wind& p) {                        // wind.h:94-136
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
     const SoilP& param = soils[p.surface];
-    const double hb = height_bilinear(p.pos);
+    // batch B: the 2x2 block under the new position; npos = round(pos) is always one of its four cells
+    const float fx = floorf(p.pos.x), fy = floorf(p.pos.y);
+    const int px = (int)fx, py = (int)fy;
+    const float wx = p.pos.x - fx, wy = p.pos.y - fy;
+    const size_t c00 = cidx(px, py);
+    const size_t cb[4] = {c00, c00 + (size_t)s.dimy, c00 + 1, c00 + (size_t)s.dimy + 1};
+    View vb[4];
+    batch<4>(cb, vb);
     if (ab) return false;
+    double hb = 0.0;                                         // Layermap::height(vec2) layermap.h:427-439
+    hb += (1.0 - wx) * (1.0 - wy) * vh(vb[0]);
+    hb += (1.0 - wx) * wy * vh(vb[1]);
+    hb += wx * (1.0 - wy) * vh(vb[2]);
+    hb += wx * wy * vh(vb[3]);
+    const int kn = (nx - px) + 2 * (ny - py);                // which of the four is npos
+    View nv = vb[0];
+    if (kn == 1) nv = vb[1]; else if (kn == 2) nv = vb[2]; else if (kn == 3) nv = vb[3];
+    const size_t cn = cidx(nx, ny), ci = cidx(p.ix, p.iy);
+    View cv; cv.size = p.csize; cv.floor = p.cfloor; cv.type = p.ctype;
     if (p.height <= hb * (float)s.scale / 80.0f) {
       if (param.transports == p.contains) {
-        const double force = sqrtf(dot3(p.speed, p.speed)) * (height(nx, ny) - p.height) * (float)s.scale / 80.0f * (1.0f - p.sediment);
-        if (ab) return false;
-        const double diff = remove(p.ix, p.iy, param.suspension * force);
+        const double force = sqrtf(dot3(p.speed, p.speed)) * (vh(nv) - p.height) * (float)s.scale / 80.0f * (1.0f - p.sediment);
+        const double diff = remove_v(p.ix, p.iy, ci, cv, param.suspension * force);
         p.sediment += (param.suspension * force - diff);
         particle_cascade<1>(f2{(float)p.ix, (float)p.iy});
       }
     } else if (param.suspension > 0.0) {
       p.sediment -= soils[p.contains].suspension * p.sediment;
-      add(nx, ny, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
-      add(p.ix, p.iy, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
+      add_v(nx, ny, cn, nv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
+      if (cn == ci) cv = nv;                                 // npos == ipos: the second add sees the first
+      add_v(p.ix, p.iy, ci, cv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
       particle_cascade<1>(f2{(float)p.ix, (float)p.iy});
       particle_cascade<1>(f2{(float)nx, (float)ny});
     }

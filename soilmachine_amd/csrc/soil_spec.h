@@ -78,7 +78,7 @@ struct SpecPart {                             // one particle of the phase
   uint32_t status, kill, aborted, fail_cell;
   uint32_t noff, nested, nlog, nchunks;
   uint32_t ndeps, dep_overflow, nalloc, nfree;
-  uint32_t overflow, attempts, rolled, pad;
+  uint32_t overflow, attempts, rolled, blocked;
   long long live_delta;
   unsigned long long ctr[SPEC_NCTR];
   uint32_t deps[MAX_DEPS];
@@ -125,6 +125,11 @@ struct ScoutPolicy {
   SMX_D ScoutPolicy(const SpecShared& sh_, uint32_t p) : sh(sh_), pid(p), out(sh_.scout_cells + (size_t)p * SCOUT_CAP) {}
   SMX_D bool touch(const DevState&, size_t c) {
     if (c != last && c != last2) { last2 = last; last = c; if (len < SCOUT_CAP) out[len++] = (uint32_t)c; }
+    return true;
+  }
+  template <int N> SMX_D bool touch_batch(const DevState& s, const size_t (&c)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) touch(s, c[i]);
     return true;
   }
   SMX_D void finish() { sh.scout_len[pid] = len; }
@@ -174,9 +179,23 @@ struct SpecPolicy {
 
   SMX_D bool touch(const DevState& s, size_t c) {
     if (c == last) return true;
-    uint32_t v = SMX_A_LOAD(&sh.stamp[c]);
+    const uint32_t v = SMX_A_LOAD(&sh.stamp[c]);
     if (v == me) { last = c; return true; }
+    return touch_slow(s, c, v);
+  }
+  // all stamp loads of a batch are in flight together; only cells that are not ours yet take the slow path
+  template <int N> SMX_D bool touch_batch(const DevState& s, const size_t (&c)[N]) {
+    uint32_t v[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = SMX_A_LOAD(&sh.stamp[c[i]]);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; i++) if (ok && v[i] != me) ok = touch_slow(s, c[i], v[i]);
+    return ok;
+  }
+  SMX_D bool touch_slow(const DevState& s, size_t c, uint32_t v) {
     while (true) {
+      if (v == me) return true;                             // (a batch may name the same cell twice)
       if (v == POISON) { fail_cell = (uint32_t)c; return false; }
       if (v > me) {                                         // a later particle got here first: it must be undone
         SMX_A_STORE(&sh.part[v - 1].kill, 1u);
@@ -474,7 +493,7 @@ SMX_D void spec_begin_team(const DevState& s, const SpecShared& sh, uint32_t n, 
     SpecPart& q = sh.part[p];
     q.status = ST_PENDING; q.kill = 0; q.aborted = 0; q.fail_cell = NOCLAIM; q.noff = 0; q.nested = 0; q.nlog = 0;
     q.nchunks = 0; q.ndeps = 0; q.dep_overflow = 0; q.nalloc = 0; q.nfree = 0; q.overflow = 0; q.attempts = 0; q.rolled = 0;
-    q.live_delta = 0;
+    q.live_delta = 0; q.blocked = 0;
     sh.pending[p] = p;
     sh.scout_len[p] = 0;
   }
@@ -497,26 +516,27 @@ SMX_D void spec_end(const DevState& s, const SpecShared& sh, uint32_t nparticles
 // the cell that attempt failed at. spec_claim_one publishes it (claim[c] = min pending id); spec_blocked asks
 // whether a LOWER pending particle wants any of those cells -- then this particle sits the round out.
 template <class F>
-SMX_D void spec_for_footprint(const SpecShared& sh, uint32_t pid, F f) {
+SMX_D void spec_for_footprint(const SpecShared& sh, uint32_t pid, uint32_t lane, uint32_t nl, F f) {
   const SpecPart& q = sh.part[pid];
   const uint32_t sl = sh.scout_len[pid];
   const uint32_t* sc = sh.scout_cells + (size_t)pid * SCOUT_CAP;
-  for (uint32_t k = 0; k < sl; k++) if (!f(sc[k])) return;
+  for (uint32_t k = lane; k < sl; k += nl) if (!f(sc[k])) return;
   if (q.attempts != 0) {
-    for (uint32_t k = 0; k < q.nlog; k++) {
+    for (uint32_t k = lane; k < q.nlog; k += nl) {
       const SpecLog* e = spec_entry(sh, pid, k);
       if (e->cell & NODE_ENTRY) continue;
       if (!f(e->cell)) return;
     }
-    if (q.fail_cell != NOCLAIM) f(q.fail_cell);
+    if (lane == 0 && q.fail_cell != NOCLAIM) f(q.fail_cell);
   }
 }
-SMX_D void spec_claim_one(const SpecShared& sh, uint32_t pid) {
-  spec_for_footprint(sh, pid, [&](uint32_t c) { if (SMX_A_LOAD(&sh.claim[c]) > pid) SMX_A_MIN(&sh.claim[c], pid); return true; });
+// (lane, nl): the footprint is walked by a team of nl lanes, lane `lane` takes every nl-th cell
+SMX_D void spec_claim_one(const SpecShared& sh, uint32_t pid, uint32_t lane, uint32_t nl) {
+  spec_for_footprint(sh, pid, lane, nl, [&](uint32_t c) { if (SMX_A_LOAD(&sh.claim[c]) > pid) SMX_A_MIN(&sh.claim[c], pid); return true; });
 }
-SMX_D bool spec_blocked(const SpecShared& sh, uint32_t pid) {
+SMX_D bool spec_blocked(const SpecShared& sh, uint32_t pid, uint32_t lane, uint32_t nl) {
   bool blocked = false;
-  spec_for_footprint(sh, pid, [&](uint32_t c) { if (SMX_A_LOAD(&sh.claim[c]) < pid) { blocked = true; return false; } return true; });
+  spec_for_footprint(sh, pid, lane, nl, [&](uint32_t c) { if (SMX_A_LOAD(&sh.claim[c]) < pid) { blocked = true; return false; } return true; });
   return blocked;
 }
 
@@ -538,7 +558,7 @@ SMX_D void spec_scout_one(const DevState& s, const SoilP* soils, const SpecShare
 
 template <bool WIND>
 SMX_D void spec_exec_one(const DevState& s, const SoilP* soils, const SpecShared& sh, uint32_t pid) {
-  if (spec_blocked(sh, pid)) { SMX_A_ADD(&sh.ctrl[SC_SKIPPED], 1u); return; }
+  if (sh.part[pid].blocked) { SMX_A_ADD(&sh.ctrl[SC_SKIPPED], 1u); return; }
   SMX_A_ADD(&sh.ctrl[SC_EXECUTED], 1u);
   SpecPolicy pol(sh, pid);
   Sim<SpecPolicy> sim(s, soils, pol);

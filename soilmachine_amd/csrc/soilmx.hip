@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -134,29 +135,40 @@ __global__ void __launch_bounds__(64) k_grid_serial(DevState s) {
 // ---------------- speculative engine kernels (protocol: soil_spec.h) ----------------
 // SPEC_LANES particles per wave: each lane walks one particle; fewer lanes per wave = less divergence
 // serialisation and more CUs in play (a phase has only ~10^3 particles, the chip has 256 CUs).
-constexpr int SPEC_LANES = 16;
+static int spec_lanes() {
+  static int v = 0;
+  if (!v) { const char* e = getenv("SMX_SPEC_LANES"); v = e ? atoi(e) : 8; if (v < 1) v = 1; if (v > 64) v = 64; }
+  return v;
+}
 
 __global__ void __launch_bounds__(256) k_spec_begin(DevState s, SpecShared sh, uint32_t n) {
   spec_begin_team(s, sh, n, threadIdx.x, blockDim.x);
 }
 template <bool WIND>
-__global__ void __launch_bounds__(64) k_spec_scout(DevState s, SpecShared sh) {
+__global__ void __launch_bounds__(64) k_spec_scout(DevState s, SpecShared sh, uint32_t lanes) {
   SMX_LOAD_SOILS(soils_sh)
   const uint32_t n = sh.ctrl[SC_N];
-  const uint32_t pid = blockIdx.x * SPEC_LANES + threadIdx.x;
-  if (threadIdx.x >= SPEC_LANES || pid >= n) return;
+  const uint32_t pid = blockIdx.x * lanes + threadIdx.x;
+  if (threadIdx.x >= lanes || pid >= n) return;
   spec_scout_one<WIND>(s, soils_sh, sh, pid);
 }
+// one wave per pending particle walks its predicted footprint: publish claims, then (next kernel) test them
 __global__ void __launch_bounds__(64) k_spec_claim(SpecShared sh) {
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= sh.ctrl[SC_NPENDING]) return;
-  spec_claim_one(sh, sh.pending[i]);
+  if (blockIdx.x >= sh.ctrl[SC_NPENDING]) return;
+  spec_claim_one(sh, sh.pending[blockIdx.x], threadIdx.x, 64u);
+}
+__global__ void __launch_bounds__(64) k_spec_select(SpecShared sh) {
+  if (blockIdx.x >= sh.ctrl[SC_NPENDING]) return;
+  const uint32_t pid = sh.pending[blockIdx.x];
+  const bool b = spec_blocked(sh, pid, threadIdx.x, 64u);
+  const bool any = __any(b);
+  if (threadIdx.x == 0) sh.part[pid].blocked = any ? 1u : 0u;
 }
 template <bool WIND>
-__global__ void __launch_bounds__(64) k_spec_exec(DevState s, SpecShared sh) {
+__global__ void __launch_bounds__(64) k_spec_exec(DevState s, SpecShared sh, uint32_t lanes) {
   SMX_LOAD_SOILS(soils_sh)
-  const uint32_t i = blockIdx.x * SPEC_LANES + threadIdx.x;
-  if (threadIdx.x >= SPEC_LANES || i >= sh.ctrl[SC_NPENDING]) return;
+  const uint32_t i = blockIdx.x * lanes + threadIdx.x;
+  if (threadIdx.x >= lanes || i >= sh.ctrl[SC_NPENDING]) return;
   spec_exec_one<WIND>(s, soils_sh, sh, sh.pending[i]);
 }
 __global__ void __launch_bounds__(256) k_spec_boundary(DevState s, SpecShared sh) {
@@ -671,14 +683,16 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
   hipStream_t st = ctx->stream;
   HIPCHK(hipMemsetAsync(sh.stamp, 0, ctx->ncells * 4, st));
   hipLaunchKernelGGL(k_spec_begin, dim3(1), dim3(256), 0, st, ctx->d, sh, (uint32_t)n);
-  if (!wind) hipLaunchKernelGGL(k_spec_scout<false>, dim3((n + SPEC_LANES - 1) / SPEC_LANES), dim3(64), 0, st, ctx->d, sh);
+  const uint32_t L = (uint32_t)spec_lanes();
+  if (!wind) hipLaunchKernelGGL(k_spec_scout<false>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
   uint32_t np = (uint32_t)n > SPEC_WINDOW ? SPEC_WINDOW : (uint32_t)n, last_base = 0, stall = 0;
   bool fallback = false;
   for (int round = 0;; round++) {
     HIPCHK(hipMemsetAsync(sh.claim, 0xFF, ctx->ncells * 4, st));
-    hipLaunchKernelGGL(k_spec_claim, dim3((np + 63) / 64), dim3(64), 0, st, sh);
-    if (wind) hipLaunchKernelGGL(k_spec_exec<true>, dim3((np + SPEC_LANES - 1) / SPEC_LANES), dim3(64), 0, st, ctx->d, sh);
-    else hipLaunchKernelGGL(k_spec_exec<false>, dim3((np + SPEC_LANES - 1) / SPEC_LANES), dim3(64), 0, st, ctx->d, sh);
+    hipLaunchKernelGGL(k_spec_claim, dim3(np), dim3(64), 0, st, sh);
+    hipLaunchKernelGGL(k_spec_select, dim3(np), dim3(64), 0, st, sh);
+    if (wind) hipLaunchKernelGGL(k_spec_exec<true>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+    else hipLaunchKernelGGL(k_spec_exec<false>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
     hipLaunchKernelGGL(k_spec_boundary, dim3(1), dim3(256), 0, st, ctx->d, sh);
     HIPCHK(hipMemcpyAsync(ctx->h_ctrl, sh.ctrl, SC_COUNT * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

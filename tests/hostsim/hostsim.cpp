@@ -247,7 +247,8 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
   while (true) {
     std::fill(b.claim.begin(), b.claim.end(), NOCLAIM);
     const uint32_t np = sh.ctrl[SC_NPENDING];
-    parallel_for(np, nthreads, [&](uint32_t i) { spec_claim_one(sh, sh.pending[i]); }, shuffle ? shuffle + 1 : 0);
+    parallel_for(np, nthreads, [&](uint32_t i) { spec_claim_one(sh, sh.pending[i], 0u, 1u); }, shuffle ? shuffle + 1 : 0);
+    parallel_for(np, nthreads, [&](uint32_t i) { const uint32_t pid = sh.pending[i]; sh.part[pid].blocked = spec_blocked(sh, pid, 0u, 1u) ? 1u : 0u; }, 0);
     parallel_for(np, nthreads, [&](uint32_t i) { spec_exec_one<WIND>(s, s.soils, sh, sh.pending[i]); }, shuffle ? shuffle + 2 + sh.ctrl[SC_ROUNDS] : 0);
     { static SpecWork* w = new SpecWork(); spec_boundary_team(s, sh, *w, 0u, 1u, []() {}); }
     if (sh.ctrl[SC_NPENDING] == 0 && sh.ctrl[SC_BASE] == n) break;
