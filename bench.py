@@ -144,18 +144,22 @@ def main():
         tmax, total_steps = float(tt.item()), float(ss.item())
 
     if rank == 0:
-        # dominant kernel = the phase with the largest HIP-event time
-        phases = {"water": (tm["ms_water"], tm["launches_water"], steps_w * B_WATER_STEP),
-                  "wind": (tm["ms_wind"], tm["launches_wind"], steps_d * B_WIND_STEP),
-                  "grid": (tm["ms_grid"], tm["launches_grid"], args.steps * n * n * 1)}   # classification reads 1 flag byte / cell
-        dom = max(phases, key=lambda k: phases[k][0])
-        ms, launches, nbytes = phases[dom]
-        kname = {"water": "k_water_serial", "wind": "k_wind_serial", "grid": "k_grid_classify+k_grid_serial"}[dom]
+        # dominant kernel = the particle kernel with the largest summed HIP-event time (every launch is bracketed
+        # by its own event pair on the context's stream inside libsoilmx)
+        spec = engine == capi.ENGINE_SPECULATIVE
+        kernels = {"water": (tm["ms_kernel_water"], tm["launches_kernel_water"], steps_w * B_WATER_STEP,
+                             "k_spec_exec<water>" if spec else "k_water_serial"),
+                   "wind": (tm["ms_kernel_wind"], tm["launches_kernel_wind"], steps_d * B_WIND_STEP,
+                            "k_spec_exec<wind>" if spec else "k_wind_serial")}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms, launches, nbytes, kname = kernels[dom]
         ach = (nbytes / max(launches, 1)) / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "avg_launch_ms": ms / max(launches, 1), "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
-                    "note": "exact engine: dependent-load latency bound, not bandwidth bound (DESIGN.md)"}
+                    "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                    "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
+                    "note": "exact engine: the particle kernels are instruction-issue / dependent-latency bound, "
+                            "not bandwidth bound (DESIGN.md); the O(cells) kernels are the HBM-streaming ones"}
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(n, nwater, nwind, 0, args.cpu_ticks, pool)

@@ -71,6 +71,10 @@ typedef struct smx_counters {
 typedef struct smx_timing {
   double ms_water, ms_grid, ms_wind, ms_freq;
   uint64_t launches_water, launches_grid, launches_wind, launches_freq;
+  /* the particle kernels alone (k_water_serial / k_wind_serial, or every k_spec_exec launch of the speculative
+   * engine), each launch bracketed by its own pair of HIP events */
+  double ms_kernel_water, ms_kernel_wind;
+  uint64_t launches_kernel_water, launches_kernel_wind;
 } smx_timing;
 
 /* ---- life cycle: replaces Layermap::Layermap + secpool::reserve (layermap.h:64-119,218-226) ---- */

@@ -133,11 +133,12 @@ __global__ void __launch_bounds__(64) k_grid_serial(DevState s) {
 }
 
 // ---------------- speculative engine kernels (protocol: soil_spec.h) ----------------
-// SPEC_LANES particles per wave: each lane walks one particle; fewer lanes per wave = less divergence
-// serialisation and more CUs in play (a phase has only ~10^3 particles, the chip has 256 CUs).
+// Particles per wave (env SMX_SPEC_LANES, default 1): a phase has only ~10^3 particles while the chip has 1024
+// SIMDs, and one particle step is issue-bound (a few thousand dependent instructions), so one particle per wave
+// is fastest (measured at 1024^2: 1 lane 349 ms, 8 lanes 429 ms, 32 lanes 537 ms per water phase).
 static int spec_lanes() {
   static int v = 0;
-  if (!v) { const char* e = getenv("SMX_SPEC_LANES"); v = e ? atoi(e) : 8; if (v < 1) v = 1; if (v > 64) v = 64; }
+  if (!v) { const char* e = getenv("SMX_SPEC_LANES"); v = e ? atoi(e) : 1; if (v < 1) v = 1; if (v > 64) v = 64; }
   return v;
 }
 
@@ -350,6 +351,8 @@ static void drain_events(smx_ctx* ctx) {
       case 0: ctx->timing.ms_water += ms; ctx->timing.launches_water++; break;
       case 1: ctx->timing.ms_grid += ms; ctx->timing.launches_grid++; break;
       case 2: ctx->timing.ms_wind += ms; ctx->timing.launches_wind++; break;
+      case 4: ctx->timing.ms_kernel_water += ms; ctx->timing.launches_kernel_water++; break;
+      case 5: ctx->timing.ms_kernel_wind += ms; ctx->timing.launches_kernel_wind++; break;
       default: ctx->timing.ms_freq += ms; ctx->timing.launches_freq++; break;
     }
     ctx->evpool.push_back(p.a); ctx->evpool.push_back(p.b);
@@ -691,8 +694,11 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
     HIPCHK(hipMemsetAsync(sh.claim, 0xFF, ctx->ncells * 4, st));
     hipLaunchKernelGGL(k_spec_claim, dim3(np), dim3(64), 0, st, sh);
     hipLaunchKernelGGL(k_spec_select, dim3(np), dim3(64), 0, st, sh);
-    if (wind) hipLaunchKernelGGL(k_spec_exec<true>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
-    else hipLaunchKernelGGL(k_spec_exec<false>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+    {
+      PhaseTimer tk(ctx, wind ? 5 : 4);
+      if (wind) hipLaunchKernelGGL(k_spec_exec<true>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+      else hipLaunchKernelGGL(k_spec_exec<false>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+    }
     hipLaunchKernelGGL(k_spec_boundary, dim3(1), dim3(256), 0, st, ctx->d, sh);
     HIPCHK(hipMemcpyAsync(ctx->h_ctrl, sh.ctrl, SC_COUNT * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -725,6 +731,7 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
 int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   PhaseTimer t(ctx, 0);
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwater, false);
+  PhaseTimer tk(ctx, 4);
   hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwater);
   HIPCHK(hipGetLastError());
   return 0;
@@ -742,6 +749,7 @@ int smx_grid_pass(smx_ctx* ctx) {
 int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
   PhaseTimer t(ctx, 2);
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwind, true);
+  PhaseTimer tk(ctx, 5);
   hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwind);
   HIPCHK(hipGetLastError());
   return 0;

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes():
     assert C.sizeof(capi.Config) == 32
     assert C.sizeof(capi.Counters) == 16 * 8
-    assert C.sizeof(capi.Timing) == 64
+    assert C.sizeof(capi.Timing) == 96
 
 
 def test_create_fails_loudly_without_gpu():
