@@ -488,30 +488,68 @@ struct Sim {
   // inside round(p)+{-1,0,1}, and the NEXT step's ipos is this step's npos -- so the 3x3 block around npos,
   // fetched once per step as a single batch (9 stamps + 9 views + the frequency/track words of its centre),
   // serves all three, and is carried into the next step in registers.
-  struct Blk { View v[9]; size_t c[9]; bool inb[8]; float fr, tr; };
+  // NOTE: the nine views are NAMED fields, not an array: a select chain over array elements gets folded back into
+  // a variably-indexed load by the compiler, which forces the whole block into scratch memory (measured: 38
+  // scratch stores per step). Named scalars cannot be indexed, so the block provably stays in registers.
+#define SMX_FOR9(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#define SMX_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+  struct Blk {
+    View v0, v1, v2, v3, v4, v5, v6, v7, v8;                 // v8 = centre, vk = neighbour code k
+    size_t c0; uint32_t inb; float fr, tr;                   // inb: bit k = neighbour code k is in bounds
+  };
   SMX_D static int code_rel(int dx, int dy) { const int lin = (dx + 1) * 3 + (dy + 1); return lin < 4 ? lin : (lin == 4 ? 8 : lin - 1); }
   SMX_D static View blk_get(const Blk& b, int k) {
-    View r = b.v[0];
-#pragma unroll
-    for (int j = 1; j < 9; j++) if (k == j) r = b.v[j];
+    View r = b.v0;
+#define X(i)                                                                                   \
+    {                                                                                          \
+      const bool hit = (k == i);                                                               \
+      r.size = hit ? b.v##i.size : r.size;                                                     \
+      r.floor = hit ? b.v##i.floor : r.floor;                                                  \
+      r.type = hit ? b.v##i.type : r.type;                                                     \
+    }
+    SMX_FOR9(X)
+#undef X
     return r;
   }
   SMX_D static void blk_put(Blk& b, int k, const View& w) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) if (k == j) b.v[j] = w;
+#define X(i)                                                                                   \
+    {                                                                                          \
+      const bool hit = (k == i);                                                               \
+      b.v##i.size = hit ? w.size : b.v##i.size;                                                \
+      b.v##i.floor = hit ? w.floor : b.v##i.floor;                                             \
+      b.v##i.type = hit ? w.type : b.v##i.type;                                                \
+    }
+    SMX_FOR9(X)
+#undef X
   }
   template <bool WIND>
   SMX_D void load_block(int cx, int cy, Blk& b) {
-    block3x3(cx, cy, b.c, b.inb, b.v);
+    const size_t c0 = cidx(cx, cy);
+    size_t cc[9];
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int nx = cx + nb_dx(k), ny = cy + nb_dy(k);
+      const bool in = !(nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0);
+      m |= in ? (1u << k) : 0u;
+      cc[k] = in ? (size_t)((long long)c0 + (long long)nb_dx(k) * s.dimy + nb_dy(k)) : c0;
+    }
+    cc[8] = c0;
+    b.c0 = c0; b.inb = m;
+    View t[9];
+    batch<9>(cc, t);
+#define X(i) b.v##i = t[i];
+    SMX_FOR9(X)
+#undef X
     const size_t fi = fidx(cx, cy);
     if constexpr (WIND) { b.fr = 0.f; b.tr = s.windfreq[fi]; } else { b.fr = s.wfreq[fi]; b.tr = s.wtrack[fi]; }
   }
   SMX_D f3 normal_blk(int x, int y, const Blk& b) const {   // Layermap::normal(ivec2) layermap.h:341-377
     const int SC = s.scale;
-    const bool xm = b.inb[1], xp = b.inb[6], ym = b.inb[3], yp = b.inb[4];   // (-1,0) (1,0) (0,-1) (0,1)
-    const double h0 = vh(b.v[8]);
-    const double hxm = xm ? vh(b.v[1]) : 0.0, hxp = xp ? vh(b.v[6]) : 0.0;
-    const double hym = ym ? vh(b.v[3]) : 0.0, hyp = yp ? vh(b.v[4]) : 0.0;
+    const bool xm = (b.inb >> 1) & 1, xp = (b.inb >> 6) & 1, ym = (b.inb >> 3) & 1, yp = (b.inb >> 4) & 1;   // (-1,0) (1,0) (0,-1) (0,1)
+    const double h0 = vh(b.v8);
+    const double hxm = xm ? vh(b.v1) : 0.0, hxp = xp ? vh(b.v6) : 0.0;
+    const double hym = ym ? vh(b.v3) : 0.0, hyp = yp ? vh(b.v4) : 0.0;
     f3 n = {0.f, 0.f, 0.f};
     const f3 p = {(float)x, (float)(SC * h0), (float)y};
     const f3 bm = {(float)(x - 1), (float)(SC * hxm), (float)y}, bp = {(float)(x + 1), (float)(SC * hxp), (float)y};
@@ -543,24 +581,25 @@ struct Sim {
   SMX_D void cascade_blk(int ix, int iy, Blk& b) {
     n_casc++;
     const double sc = (double)(float)s.scale, d80 = (double)80.0f;
-    View ctr = b.v[8];
+    View ctr = b.v8;
     // cheap, conservative pre-check: |dh|*scale/80 is at least 0.01 % below maxdiff for every neighbour -> the
     // exact float excess (particle.h:78) is negative everywhere, the loop below would do nothing
     bool any = false;
     const double hC = vh(ctr);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (b.inb[k]) {
-        const double dh = hC - vh(b.v[k]);
-        const uint32_t ty = dh > 0 ? vsurf(ctr) : vsurf(b.v[k]);
-        const double lim = (double)soils[ty].maxdiff * 0.9999;
-        if (!(fabs(dh) * sc * 0.0125 < lim)) any = true;
-      }
+#define X(k)                                                                                   \
+    if ((b.inb >> k) & 1) {                                                                    \
+      const double dh = hC - vh(b.v##k);                                                       \
+      const uint32_t ty = dh > 0 ? vsurf(ctr) : vsurf(b.v##k);                                 \
+      const double lim = (double)soils[ty].maxdiff * 0.9999;                                   \
+      if (!(fabs(dh) * sc * 0.0125 < lim)) any = true;                                         \
     }
+    SMX_FOR8(X)
+#undef X
     if (!any) return;
     double hs[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) hs[k] = b.inb[k] ? vh(b.v[k]) : -INFINITY;
+#define X(k) hs[k] = ((b.inb >> k) & 1) ? vh(b.v##k) : -INFINITY;
+    SMX_FOR8(X)
+#undef X
     const Sorted sn = sort8(hs);
     for (int i = 0; i < sn.num; i++) {
       const int k = (sn.codes >> (4 * i)) & 15;
@@ -578,11 +617,11 @@ struct Sim {
       const double tsize = T.size;
       if ((double)transfer > tsize) transfer = (float)tsize;
       const uint32_t casc = soils[type].cascades;
-      if (down) { remove_v(ix, iy, b.c[8], ctr, (double)transfer); add_v(nx, ny, cn, nb, (double)transfer, casc); }
-      else { remove_v(nx, ny, cn, nb, (double)transfer); add_v(ix, iy, b.c[8], ctr, (double)transfer, casc); }
+      if (down) { remove_v(ix, iy, b.c0, ctr, (double)transfer); add_v(nx, ny, cn, nb, (double)transfer, casc); }
+      else { remove_v(nx, ny, cn, nb, (double)transfer); add_v(ix, iy, b.c0, ctr, (double)transfer, casc); }
       n_casc_tr++;
       blk_put(b, k, nb);
-      b.v[8] = ctr;
+      b.v8 = ctr;
       if (ab) return;
     }
   }
@@ -707,138 +746,145 @@ struct Sim {
     Frame& f = st[depth++];
     f.ix = ix; f.iy = iy; f.spill = spill; f.num = sn.num; f.i = 0; f.codes = sn.codes;
   }
-  // while(particle.move(..) && particle.interact(..)); (SoilMachine.cpp:293, water.h:259) as one fused loop
+  // One fused move()+interact() of a WaterParticle (water.h:43-121). `cur` is the 3x3 block around ipos, `nb`
+  // receives the block around the new position. Returns false when the particle's move/interact loop ends.
+  SMX_D bool water_step(Water& p, bool toplevel, const Blk& cur, Blk& nb) {
+    // ---- move (water.h:43-73)
+    View cv = cur.v8;
+    const f3 n = normal_blk(p.ix, p.iy, cur);
+    p.surface = vsurf(cv);
+    p.evaprate = 0.01;
+    const size_t fi = fidx(p.ix, p.iy);
+    const float fr = cur.fr;
+    if constexpr (!P::READ_ONLY)
+      s.wtrack[fi] = (float)((double)cur.tr + p.volume);                 // updatefrequency :348-351
+    p.friction = soils[p.surface].friction * (1.0f - fr);
+    p.evaprate = p.evaprate * (double)(1.0f - 0.2f * fr);
+    const f2 nxz = {n.x, n.z};
+    const f2 scaled = {nxz.x * p.friction, nxz.y * p.friction};
+    if ((double)sqrtf(dot2(scaled, scaled)) < 1E-5) return false;
+    const float a = p.friction;                                          // mix(nxz, speed, friction)
+    p.speed = {nxz.x * (1.0f - a) + p.speed.x * a, nxz.y * (1.0f - a) + p.speed.y * a};
+    const f2 nn = normalize2(p.speed);
+    const float s2 = sqrtf(2.0f);
+    p.speed = {s2 * nn.x, s2 * nn.y};
+    p.pos.x += p.speed.x; p.pos.y += p.speed.y;
+    if (!(p.pos.x >= 0.0f && p.pos.y >= 0.0f) ||
+        !(p.pos.x < (float)s.dimx - 1.0f && p.pos.y < (float)s.dimy - 1.0f)) {
+      p.volume = 0.0;
+      return false;
+    }
+    n_steps_w_all++;
+    if (toplevel) n_steps_w_top++;
+    // ---- interact (water.h:75-121)
+    const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
+    load_block<false>(nx, ny, nb);                           // THE memory round trip of this step
+    if (ab) return false;
+    const SoilP& param = soils[p.surface];
+    const double hb = bilinear_blk(p.pos, nx, ny, nb);
+    double c_eq = param.solubility * (vh(cv) - hb) * (double)s.scale / 80.0;
+    if (c_eq < 0.0) c_eq = 0.0;
+    if (c_eq > 1.0) c_eq = 1.0;
+    if ((double)(soils[p.contains].erosionrate) < fr) p.contains = soils[p.contains].erodes;
+    const double cdiff = c_eq - p.sediment;
+    const size_t cc = cur.c0;
+    if (cdiff > 0) {
+      p.sediment += param.equrate * cdiff;
+      p.contains = soils[vsurf(cv)].transports;              // soils[map.surface(ipos)].transports (:94)
+      double diff = remove_v(p.ix, p.iy, cc, cv, param.equrate * cdiff * p.volume);
+      while (fabs(diff) > 1E-8) diff = remove_v(p.ix, p.iy, cc, cv, diff);
+    } else if (cdiff < 0) {
+      p.sediment += soils[p.contains].equrate * cdiff;
+      add_v(p.ix, p.iy, cc, cv, -soils[p.contains].equrate * cdiff * p.volume, p.contains);
+    }
+    if (ab) return false;
+    const int rdx = p.ix - nx, rdy = p.iy - ny;              // the column just eroded may lie inside the new block
+    if (rdx >= -1 && rdx <= 1 && rdy >= -1 && rdy <= 1) blk_put(nb, code_rel(rdx, rdy), cv);
+    cascade_blk(nx, ny, nb);                                 // Particle::cascade(pos, .., 0) (:113)
+    if (ab) return false;
+    p.sediment /= (1.0 - p.evaprate);
+    if (p.sediment > 1.0) p.sediment = 1.0;
+    p.volume *= (1.0 - p.evaprate);
+    p.ix = nx; p.iy = ny;                                    // (the reference recomputes round(pos) in the next move())
+    return p.volume > 0.01;
+  }
+  // while(particle.move(..) && particle.interact(..)); (SoilMachine.cpp:293, water.h:259); the two blocks ping-pong
   SMX_D void water_loop(Water& p, bool toplevel) {
-    Blk cur;
+    Blk A, B;
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    load_block<false>(p.ix, p.iy, cur);
+    load_block<false>(p.ix, p.iy, A);
     if (ab) return;
     while (true) {
-      // ---- move (water.h:43-73)
-      View cv = cur.v[8];
-      const f3 n = normal_blk(p.ix, p.iy, cur);
-      p.surface = vsurf(cv);
-      p.evaprate = 0.01;
-      const size_t fi = fidx(p.ix, p.iy);
-      const float fr = cur.fr;
-      if constexpr (!P::READ_ONLY)
-        s.wtrack[fi] = (float)((double)cur.tr + p.volume);               // updatefrequency :348-351
-      p.friction = soils[p.surface].friction * (1.0f - fr);
-      p.evaprate = p.evaprate * (double)(1.0f - 0.2f * fr);
-      const f2 nxz = {n.x, n.z};
-      const f2 scaled = {nxz.x * p.friction, nxz.y * p.friction};
-      if ((double)sqrtf(dot2(scaled, scaled)) < 1E-5) return;
-      const float a = p.friction;                                        // mix(nxz, speed, friction)
-      p.speed = {nxz.x * (1.0f - a) + p.speed.x * a, nxz.y * (1.0f - a) + p.speed.y * a};
-      const f2 nn = normalize2(p.speed);
-      const float s2 = sqrtf(2.0f);
-      p.speed = {s2 * nn.x, s2 * nn.y};
-      p.pos.x += p.speed.x; p.pos.y += p.speed.y;
-      if (!(p.pos.x >= 0.0f && p.pos.y >= 0.0f) ||
-          !(p.pos.x < (float)s.dimx - 1.0f && p.pos.y < (float)s.dimy - 1.0f)) {
-        p.volume = 0.0;
-        return;
-      }
-      n_steps_w_all++;
-      if (toplevel) n_steps_w_top++;
-      // ---- interact (water.h:75-121)
-      const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-      Blk nb;
-      load_block<false>(nx, ny, nb);                         // THE memory round trip of this step
-      if (ab) return;
-      const SoilP& param = soils[p.surface];
-      const double hb = bilinear_blk(p.pos, nx, ny, nb);
-      double c_eq = param.solubility * (vh(cv) - hb) * (double)s.scale / 80.0;
-      if (c_eq < 0.0) c_eq = 0.0;
-      if (c_eq > 1.0) c_eq = 1.0;
-      if ((double)(soils[p.contains].erosionrate) < fr) p.contains = soils[p.contains].erodes;
-      const double cdiff = c_eq - p.sediment;
-      const size_t cc = cur.c[8];
-      if (cdiff > 0) {
-        p.sediment += param.equrate * cdiff;
-        p.contains = soils[vsurf(cv)].transports;            // soils[map.surface(ipos)].transports (:94)
-        double diff = remove_v(p.ix, p.iy, cc, cv, param.equrate * cdiff * p.volume);
-        while (fabs(diff) > 1E-8) diff = remove_v(p.ix, p.iy, cc, cv, diff);
-      } else if (cdiff < 0) {
-        p.sediment += soils[p.contains].equrate * cdiff;
-        add_v(p.ix, p.iy, cc, cv, -soils[p.contains].equrate * cdiff * p.volume, p.contains);
-      }
-      if (ab) return;
-      const int rdx = p.ix - nx, rdy = p.iy - ny;            // the column just eroded may lie inside the new block
-      if (rdx >= -1 && rdx <= 1 && rdy >= -1 && rdy <= 1) blk_put(nb, code_rel(rdx, rdy), cv);
-      cascade_blk(nx, ny, nb);                               // Particle::cascade(pos, .., 0) (:113)
-      if (ab) return;
-      p.sediment /= (1.0 - p.evaprate);
-      if (p.sediment > 1.0) p.sediment = 1.0;
-      p.volume *= (1.0 - p.evaprate);
-      p.ix = nx; p.iy = ny;                                  // (the reference recomputes round(pos) in the next move())
-      if (!(p.volume > 0.01)) return;
-      cur = nb;
+      if (!water_step(p, toplevel, A, B)) return;
+      if (!water_step(p, toplevel, B, A)) return;
     }
   }
-  // while(particle.move(..) && particle.interact(..)); for WindParticle (SoilMachine.cpp:306), fused
-  SMX_D void wind_loop(Wind& p) {
+  // One fused move()+interact() of a WindParticle (wind.h:54-136); same block scheme as water_step.
+  SMX_D bool wind_step(Wind& p, const Blk& cur, Blk& nb) {
     const f3 pspeed = {-2.f, 0.f, 1.f};
     const double gravity = 0.25, winddominance = 0.2, windfriction = 0.8;
+    // ---- move (wind.h:54-92)
+    View cv = cur.v8;
+    const f3 n = normal_blk(p.ix, p.iy, cur);
+    p.surface = vsurf(cv);
+    const size_t fi = fidx(p.ix, p.iy);
+    if constexpr (!P::READ_ONLY)
+      s.windfreq[fi] = (float)(0.5 * cur.tr + 0.5f);                     // wind.h:49-52
+    p.sheight = vh(cv) * (float)s.scale / 80.0f;
+    if (p.height < p.sheight) p.height = p.sheight;
+    if (p.height > p.sheight) {
+      p.speed.y = (float)(p.speed.y - gravity);
+    } else {
+      const f3 c = cross3(cross3(p.speed, n), n);
+      p.speed = {mixd(p.speed.x, c.x, windfriction), mixd(p.speed.y, c.y, windfriction), mixd(p.speed.z, c.z, windfriction)};
+    }
+    p.speed = {mixd(p.speed.x, pspeed.x, winddominance), mixd(p.speed.y, pspeed.y, winddominance),
+               mixd(p.speed.z, pspeed.z, winddominance)};
+    p.pos.x += p.speed.x; p.pos.y += p.speed.z;
+    p.height += p.speed.y;
+    if (!(p.pos.x >= 0.0f && p.pos.y >= 0.0f) || !((int)p.pos.x < s.dimx - 1 && (int)p.pos.y < s.dimy - 1)) return false;
+    if (sqrtf(dot3(p.speed, p.speed)) < 0.01) return false;
+    n_steps_wind++;
+    // ---- interact (wind.h:94-136)
+    const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
+    load_block<true>(nx, ny, nb);
+    if (ab) return false;
+    const SoilP& param = soils[p.surface];
+    const double hb = bilinear_blk(p.pos, nx, ny, nb);
+    View nv = nb.v8;
+    int ncasc = 0;                                           // Particle::cascade(.., 1) calls that follow (one code site)
+    if (p.height <= hb * (float)s.scale / 80.0f) {
+      if (param.transports == p.contains) {
+        const double force = sqrtf(dot3(p.speed, p.speed)) * (vh(nv) - p.height) * (float)s.scale / 80.0f * (1.0f - p.sediment);
+        const double diff = remove_v(p.ix, p.iy, cur.c0, cv, param.suspension * force);
+        p.sediment += (param.suspension * force - diff);
+        ncasc = 1;                                           // cascade(ipos)
+      }
+    } else if (param.suspension > 0.0) {
+      p.sediment -= soils[p.contains].suspension * p.sediment;
+      add_v(nx, ny, nb.c0, nv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
+      if (nb.c0 == cur.c0) cv = nv;                          // npos == ipos: the second add sees the first
+      add_v(p.ix, p.iy, cur.c0, cv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
+      ncasc = 2;                                             // cascade(ipos); cascade(npos)
+    }
+    for (int q = 0; q < ncasc; q++) {
+      const f2 at = (q == 0) ? f2{(float)p.ix, (float)p.iy} : f2{(float)nx, (float)ny};
+      particle_cascade<1>(at);
+      if (ab) return false;
+    }
+    p.ix = nx; p.iy = ny;
+    if (ncasc) load_block<true>(nx, ny, nb);                 // the cascades may have moved material inside the block
+    return !ab;
+  }
+  SMX_D void wind_loop(Wind& p) {                            // SoilMachine.cpp:306
     if (soils[p.contains].suspension == 0.0) return;         // wind.h:56-57 (contains never changes: checked once)
-    Blk cur;
+    Blk A, B;
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    load_block<true>(p.ix, p.iy, cur);
+    load_block<true>(p.ix, p.iy, A);
     if (ab) return;
     while (true) {
-      // ---- move (wind.h:54-92)
-      View cv = cur.v[8];
-      const f3 n = normal_blk(p.ix, p.iy, cur);
-      p.surface = vsurf(cv);
-      const size_t fi = fidx(p.ix, p.iy);
-      if constexpr (!P::READ_ONLY)
-        s.windfreq[fi] = (float)(0.5 * cur.tr + 0.5f);                   // wind.h:49-52
-      p.sheight = vh(cv) * (float)s.scale / 80.0f;
-      if (p.height < p.sheight) p.height = p.sheight;
-      if (p.height > p.sheight) {
-        p.speed.y = (float)(p.speed.y - gravity);
-      } else {
-        const f3 c = cross3(cross3(p.speed, n), n);
-        p.speed = {mixd(p.speed.x, c.x, windfriction), mixd(p.speed.y, c.y, windfriction), mixd(p.speed.z, c.z, windfriction)};
-      }
-      p.speed = {mixd(p.speed.x, pspeed.x, winddominance), mixd(p.speed.y, pspeed.y, winddominance),
-                 mixd(p.speed.z, pspeed.z, winddominance)};
-      p.pos.x += p.speed.x; p.pos.y += p.speed.z;
-      p.height += p.speed.y;
-      if (!(p.pos.x >= 0.0f && p.pos.y >= 0.0f) || !((int)p.pos.x < s.dimx - 1 && (int)p.pos.y < s.dimy - 1)) return;
-      if (sqrtf(dot3(p.speed, p.speed)) < 0.01) return;
-      n_steps_wind++;
-      // ---- interact (wind.h:94-136)
-      const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-      Blk nb;
-      load_block<true>(nx, ny, nb);
-      if (ab) return;
-      const SoilP& param = soils[p.surface];
-      const double hb = bilinear_blk(p.pos, nx, ny, nb);
-      View nv = nb.v[8];
-      bool dirty = false;
-      if (p.height <= hb * (float)s.scale / 80.0f) {
-        if (param.transports == p.contains) {
-          const double force = sqrtf(dot3(p.speed, p.speed)) * (vh(nv) - p.height) * (float)s.scale / 80.0f * (1.0f - p.sediment);
-          const double diff = remove_v(p.ix, p.iy, cur.c[8], cv, param.suspension * force);
-          p.sediment += (param.suspension * force - diff);
-          particle_cascade<1>(f2{(float)p.ix, (float)p.iy});
-          dirty = true;
-        }
-      } else if (param.suspension > 0.0) {
-        p.sediment -= soils[p.contains].suspension * p.sediment;
-        add_v(nx, ny, nb.c[8], nv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
-        if (nb.c[8] == cur.c[8]) cv = nv;                    // npos == ipos: the second add sees the first
-        add_v(p.ix, p.iy, cur.c[8], cv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
-        particle_cascade<1>(f2{(float)p.ix, (float)p.iy});
-        particle_cascade<1>(f2{(float)nx, (float)ny});
-        dirty = true;
-      }
-      if (ab) return;
-      p.ix = nx; p.iy = ny;
-      if (dirty) load_block<true>(nx, ny, cur);              // the cascades may have moved material inside the block
-      else cur = nb;
-      if (ab) return;
+      if (!wind_step(p, A, B)) return;
+      if (!wind_step(p, B, A)) return;
     }
   }
   // Runs one WaterParticle to completion INCLUDING everything it spawns (SoilMachine.cpp:292-296, water.h:258-262),
