@@ -102,8 +102,6 @@ struct Water {            // WaterParticle (water.h:9-41); `param` is re-read fr
   int spill, ix, iy;
   float friction;         // param.friction after the frequency scaling of move() (water.h:53)
   uint32_t surface, contains;
-  double csize, cfloor;   // view of the column at ipos taken by move() (nothing writes it before interact())
-  uint32_t ctype;
 };
 struct Wind {             // WindParticle (wind.h:11-46)
   f2 pos;
@@ -111,8 +109,6 @@ struct Wind {             // WindParticle (wind.h:11-46)
   double sediment, height, sheight;
   int ix, iy;
   uint32_t surface, contains;
-  double csize, cfloor;   // view of the column at ipos taken by move()
-  uint32_t ctype;
 };
 
 // One suspended WaterParticle::cascade invocation (water.h:151-283): centre, remaining spill budget,
@@ -414,6 +410,7 @@ struct Sim {
   SMX_D void add_v(int x, int y, size_t c, View& v, double size, uint32_t type) {
     if (ab) return;
     if constexpr (P::READ_ONLY) return;
+    if (size <= 0) { if (!pol.can_get(s)) n_overflow++; return; }   // pool.get + unget of an empty section (layermap.h:237-240)
     if (v.type == type && v.type != EMPTY && size > 0 && pol.can_get(s)) {   // layermap.h:249-253 elongate (pool.get + unget: net 0)
       v.size += size;
       s.cells[c].size = v.size;
@@ -421,65 +418,6 @@ struct Sim {
     }
     add(x, y, size, type, true);
     v = load_view(c);
-  }
-
-  // ---------------- Particle::cascade particle.h:24-101 ----------------
-  // LOOP: remaining recursion budget (transferloop). Water uses 0, wind 1 (wind.h:112,126,129).
-  // The 3x3 block is fetched as ONE batch; the neighbour loop then runs on register views: a transfer only
-  // changes the centre and the current neighbour, and every neighbour is visited once, so the views stay exact.
-  template <int LOOP>
-  SMX_D void particle_cascade(f2 pos) {
-    n_casc++;
-    const int ix = (int)roundf(pos.x), iy = (int)roundf(pos.y);
-    size_t cc[9]; bool inb[8]; View v[9];
-    block3x3(ix, iy, cc, inb, v);
-    if (ab) return;
-    double hs[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) hs[k] = inb[k] ? vh(v[k]) : -INFINITY;
-    const Sorted sn = sort8(hs);
-    const double sc = (double)(float)s.scale, d80 = (double)80.0f;
-    int transferloop = LOOP;
-    View ctr = v[8];
-    for (int i = 0; i < sn.num; i++) {
-      const int k = (sn.codes >> (4 * i)) & 15;
-      View nb = v[0]; size_t cn = cc[0];
-#pragma unroll
-      for (int j = 1; j < 8; j++) if (k == j) { nb = v[j]; cn = cc[j]; }
-      const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
-      const float diff = (float)((vh(ctr) - vh(nb)) * sc / d80);
-      if (diff == 0) continue;
-      const bool down = diff > 0;                           // centre is the higher column
-      const View& T = down ? ctr : nb;
-      const uint32_t type = vsurf(T);
-      const float excess = fabsf(diff) - soils[type].maxdiff;
-      if (excess <= 0) continue;
-      float transfer = soils[type].settling * excess / 2.0f;
-      const double tsize = T.size;
-      if ((double)transfer > tsize) transfer = (float)tsize;
-      const uint32_t casc = soils[type].cascades;
-      bool recascade = false;
-      if (down) {
-        if (remove_v(ix, iy, cc[8], ctr, (double)transfer) != 0) recascade = true;
-        add_v(nx, ny, cn, nb, (double)transfer, casc);
-      } else {
-        if (remove_v(nx, ny, cn, nb, (double)transfer) != 0) recascade = true;
-        add_v(ix, iy, cc[8], ctr, (double)transfer, casc);
-      }
-      n_casc_tr++;
-      if (ab) return;
-      if constexpr (LOOP > 0) {
-        if (recascade && transferloop > 0) {
-          --transferloop;
-          particle_cascade<0>(f2{(float)nx, (float)ny});
-          if (ab) return;
-          // the nested cascade may have moved material in this block: refresh every view (cells are owned)
-#pragma unroll
-          for (int j = 0; j < 9; j++) v[j] = load_view(cc[j]);
-          ctr = v[8];
-        }
-      }
-    }
   }
 
   // ---------------- the carried 3x3 block: ONE memory round trip per particle step ----------------
@@ -522,7 +460,7 @@ struct Sim {
     SMX_FOR9(X)
 #undef X
   }
-  template <bool WIND>
+  template <int MODE>                                         // 0: + water frequency/track, 1: + wind frequency, 2: cells only
   SMX_D void load_block(int cx, int cy, Blk& b) {
     const size_t c0 = cidx(cx, cy);
     size_t cc[9];
@@ -542,7 +480,9 @@ struct Sim {
     SMX_FOR9(X)
 #undef X
     const size_t fi = fidx(cx, cy);
-    if constexpr (WIND) { b.fr = 0.f; b.tr = s.windfreq[fi]; } else { b.fr = s.wfreq[fi]; b.tr = s.wtrack[fi]; }
+    if constexpr (MODE == 1) { b.fr = 0.f; b.tr = s.windfreq[fi]; }
+    else if constexpr (MODE == 0) { b.fr = s.wfreq[fi]; b.tr = s.wtrack[fi]; }
+    else { b.fr = 0.f; b.tr = 0.f; }
   }
   SMX_D f3 normal_blk(int x, int y, const Blk& b) const {   // Layermap::normal(ivec2) layermap.h:341-377
     const int SC = s.scale;
@@ -576,14 +516,12 @@ struct Sim {
     h += wx * wy * h11;                                     // wx*wy is a FLOAT product (:436)
     return h;
   }
-  // Particle::cascade(pos, .., 0) (particle.h:24-101) on a block that is already in registers; the block is
-  // kept exact (views written back) because the next step continues from it.
-  SMX_D void cascade_blk(int ix, int iy, Blk& b) {
-    n_casc++;
-    const double sc = (double)(float)s.scale, d80 = (double)80.0f;
-    View ctr = b.v8;
-    // cheap, conservative pre-check: |dh|*scale/80 is at least 0.01 % below maxdiff for every neighbour -> the
-    // exact float excess (particle.h:78) is negative everywhere, the loop below would do nothing
+  // ---- Particle::cascade (particle.h:24-101) on a block that is already in registers.
+  // cascade_precheck: cheap, conservative test -- |dh|*scale/80 is at least 0.01 % below maxdiff for every
+  // neighbour, so the exact float excess (particle.h:78) is negative everywhere and the loop would do nothing.
+  SMX_D bool cascade_precheck(const Blk& b) const {
+    const double sc = (double)(float)s.scale;
+    const View& ctr = b.v8;
     bool any = false;
     const double hC = vh(ctr);
 #define X(k)                                                                                   \
@@ -595,20 +533,28 @@ struct Sim {
     }
     SMX_FOR8(X)
 #undef X
-    if (!any) return;
+    return any;
+  }
+  SMX_D Sorted cascade_sort(const Blk& b) const {           // particle.h:43-60
     double hs[8];
 #define X(k) hs[k] = ((b.inb >> k) & 1) ? vh(b.v##k) : -INFINITY;
     SMX_FOR8(X)
 #undef X
-    const Sorted sn = sort8(hs);
-    for (int i = 0; i < sn.num; i++) {
+    return sort8(hs);
+  }
+  // the neighbour loop (particle.h:62-99) from index i on; the block is kept exact (views written back).
+  // Stops early (returning the neighbour code) when a section was exhausted and the caller may recurse there.
+  SMX_D int cascade_loop(int ix, int iy, Blk& b, const Sorted& sn, int& i, bool may_recurse, bool& moved) {
+    const double sc = (double)(float)s.scale, d80 = (double)80.0f;
+    View ctr = b.v8;
+    for (; i < sn.num; i++) {
       const int k = (sn.codes >> (4 * i)) & 15;
       View nb = blk_get(b, k);
       const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
       const size_t cn = cidx(nx, ny);
       const float diff = (float)((vh(ctr) - vh(nb)) * sc / d80);
       if (diff == 0) continue;
-      const bool down = diff > 0;
+      const bool down = diff > 0;                           // the centre is the higher column
       const View& T = down ? ctr : nb;
       const uint32_t type = vsurf(T);
       const float excess = fabsf(diff) - soils[type].maxdiff;
@@ -617,12 +563,61 @@ struct Sim {
       const double tsize = T.size;
       if ((double)transfer > tsize) transfer = (float)tsize;
       const uint32_t casc = soils[type].cascades;
-      if (down) { remove_v(ix, iy, b.c0, ctr, (double)transfer); add_v(nx, ny, cn, nb, (double)transfer, casc); }
-      else { remove_v(nx, ny, cn, nb, (double)transfer); add_v(ix, iy, b.c0, ctr, (double)transfer, casc); }
+      bool recascade = false;
+      if (down) { if (remove_v(ix, iy, b.c0, ctr, (double)transfer) != 0) recascade = true; add_v(nx, ny, cn, nb, (double)transfer, casc); }
+      else { if (remove_v(nx, ny, cn, nb, (double)transfer) != 0) recascade = true; add_v(ix, iy, b.c0, ctr, (double)transfer, casc); }
       n_casc_tr++;
+      moved = true;
       blk_put(b, k, nb);
       b.v8 = ctr;
-      if (ab) return;
+      if (ab) return -1;
+      if (recascade && may_recurse) { i++; return k; }
+    }
+    return -1;
+  }
+  SMX_D void cascade_blk(int ix, int iy, Blk& b) {          // Particle::cascade(pos, .., 0) on a loaded block
+    n_casc++;
+    if (!cascade_precheck(b)) return;
+    const Sorted sn = cascade_sort(b);
+    int i = 0; bool moved = false;
+    cascade_loop(ix, iy, b, sn, i, false, moved);
+  }
+  // Particle::cascade(pos, .., LOOP) (particle.h:24-101), LOOP = recursion budget (transferloop): water 0, wind 1
+  // (wind.h:112,126,129). The one level of recursion is an explicit parent frame, so the neighbour loop exists
+  // once in the code. Returns true if any material moved.
+  template <int LOOP>
+  SMX_D bool particle_cascade(f2 pos) {
+    static_assert(LOOP <= 1, "one level of recursion is all the reference uses");
+    int ix = (int)roundf(pos.x), iy = (int)roundf(pos.y);
+    int budget = LOOP;
+    bool moved = false, in_child = false;
+    int pix = 0, piy = 0, pi = 0; Sorted psn; psn.num = 0; psn.codes = 0;
+    Blk b;
+    Sorted sn; int i = 0;
+    bool enter = true;
+    while (true) {
+      if (enter) {
+        n_casc++;
+        load_block<2>(ix, iy, b);
+        if (ab) return moved;
+        i = 0; sn.num = 0; sn.codes = 0;
+        if (cascade_precheck(b)) sn = cascade_sort(b);
+      }
+      const int k = cascade_loop(ix, iy, b, sn, i, budget > 0 && !in_child, moved);
+      if (ab) return moved;
+      if (k >= 0) {                                         // cascade(npos, .., --transferloop) (particle.h:96-97)
+        --budget;
+        pix = ix; piy = iy; pi = i; psn = sn; in_child = true;
+        ix = ix + nb_dx(k); iy = iy + nb_dy(k);
+        enter = true;
+        continue;
+      }
+      if (!in_child) return moved;
+      in_child = false;                                     // back in the parent: its block may have changed
+      ix = pix; iy = piy; i = pi; sn = psn;
+      load_block<2>(ix, iy, b);
+      if (ab) return moved;
+      enter = false;
     }
   }
 
@@ -635,64 +630,6 @@ struct Sim {
     p.surface = surface(p.ix, p.iy);
     p.friction = soils[p.surface].friction;
     p.contains = soils[p.surface].transports;
-  }
-  SMX_D bool water_move(Water& p) {                          // water.h:43-73
-    p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    View cv;
-    const f3 n = normal(p.ix, p.iy, cv);                     // batch A: plus-stencil
-    p.csize = cv.size; p.cfloor = cv.floor; p.ctype = cv.type;
-    p.surface = vsurf(cv);
-    if (ab) return false;
-    p.evaprate = 0.01;
-    const size_t fi = fidx(p.ix, p.iy);
-    const float fr = s.wfreq[fi];
-    if constexpr (!P::READ_ONLY)
-      s.wtrack[fi] = (float)((double)s.wtrack[fi] + p.volume);          // updatefrequency :348-351
-    p.friction = soils[p.surface].friction * (1.0f - fr);
-    p.evaprate = p.evaprate * (double)(1.0f - 0.2f * fr);
-    const f2 nxz = {n.x, n.z};
-    const f2 scaled = {nxz.x * p.friction, nxz.y * p.friction};
-    if ((double)sqrtf(dot2(scaled, scaled)) < 1E-5) return false;
-    const float a = p.friction;                                          // mix(nxz, speed, friction)
-    p.speed = {nxz.x * (1.0f - a) + p.speed.x * a, nxz.y * (1.0f - a) + p.speed.y * a};
-    const f2 nn = normalize2(p.speed);
-    const float s2 = sqrtf(2.0f);
-    p.speed = {s2 * nn.x, s2 * nn.y};
-    p.pos.x += p.speed.x; p.pos.y += p.speed.y;
-    if (!(p.pos.x >= 0.0f && p.pos.y >= 0.0f) ||
-        !(p.pos.x < (float)s.dimx - 1.0f && p.pos.y < (float)s.dimy - 1.0f)) {
-      p.volume = 0.0;
-      return false;
-    }
-    return true;
-  }
-  SMX_D bool water_interact(Water& p) {                      // water.h:75-121
-    const SoilP& param = soils[p.surface];
-    View cv; cv.size = p.csize; cv.floor = p.cfloor; cv.type = p.ctype;   // height(ipos): unchanged since move()
-    const double hb = height_bilinear(p.pos);                // batch B: the 2x2 block under the new position
-    double c_eq = param.solubility * (vh(cv) - hb) * (double)s.scale / 80.0;
-    if (ab) return false;
-    if (c_eq < 0.0) c_eq = 0.0;
-    if (c_eq > 1.0) c_eq = 1.0;
-    const size_t fi = fidx(p.ix, p.iy);
-    if ((double)(soils[p.contains].erosionrate) < s.wfreq[fi]) p.contains = soils[p.contains].erodes;
-    const double cdiff = c_eq - p.sediment;
-    const size_t cc = cidx(p.ix, p.iy);
-    if (cdiff > 0) {
-      p.sediment += param.equrate * cdiff;
-      p.contains = soils[vsurf(cv)].transports;              // soils[map.surface(ipos)].transports (:94)
-      double diff = remove_v(p.ix, p.iy, cc, cv, param.equrate * cdiff * p.volume);
-      while (fabs(diff) > 1E-8) diff = remove_v(p.ix, p.iy, cc, cv, diff);
-    } else if (cdiff < 0) {
-      p.sediment += soils[p.contains].equrate * cdiff;
-      add_v(p.ix, p.iy, cc, cv, -soils[p.contains].equrate * cdiff * p.volume, p.contains);
-    }
-    particle_cascade<0>(p.pos);                              // batch C: the 3x3 block around the new position
-    if (ab) return false;
-    p.sediment /= (1.0 - p.evaprate);
-    if (p.sediment > 1.0) p.sediment = 1.0;
-    p.volume *= (1.0 - p.evaprate);
-    return (p.volume > 0.01);
   }
   SMX_D void seep(int ix, int iy) {                          // WaterParticle::seep(vec2,..) water.h:285-333
     Sec& top = cell(ix, iy);
@@ -778,7 +715,7 @@ struct Sim {
     if (toplevel) n_steps_w_top++;
     // ---- interact (water.h:75-121)
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-    load_block<false>(nx, ny, nb);                           // THE memory round trip of this step
+    load_block<0>(nx, ny, nb);                           // THE memory round trip of this step
     if (ab) return false;
     const SoilP& param = soils[p.surface];
     const double hb = bilinear_blk(p.pos, nx, ny, nb);
@@ -812,7 +749,7 @@ struct Sim {
   SMX_D void water_loop(Water& p, bool toplevel) {
     Blk A, B;
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    load_block<false>(p.ix, p.iy, A);
+    load_block<0>(p.ix, p.iy, A);
     if (ab) return;
     while (true) {
       if (!water_step(p, toplevel, A, B)) return;
@@ -847,40 +784,45 @@ struct Sim {
     n_steps_wind++;
     // ---- interact (wind.h:94-136)
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-    load_block<true>(nx, ny, nb);
+    load_block<1>(nx, ny, nb);
     if (ab) return false;
     const SoilP& param = soils[p.surface];
     const double hb = bilinear_blk(p.pos, nx, ny, nb);
     View nv = nb.v8;
     int ncasc = 0;                                           // Particle::cascade(.., 1) calls that follow (one code site)
+    bool changed = false;
     if (p.height <= hb * (float)s.scale / 80.0f) {
       if (param.transports == p.contains) {
         const double force = sqrtf(dot3(p.speed, p.speed)) * (vh(nv) - p.height) * (float)s.scale / 80.0f * (1.0f - p.sediment);
-        const double diff = remove_v(p.ix, p.iy, cur.c0, cv, param.suspension * force);
-        p.sediment += (param.suspension * force - diff);
+        const double amount = param.suspension * force;
+        const double diff = remove_v(p.ix, p.iy, cur.c0, cv, amount);
+        p.sediment += (amount - diff);
+        changed = amount > 0.0;
         ncasc = 1;                                           // cascade(ipos)
       }
     } else if (param.suspension > 0.0) {
       p.sediment -= soils[p.contains].suspension * p.sediment;
-      add_v(nx, ny, nb.c0, nv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
+      const double dep = 0.5f * soils[p.contains].suspension * p.sediment;
+      add_v(nx, ny, nb.c0, nv, dep, p.contains);
       if (nb.c0 == cur.c0) cv = nv;                          // npos == ipos: the second add sees the first
-      add_v(p.ix, p.iy, cur.c0, cv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
+      add_v(p.ix, p.iy, cur.c0, cv, dep, p.contains);
+      changed = dep > 0.0;
       ncasc = 2;                                             // cascade(ipos); cascade(npos)
     }
     for (int q = 0; q < ncasc; q++) {
       const f2 at = (q == 0) ? f2{(float)p.ix, (float)p.iy} : f2{(float)nx, (float)ny};
-      particle_cascade<1>(at);
+      changed |= particle_cascade<1>(at);
       if (ab) return false;
     }
     p.ix = nx; p.iy = ny;
-    if (ncasc) load_block<true>(nx, ny, nb);                 // the cascades may have moved material inside the block
+    if (changed) load_block<1>(nx, ny, nb);               // material moved inside the block: refresh the views
     return !ab;
   }
   SMX_D void wind_loop(Wind& p) {                            // SoilMachine.cpp:306
     if (soils[p.contains].suspension == 0.0) return;         // wind.h:56-57 (contains never changes: checked once)
     Blk A, B;
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    load_block<true>(p.ix, p.iy, A);
+    load_block<1>(p.ix, p.iy, A);
     if (ab) return;
     while (true) {
       if (!wind_step(p, A, B)) return;
@@ -972,74 +914,6 @@ struct Sim {
     p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
     p.surface = surface(p.ix, p.iy);
     p.contains = soils[p.surface].transports;
-  }
-  SMX_D bool wind_move(Wind& p) {                            // wind.h:54-92
-    const f3 pspeed = {-2.f, 0.f, 1.f};
-    const double gravity = 0.25, winddominance = 0.2, windfriction = 0.8;
-    if (soils[p.contains].suspension == 0.0) return false;
-    p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    View cv;
-    const f3 n = normal(p.ix, p.iy, cv);                     // batch A
-    p.csize = cv.size; p.cfloor = cv.floor; p.ctype = cv.type;
-    p.surface = vsurf(cv);
-    if (ab) return false;
-    const size_t fi = fidx(p.ix, p.iy);
-    if constexpr (!P::READ_ONLY)
-      s.windfreq[fi] = (float)(0.5 * s.windfreq[fi] + 0.5f);            // wind.h:49-52
-    p.sheight = vh(cv) * (float)s.scale / 80.0f;
-    if (p.height < p.sheight) p.height = p.sheight;
-    if (p.height > p.sheight) {
-      p.speed.y = (float)(p.speed.y - gravity);
-    } else {
-      const f3 c = cross3(cross3(p.speed, n), n);
-      p.speed = {mixd(p.speed.x, c.x, windfriction), mixd(p.speed.y, c.y, windfriction), mixd(p.speed.z, c.z, windfriction)};
-    }
-    p.speed = {mixd(p.speed.x, pspeed.x, winddominance), mixd(p.speed.y, pspeed.y, winddominance),
-               mixd(p.speed.z, pspeed.z, winddominance)};
-    p.pos.x += p.speed.x; p.pos.y += p.speed.z;
-    p.height += p.speed.y;
-    if (!(p.pos.x >= 0.0f && p.pos.y >= 0.0f) || !((int)p.pos.x < s.dimx - 1 && (int)p.pos.y < s.dimy - 1)) return false;
-    if (sqrtf(dot3(p.speed, p.speed)) < 0.01) return false;
-    return true;
-  }
-  SMX_D bool wind_interact(Wind& p) {                        // wind.h:94-136
-    const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-    const SoilP& param = soils[p.surface];
-    // batch B: the 2x2 block under the new position; npos = round(pos) is always one of its four cells
-    const float fx = floorf(p.pos.x), fy = floorf(p.pos.y);
-    const int px = (int)fx, py = (int)fy;
-    const float wx = p.pos.x - fx, wy = p.pos.y - fy;
-    const size_t c00 = cidx(px, py);
-    const size_t cb[4] = {c00, c00 + (size_t)s.dimy, c00 + 1, c00 + (size_t)s.dimy + 1};
-    View vb[4];
-    batch<4>(cb, vb);
-    if (ab) return false;
-    double hb = 0.0;                                         // Layermap::height(vec2) layermap.h:427-439
-    hb += (1.0 - wx) * (1.0 - wy) * vh(vb[0]);
-    hb += (1.0 - wx) * wy * vh(vb[1]);
-    hb += wx * (1.0 - wy) * vh(vb[2]);
-    hb += wx * wy * vh(vb[3]);
-    const int kn = (nx - px) + 2 * (ny - py);                // which of the four is npos
-    View nv = vb[0];
-    if (kn == 1) nv = vb[1]; else if (kn == 2) nv = vb[2]; else if (kn == 3) nv = vb[3];
-    const size_t cn = cidx(nx, ny), ci = cidx(p.ix, p.iy);
-    View cv; cv.size = p.csize; cv.floor = p.cfloor; cv.type = p.ctype;
-    if (p.height <= hb * (float)s.scale / 80.0f) {
-      if (param.transports == p.contains) {
-        const double force = sqrtf(dot3(p.speed, p.speed)) * (vh(nv) - p.height) * (float)s.scale / 80.0f * (1.0f - p.sediment);
-        const double diff = remove_v(p.ix, p.iy, ci, cv, param.suspension * force);
-        p.sediment += (param.suspension * force - diff);
-        particle_cascade<1>(f2{(float)p.ix, (float)p.iy});
-      }
-    } else if (param.suspension > 0.0) {
-      p.sediment -= soils[p.contains].suspension * p.sediment;
-      add_v(nx, ny, cn, nv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
-      if (cn == ci) cv = nv;                                 // npos == ipos: the second add sees the first
-      add_v(p.ix, p.iy, ci, cv, 0.5f * soils[p.contains].suspension * p.sediment, p.contains);
-      particle_cascade<1>(f2{(float)p.ix, (float)p.iy});
-      particle_cascade<1>(f2{(float)nx, (float)ny});
-    }
-    return !ab;
   }
   SMX_D void wind_run(Wind& p) { wind_loop(p); }             // SoilMachine.cpp:305-306
 };

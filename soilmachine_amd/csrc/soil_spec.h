@@ -78,7 +78,7 @@ struct SpecPart {                             // one particle of the phase
   uint32_t status, kill, aborted, fail_cell;
   uint32_t noff, nested, nlog, nchunks;
   uint32_t ndeps, dep_overflow, nalloc, nfree;
-  uint32_t overflow, attempts, rolled, blocked;
+  uint32_t overflow, attempts, nnode, blocked;     // nnode: NODE_ENTRY records in the log
   long long live_delta;
   unsigned long long ctr[SPEC_NCTR];
   uint32_t deps[MAX_DEPS];
@@ -98,7 +98,7 @@ struct SpecShared {
   uint32_t* free_log;       // [n][MAX_NODELOG]
   uint32_t* pending;        // ids of the particles to run this round
   uint32_t* ctrl;           // SpecCtrl
-  int* draws;               // the phase's rand() stream, peeked ahead
+  uint32_t* draws;          // the phase's rand() stream, peeked ahead: RAW 32-bit generator outputs (rand() = raw >> 1)
   uint32_t ndraws;
   uint32_t* reclaim;        // pool nodes that return to the free stack at phase end
   uint32_t reclaim_cap;
@@ -150,7 +150,7 @@ struct SpecPolicy {
   const SpecShared& sh;
   uint32_t pid, me;
   SpecPart* part;
-  uint32_t nlog = 0, nchunks, ndeps = 0, dep_overflow = 0, nalloc = 0, nfree = 0, nested_drawn = 0, overflow = 0;
+  uint32_t nlog = 0, nchunks, ndeps = 0, dep_overflow = 0, nalloc = 0, nfree = 0, nested_drawn = 0, overflow = 0, nnode = 0;
   uint32_t fail_cell = NOCLAIM;
   long long live_delta = 0;
   unsigned long long ctr[SPEC_NCTR];
@@ -183,14 +183,74 @@ struct SpecPolicy {
     if (v == me) { last = c; return true; }
     return touch_slow(s, c, v);
   }
-  // all stamp loads of a batch are in flight together; only cells that are not ours yet take the slow path
+  // A batch is acquired in STAGES so that the memory operations of all its new cells overlap: stamp loads ->
+  // (owner status, claim) loads -> CAS -> snapshot loads -> log writes. Cells already ours cost one load.
+  SMX_D void add_dep(uint32_t owner) {
+    bool have = false;
+    for (uint32_t i = 0; i < ndeps; i++) have |= (part->deps[i] == owner);
+    if (!have) { if (ndeps < (uint32_t)MAX_DEPS) part->deps[ndeps++] = owner; else dep_overflow = 1; }
+  }
   template <int N> SMX_D bool touch_batch(const DevState& s, const size_t (&c)[N]) {
     uint32_t v[N];
+    bool need[N];
+    bool any = false;
 #pragma unroll
     for (int i = 0; i < N; i++) v[i] = SMX_A_LOAD(&sh.stamp[c[i]]);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      need[i] = (v[i] != me);
+#pragma unroll
+      for (int j = 0; j < i; j++) if (c[j] == c[i]) need[i] = false;   // a batch may name a cell twice (map border)
+      any |= need[i];
+    }
+    if (!any) return true;
+    // ---- may we take them at all?
+    bool fail = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (need[i] && (v[i] == POISON || v[i] > me)) {
+        if (v[i] != POISON) SMX_A_STORE(&sh.part[v[i] - 1].kill, 1u);   // a later particle got here first: undo it
+        fail_cell = (uint32_t)c[i]; fail = true;
+      }
+    }
+    if (fail) return false;
+    uint32_t stv[N], clv[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      stv[i] = (need[i] && v[i] != 0) ? SMX_A_LOAD(&sh.part[v[i] - 1].status) : ST_COMMITTED;
+      clv[i] = need[i] ? SMX_A_LOAD(&sh.claim[c[i]]) : NOCLAIM;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (need[i] && (stv[i] == ST_PENDING || stv[i] == ST_DONE_NEW || clv[i] < pid)) { fail_cell = (uint32_t)c[i]; fail = true; }
+    }
+    if (fail) return false;
+    // ---- take them
+    uint32_t old[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) old[i] = need[i] ? SMX_A_CAS(&sh.stamp[c[i]], v[i], me) : v[i];
+    Sec rec[N]; float tr[N], wf[N]; uint32_t fl[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (need[i] && old[i] == v[i]) {
+        const size_t fi = spec_fidx(s, c[i]);
+        rec[i] = s.cells[c[i]]; tr[i] = s.wtrack[fi]; wf[i] = s.windfreq[fi]; fl[i] = s.flags[c[i]];
+      }
+    }
     bool ok = true;
 #pragma unroll
-    for (int i = 0; i < N; i++) if (ok && v[i] != me) ok = touch_slow(s, c[i], v[i]);
+    for (int i = 0; i < N; i++) {
+      if (!need[i]) continue;
+      if (old[i] == v[i]) {
+        SpecLog* e = append((uint32_t)c[i], v[i]);
+        if (!e) { SMX_A_STORE(&sh.stamp[c[i]], v[i]); fail_cell = (uint32_t)c[i]; ok = false; continue; }
+        e->rec = rec[i]; e->wtrack = tr[i]; e->windfreq = wf[i]; e->flags = fl[i];
+        if (stv[i] == ST_DONE_OLD && v[i] != 0) add_dep(v[i] - 1);
+      } else if (ok) {
+        ok = touch_slow(s, c[i], old[i]);                   // somebody changed the stamp under us: one-cell protocol
+      }
+    }
+    if (ok) last = c[N - 1];
     return ok;
   }
   SMX_D bool touch_slow(const DevState& s, size_t c, uint32_t v) {
@@ -215,18 +275,14 @@ struct SpecPolicy {
       if (!e) { SMX_A_STORE(&sh.stamp[c], v); fail_cell = (uint32_t)c; return false; }
       const size_t fi = spec_fidx(s, c);
       e->rec = s.cells[c]; e->wtrack = s.wtrack[fi]; e->windfreq = s.windfreq[fi]; e->flags = s.flags[c];
-      if (dep) {
-        bool have = false;
-        for (uint32_t i = 0; i < ndeps; i++) have |= (part->deps[i] == v - 1);
-        if (!have) { if (ndeps < (uint32_t)MAX_DEPS) part->deps[ndeps++] = v - 1; else dep_overflow = 1; }
-      }
+      if (dep) add_dep(v - 1);
       last = c;
       return true;
     }
   }
   SMX_D void pre_write_node(const DevState& s, uint32_t node) {
     SpecLog* e = append(NODE_ENTRY | node, 0);
-    if (e) e->rec = s.pool[node];
+    if (e) { e->rec = s.pool[node]; nnode++; }
   }
   SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (!(v & f)) s.flags[c] = v | f; }
   SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (v & f) s.flags[c] = v & (uint8_t)~f; }
@@ -249,11 +305,11 @@ struct SpecPolicy {
     const uint32_t k = 2u * pid + 2u * part->noff + 2u + 2u * nested_drawn;
     nested_drawn++;
     if (k + 1 >= sh.ndraws) { overflow = 1; first = second = 0; return; }
-    first = sh.draws[k]; second = sh.draws[k + 1];
+    first = (int)(sh.draws[k] >> 1); second = (int)(sh.draws[k + 1] >> 1);
   }
   SMX_D void spawn_draws(int& first, int& second) const {
     const uint32_t k = 2u * pid + 2u * part->noff;
-    first = sh.draws[k]; second = sh.draws[k + 1];
+    first = (int)(sh.draws[k] >> 1); second = (int)(sh.draws[k + 1] >> 1);
   }
   SMX_D void add_counter(const DevState&, int which, unsigned long long v) { if (which < SPEC_NCTR) ctr[which] += v; }
 
@@ -273,7 +329,7 @@ struct SpecPolicy {
       SMX_A_STORE(&sh.stamp[c], POISON);
     }
     reclaim_nodes(sh.alloc_log + (size_t)pid * MAX_NODELOG, nalloc);
-    part->nlog = nlog; part->nchunks = nchunks; part->fail_cell = fail_cell; part->overflow = overflow;
+    part->nlog = nlog; part->nchunks = nchunks; part->fail_cell = fail_cell; part->overflow = overflow; part->nnode = nnode;
     part->ndeps = 0; part->dep_overflow = 0; part->nalloc = 0; part->nfree = 0; part->nested = 0;
     part->aborted = 1; part->attempts++;
     SMX_A_ADD(&sh.ctrl[SC_ABORTS], 1u);
@@ -281,7 +337,7 @@ struct SpecPolicy {
   SMX_D void finish_done(const DevState&) {
     part->nlog = nlog; part->nchunks = nchunks; part->ndeps = ndeps; part->dep_overflow = dep_overflow;
     part->nalloc = nalloc; part->nfree = nfree; part->nested = nested_drawn; part->live_delta = live_delta;
-    part->overflow = overflow; part->fail_cell = NOCLAIM; part->aborted = 0; part->attempts++;
+    part->overflow = overflow; part->fail_cell = NOCLAIM; part->aborted = 0; part->attempts++; part->nnode = nnode;
     for (int i = 0; i < SPEC_NCTR; i++) part->ctr[i] = ctr[i];
     SMX_A_STORE(&part->status, ST_DONE_NEW);
   }
@@ -368,15 +424,16 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
         sh.stamp[c] = e->prev;
       }
       if (tid == 0) {
-        for (uint32_t k = nl; k-- > 0;) {
-          const SpecLog* e = spec_entry(sh, p, k);
-          if (e->cell & NODE_ENTRY) s.pool[e->cell & ~NODE_ENTRY] = e->rec;
-        }
+        if (q.nnode)                                        // buried sections changed by seep(): oldest snapshot must win
+          for (uint32_t k = nl; k-- > 0;) {
+            const SpecLog* e = spec_entry(sh, p, k);
+            if (e->cell & NODE_ENTRY) s.pool[e->cell & ~NODE_ENTRY] = e->rec;
+          }
         for (uint32_t k = 0; k < q.nalloc; k++) {
           const uint32_t r = ctrl[SC_NRECLAIM]++;
           if (r < sh.reclaim_cap) sh.reclaim[r] = sh.alloc_log[(size_t)p * MAX_NODELOG + k]; else ctrl[SC_RECLAIM_LOST]++;
         }
-        q.rolled = 1; q.nalloc = 0; q.nfree = 0; q.ndeps = 0; q.dep_overflow = 0; q.nested = 0; q.overflow = 0;
+        q.nalloc = 0; q.nfree = 0; q.ndeps = 0; q.dep_overflow = 0; q.nested = 0; q.overflow = 0;
         ctrl[SC_KILLS]++;
         w.st[i] = ST_PENDING; w.nested[i] = 0;
       }
@@ -481,7 +538,7 @@ SMX_D void spec_begin_team(const DevState& s, const SpecShared& sh, uint32_t n, 
       const uint32_t i = r.idx;
       const uint32_t v = r.ring[i % 31] + r.ring[(i - 3) % 31];
       r.ring[i % 31] = v; r.idx = i + 1;
-      sh.draws[k] = (int)(v >> 1);
+      sh.draws[k] = v;
     }
     for (int i = 0; i < SC_COUNT; i++) sh.ctrl[i] = 0;
     const unsigned long long live = s.ctr[C_LIVE_SECTIONS];
@@ -492,24 +549,37 @@ SMX_D void spec_begin_team(const DevState& s, const SpecShared& sh, uint32_t n, 
   for (uint32_t p = tid; p < n; p += nt) {
     SpecPart& q = sh.part[p];
     q.status = ST_PENDING; q.kill = 0; q.aborted = 0; q.fail_cell = NOCLAIM; q.noff = 0; q.nested = 0; q.nlog = 0;
-    q.nchunks = 0; q.ndeps = 0; q.dep_overflow = 0; q.nalloc = 0; q.nfree = 0; q.overflow = 0; q.attempts = 0; q.rolled = 0;
+    q.nchunks = 0; q.ndeps = 0; q.dep_overflow = 0; q.nalloc = 0; q.nfree = 0; q.overflow = 0; q.attempts = 0; q.nnode = 0;
     q.live_delta = 0; q.blocked = 0;
     sh.pending[p] = p;
     sh.scout_len[p] = 0;
   }
 }
 SMX_D void spec_begin(const DevState& s, const SpecShared& sh, uint32_t n) { spec_begin_team(s, sh, n, 0u, 1u); }
-// phase end (ONE thread): consume the draws the phase used, rebuild the free-node stack
-SMX_D void spec_end(const DevState& s, const SpecShared& sh, uint32_t nparticles_done, uint32_t nested_done) {
-  RandState& r = *s.rnd;
-  const uint64_t nd = 2ull * nparticles_done + 2ull * nested_done;
-  for (uint64_t k = 0; k < nd; k++) {
-    const uint32_t i = r.idx;
-    const uint32_t v = r.ring[i % 31] + r.ring[(i - 3) % 31];
-    r.ring[i % 31] = v; r.idx = i + 1;
+// phase end (team): consume the draws the phase used, rebuild the free-node stack. The generator state after
+// nd draws is just its last 31 raw outputs, which the peeked stream already holds -- no replay loop.
+SMX_D void spec_end_team(const DevState& s, const SpecShared& sh, uint32_t nparticles_done, uint32_t nested_done,
+                         uint32_t tid, uint32_t nt) {
+  if (tid == 0) {
+    RandState& r = *s.rnd;
+    const uint64_t nd = 2ull * nparticles_done + 2ull * nested_done;
+    const uint32_t idx0 = r.idx;
+    for (uint64_t t = nd > 31 ? nd - 31 : 0; t < nd; t++) r.ring[(idx0 + (uint32_t)t) % 31] = sh.draws[t];
+    r.idx = idx0 + (uint32_t)nd;
+    r.calls += nd;
   }
-  r.calls += nd;
-  spec_finish_pool(s, sh);
+  uint32_t* ctrl = sh.ctrl;
+  const uint32_t nstart = ctrl[SC_NFREE_START];
+  uint32_t used = ctrl[SC_NODE_CURSOR];
+  if (used > nstart) used = nstart;
+  const uint32_t nf = nstart - used;
+  uint32_t nr = ctrl[SC_NRECLAIM];
+  if (nr > sh.reclaim_cap) nr = sh.reclaim_cap;
+  for (uint32_t i = tid; i < nr; i += nt) s.freelist[nf + i] = sh.reclaim[i];
+  if (tid == 0) *s.free_count = nf + nr;
+}
+SMX_D void spec_end(const DevState& s, const SpecShared& sh, uint32_t nparticles_done, uint32_t nested_done) {
+  spec_end_team(s, sh, nparticles_done, nested_done, 0u, 1u);
 }
 
 // A pending particle's predicted footprint = cells of its scout run + cells its previous attempt really touched +
@@ -546,7 +616,7 @@ SMX_D void spec_scout_one(const DevState& s, const SoilP* soils, const SpecShare
   ScoutPolicy pol(sh, pid);
   Sim<ScoutPolicy> sim(s, soils, pol);
   const uint32_t k = 2u * pid + 2u * sh.part[pid].noff;
-  const int ry = sh.draws[k] % s.dimy, rx = sh.draws[k + 1] % s.dimx;
+  const int ry = (int)(sh.draws[k] >> 1) % s.dimy, rx = (int)(sh.draws[k + 1] >> 1) % s.dimx;
   if constexpr (WIND) {
     Wind p; sim.wind_init(p, rx, ry); sim.wind_run(p);
   } else {

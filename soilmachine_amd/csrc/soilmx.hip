@@ -179,10 +179,9 @@ __global__ void __launch_bounds__(256) k_spec_boundary(DevState s, SpecShared sh
 __global__ void __launch_bounds__(64) k_spec_abandon(DevState s, SpecShared sh) {
   if (threadIdx.x == 0) spec_abandon(s, sh);
 }
-__global__ void __launch_bounds__(64) k_spec_end(DevState s, SpecShared sh, uint32_t whole_phase) {
-  if (threadIdx.x != 0) return;
+__global__ void __launch_bounds__(256) k_spec_end(DevState s, SpecShared sh, uint32_t whole_phase) {
   const uint32_t done = whole_phase ? sh.ctrl[SC_N] : sh.ctrl[SC_BASE];
-  spec_end(s, sh, done, sh.ctrl[SC_NESTED_COMMITTED]);
+  spec_end_team(s, sh, done, sh.ctrl[SC_NESTED_COMMITTED], threadIdx.x, blockDim.x);
 }
 
 __global__ void __launch_bounds__(256) k_map_frequency(float* __restrict__ freq, const float* __restrict__ track, size_t n4, size_t n) {
@@ -716,12 +715,12 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
     const uint32_t base = (c[SC_N] == 0) ? 0u : c[SC_BASE];
     if (c[SC_N] != 0) {
       hipLaunchKernelGGL(k_spec_abandon, dim3(1), dim3(64), 0, st, ctx->d, sh);
-      hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(64), 0, st, ctx->d, sh, 0u);
+      hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(256), 0, st, ctx->d, sh, 0u);
     }
     if (wind) hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, st, ctx->d, n - (int)base);
     else hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, st, ctx->d, n - (int)base);
   } else {
-    hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(64), 0, st, ctx->d, sh, 1u);
+    hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(256), 0, st, ctx->d, sh, 1u);
   }
   HIPCHK(hipGetLastError());
   return 0;

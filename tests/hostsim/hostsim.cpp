@@ -206,7 +206,7 @@ struct SpecBuffers {
   std::vector<uint32_t> stamp, claim, chunk_tab, alloc_log, free_log, pending, ctrl, reclaim, scout_cells, scout_len;
   std::vector<SpecPart> part;
   std::vector<SpecLog> arena;
-  std::vector<int> draws;
+  std::vector<uint32_t> draws;
   SpecShared sh;
 };
 static void spec_setup(hs_ctx* c, SpecBuffers& b, uint32_t n) {
