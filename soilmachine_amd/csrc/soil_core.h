@@ -168,9 +168,14 @@ struct Sim {
   }
   template <int N>
   SMX_D void batch(const size_t (&c)[N], View (&v)[N]) {
-    if (!pol.template touch_batch<N>(s, c)) ab = true;
+    uint32_t fresh = 0;                                     // bit i: cell i was acquired by this call (speculative engine)
+    if (!pol.template acquire_batch<N>(s, c, fresh)) ab = true;
+    Sec r[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] = load_view(c[i]);
+    for (int i = 0; i < N; i++) r[i] = s.cells[c[i]];       // whole 32-byte records: the views AND the undo snapshots
+    pol.template log_batch<N>(s, c, fresh, r);
+#pragma unroll
+    for (int i = 0; i < N; i++) { v[i].size = r[i].size; v[i].floor = r[i].floor; v[i].type = r[i].type; }
   }
 
   SMX_D double height_bilinear(f2 pos) {                    // Layermap::height(vec2) layermap.h:427-439
@@ -811,6 +816,12 @@ struct Sim {
     }
     for (int q = 0; q < ncasc; q++) {
       const f2 at = (q == 0) ? f2{(float)p.ix, (float)p.iy} : f2{(float)nx, (float)ny};
+      // while nothing has moved in this step, `cur` / `nb` are exact copies of the blocks around ipos / npos: the
+      // common "nothing to move" outcome is decided on them without any memory access
+      if (!changed) {
+        const bool any = (q == 0) ? cascade_precheck(cur) : cascade_precheck(nb);
+        if (!any) { n_casc++; continue; }
+      }
       changed |= particle_cascade<1>(at);
       if (ab) return false;
     }

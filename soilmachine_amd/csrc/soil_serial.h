@@ -12,7 +12,8 @@ struct SerialPolicy {
   SMX_D void finish(const DevState& s) { s.ctr[C_LIVE_SECTIONS] = live; *s.free_count = nfree; }
 
   SMX_D bool touch(const DevState&, size_t) { return true; }
-  template <int N> SMX_D bool touch_batch(const DevState&, const size_t (&)[N]) { return true; }
+  template <int N> SMX_D bool acquire_batch(const DevState&, const size_t (&)[N], uint32_t&) { return true; }
+  template <int N> SMX_D void log_batch(const DevState&, const size_t (&)[N], uint32_t, const Sec (&)[N]) {}
   SMX_D void pre_write_node(const DevState&, uint32_t) {}
   SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (!(v & f)) s.flags[c] = v | f; }
   SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (v & f) s.flags[c] = v & (uint8_t)~f; }

@@ -127,11 +127,12 @@ struct ScoutPolicy {
     if (c != last && c != last2) { last2 = last; last = c; if (len < SCOUT_CAP) out[len++] = (uint32_t)c; }
     return true;
   }
-  template <int N> SMX_D bool touch_batch(const DevState& s, const size_t (&c)[N]) {
+  template <int N> SMX_D bool acquire_batch(const DevState& s, const size_t (&c)[N], uint32_t&) {
 #pragma unroll
     for (int i = 0; i < N; i++) touch(s, c[i]);
     return true;
   }
+  template <int N> SMX_D void log_batch(const DevState&, const size_t (&)[N], uint32_t, const Sec (&)[N]) {}
   SMX_D void finish() { sh.scout_len[pid] = len; }
   SMX_D void pre_write_node(const DevState&, uint32_t) {}
   SMX_D void set_flag(const DevState&, size_t, uint8_t) {}
@@ -161,18 +162,26 @@ struct SpecPolicy {
     for (int i = 0; i < SPEC_NCTR; i++) ctr[i] = 0;
   }
 
-  SMX_D SpecLog* append(uint32_t cellkey, uint32_t prev) {
-    const uint32_t k = nlog;
-    const uint32_t ch = k / LOG_CHUNK;
-    if (ch >= nchunks) {
-      if (ch >= (uint32_t)MAX_CHUNKS) { overflow = 1; return nullptr; }
-      const uint32_t cid = SMX_A_ADD(&sh.ctrl[SC_CHUNK_CURSOR], 1u);
-      if (cid >= sh.arena_chunks) { overflow = 1; return nullptr; }
+  SpecLog* chunk = nullptr;                                 // arena chunk that receives the next log entries
+  SMX_D bool next_chunk() {                                 // nlog is a multiple of LOG_CHUNK: open chunk nlog / LOG_CHUNK
+    const uint32_t ch = nlog / LOG_CHUNK;
+    uint32_t cid;
+    if (ch < nchunks) cid = sh.chunk_tab[(size_t)pid * MAX_CHUNKS + ch];      // chunk kept from an earlier attempt
+    else {
+      if (ch >= (uint32_t)MAX_CHUNKS) { overflow = 1; return false; }
+      cid = SMX_A_ADD(&sh.ctrl[SC_CHUNK_CURSOR], 1u);
+      if (cid >= sh.arena_chunks) { overflow = 1; return false; }
       sh.chunk_tab[(size_t)pid * MAX_CHUNKS + ch] = cid;
       nchunks = ch + 1;
     }
-    nlog = k + 1;
-    SpecLog* e = spec_entry(sh, pid, k);
+    chunk = sh.arena + (size_t)cid * LOG_CHUNK;
+    return true;
+  }
+  SMX_D SpecLog* append(uint32_t cellkey, uint32_t prev) {
+    const uint32_t off = nlog % LOG_CHUNK;
+    if (off == 0 && !next_chunk()) return nullptr;
+    nlog++;
+    SpecLog* e = chunk + off;
     e->cell = cellkey; e->prev = prev;
     return e;
   }
@@ -190,25 +199,29 @@ struct SpecPolicy {
     for (uint32_t i = 0; i < ndeps; i++) have |= (part->deps[i] == owner);
     if (!have) { if (ndeps < (uint32_t)MAX_DEPS) part->deps[ndeps++] = owner; else dep_overflow = 1; }
   }
-  template <int N> SMX_D bool touch_batch(const DevState& s, const size_t (&c)[N]) {
+  // acquire_batch: stamps of all N cells -> which are new -> may we take them (owner status, claims) -> CAS.
+  // `fresh` gets one bit per cell this call acquired; log_batch then snapshots exactly those.
+  uint32_t prevs[9];                                        // stamp values replaced by the last acquire_batch
+  uint32_t depmask = 0;                                     // bit i: prevs[i] belongs to a tentative (DONE_OLD) particle
+  template <int N> SMX_D bool acquire_batch(const DevState&, const size_t (&c)[N], uint32_t& fresh) {
+    static_assert(N <= 9, "batches are at most one 3x3 block");
     uint32_t v[N];
-    bool need[N];
-    bool any = false;
+    uint32_t need = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) v[i] = SMX_A_LOAD(&sh.stamp[c[i]]);
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      need[i] = (v[i] != me);
+      bool nd = (v[i] != me);
 #pragma unroll
-      for (int j = 0; j < i; j++) if (c[j] == c[i]) need[i] = false;   // a batch may name a cell twice (map border)
-      any |= need[i];
+      for (int j = 0; j < i; j++) if (c[j] == c[i]) nd = false;   // a batch may name a cell twice (map border)
+      need |= nd ? (1u << i) : 0u;
     }
-    if (!any) return true;
-    // ---- may we take them at all?
+    fresh = 0; depmask = 0;
+    if (!need) return true;
     bool fail = false;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      if (need[i] && (v[i] == POISON || v[i] > me)) {
+      if (((need >> i) & 1) && (v[i] == POISON || v[i] > me)) {
         if (v[i] != POISON) SMX_A_STORE(&sh.part[v[i] - 1].kill, 1u);   // a later particle got here first: undo it
         fail_cell = (uint32_t)c[i]; fail = true;
       }
@@ -217,41 +230,43 @@ struct SpecPolicy {
     uint32_t stv[N], clv[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      stv[i] = (need[i] && v[i] != 0) ? SMX_A_LOAD(&sh.part[v[i] - 1].status) : ST_COMMITTED;
-      clv[i] = need[i] ? SMX_A_LOAD(&sh.claim[c[i]]) : NOCLAIM;
+      const bool nd = (need >> i) & 1;
+      stv[i] = (nd && v[i] != 0) ? SMX_A_LOAD(&sh.part[v[i] - 1].status) : ST_COMMITTED;
+      clv[i] = nd ? SMX_A_LOAD(&sh.claim[c[i]]) : NOCLAIM;
     }
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      if (need[i] && (stv[i] == ST_PENDING || stv[i] == ST_DONE_NEW || clv[i] < pid)) { fail_cell = (uint32_t)c[i]; fail = true; }
+      if (((need >> i) & 1) && (stv[i] == ST_PENDING || stv[i] == ST_DONE_NEW || clv[i] < pid)) { fail_cell = (uint32_t)c[i]; fail = true; }
     }
     if (fail) return false;
-    // ---- take them
-    uint32_t old[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) old[i] = need[i] ? SMX_A_CAS(&sh.stamp[c[i]], v[i], me) : v[i];
-    Sec rec[N]; float tr[N], wf[N]; uint32_t fl[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      if (need[i] && old[i] == v[i]) {
-        const size_t fi = spec_fidx(s, c[i]);
-        rec[i] = s.cells[c[i]]; tr[i] = s.wtrack[fi]; wf[i] = s.windfreq[fi]; fl[i] = s.flags[c[i]];
-      }
-    }
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      if (!need[i]) continue;
-      if (old[i] == v[i]) {
-        SpecLog* e = append((uint32_t)c[i], v[i]);
-        if (!e) { SMX_A_STORE(&sh.stamp[c[i]], v[i]); fail_cell = (uint32_t)c[i]; ok = false; continue; }
-        e->rec = rec[i]; e->wtrack = tr[i]; e->windfreq = wf[i]; e->flags = fl[i];
-        if (stv[i] == ST_DONE_OLD && v[i] != 0) add_dep(v[i] - 1);
-      } else if (ok) {
-        ok = touch_slow(s, c[i], old[i]);                   // somebody changed the stamp under us: one-cell protocol
+      if ((need >> i) & 1) {
+        const uint32_t old = SMX_A_CAS(&sh.stamp[c[i]], v[i], me);
+        if (old == v[i]) { fresh |= 1u << i; prevs[i] = v[i]; if (stv[i] == ST_DONE_OLD && v[i] != 0) depmask |= 1u << i; }
+        else { fail_cell = (uint32_t)c[i]; ok = false; }    // somebody changed the stamp under us (rare): give up
       }
     }
     if (ok) last = c[N - 1];
     return ok;
+  }
+  template <int N> SMX_D void log_batch(const DevState& s, const size_t (&c)[N], uint32_t fresh, const Sec (&r)[N]) {
+    if (!fresh) return;
+    float tr[N], wf[N]; uint32_t fl[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if ((fresh >> i) & 1) { const size_t fi = spec_fidx(s, c[i]); tr[i] = s.wtrack[fi]; wf[i] = s.windfreq[fi]; fl[i] = s.flags[c[i]]; }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if ((fresh >> i) & 1) {
+        SpecLog* e = append((uint32_t)c[i], prevs[i]);
+        if (!e) { SMX_A_STORE(&sh.stamp[c[i]], prevs[i]); continue; }   // log full: overflow is set, the attempt is void
+        e->rec = r[i]; e->wtrack = tr[i]; e->windfreq = wf[i]; e->flags = fl[i];
+        if ((depmask >> i) & 1) add_dep(prevs[i] - 1);
+      }
+    }
   }
   SMX_D bool touch_slow(const DevState& s, size_t c, uint32_t v) {
     while (true) {
