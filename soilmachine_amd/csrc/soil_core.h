@@ -144,7 +144,7 @@ struct Sim {
   // ---------------- cell access (every access announces itself to the policy first) ----------------
   SMX_D Sec& cell(int x, int y) {
     const size_t c = cidx(x, y);
-    if (!pol.touch(s, c)) ab = true;
+    if (!pol.touch(s, c, fidx(x, y))) ab = true;
     return s.cells[c];
   }
   SMX_D double height(int x, int y) {                       // Layermap::height(ivec2) layermap.h:422-425
@@ -166,14 +166,15 @@ struct Sim {
     View v; v.size = r.size; v.floor = r.floor; v.type = r.type;
     return v;
   }
+  // c[i] = cell-order index, f[i] = frequency-order index of the same column (water.h:53)
   template <int N>
-  SMX_D void batch(const size_t (&c)[N], View (&v)[N]) {
-    uint32_t fresh = 0;                                     // bit i: cell i was acquired by this call (speculative engine)
-    if (!pol.template acquire_batch<N>(s, c, fresh)) ab = true;
+  SMX_D void batch(const size_t (&c)[N], const size_t (&f)[N], View (&v)[N]) {
+    typename P::template Pre<N> pf;
+    pol.template prefetch<N>(s, c, f, pf);                  // stamps, claims, undo words: loads only, no waiting
     Sec r[N];
 #pragma unroll
     for (int i = 0; i < N; i++) r[i] = s.cells[c[i]];       // whole 32-byte records: the views AND the undo snapshots
-    pol.template log_batch<N>(s, c, fresh, r);
+    if (!pol.template acquire_log<N>(s, c, pf, r)) ab = true;
 #pragma unroll
     for (int i = 0; i < N; i++) { v[i].size = r[i].size; v[i].floor = r[i].floor; v[i].type = r[i].type; }
   }
@@ -183,10 +184,11 @@ struct Sim {
     const float fx = floorf(pos.x), fy = floorf(pos.y);
     const int px = (int)fx, py = (int)fy;
     const float wx = pos.x - fx, wy = pos.y - fy;
-    const size_t c00 = cidx(px, py);
+    const size_t c00 = cidx(px, py), f00 = fidx(px, py);
     const size_t cc[4] = {c00, c00 + (size_t)s.dimy, c00 + 1, c00 + (size_t)s.dimy + 1};
+    const size_t ff[4] = {f00, f00 + 1, f00 + (size_t)s.dimx, f00 + (size_t)s.dimx + 1};
     View v[4];
-    batch<4>(cc, v);
+    batch<4>(cc, ff, v);
     const double h00 = vh(v[0]), h10 = vh(v[1]), h01 = vh(v[2]), h11 = vh(v[3]);
     h += (1.0 - wx) * (1.0 - wy) * h00;
     h += (1.0 - wx) * wy * h10;                             // crossed weights as in the reference (:434-435)
@@ -199,9 +201,11 @@ struct Sim {
     const int SC = s.scale;
     const bool xm = x > 0, xp = x < s.dimx - 1, ym = y > 0, yp = y < s.dimy - 1;
     const size_t c0 = cidx(x, y);
+    const size_t f0 = fidx(x, y);
     const size_t cc[5] = {c0, xm ? c0 - (size_t)s.dimy : c0, xp ? c0 + (size_t)s.dimy : c0, ym ? c0 - 1 : c0, yp ? c0 + 1 : c0};
+    const size_t ff[5] = {f0, xm ? f0 - 1 : f0, xp ? f0 + 1 : f0, ym ? f0 - (size_t)s.dimx : f0, yp ? f0 + (size_t)s.dimx : f0};
     View v[5];
-    batch<5>(cc, v);
+    batch<5>(cc, ff, v);
     centre = v[0];
     const double h0 = vh(v[0]);
     const double hxm = xm ? vh(v[1]) : 0.0, hxp = xp ? vh(v[2]) : 0.0;
@@ -252,15 +256,17 @@ struct Sim {
   // the 3x3 block around (ix,iy): cells[k] / views[k] for neighbour code k (out-of-bounds -> the centre cell,
   // flagged by inb[k] = false), index 8 = centre
   SMX_D void block3x3(int ix, int iy, size_t (&cc)[9], bool (&inb)[8], View (&v)[9]) {
-    const size_t c0 = cidx(ix, iy);
+    const size_t c0 = cidx(ix, iy), f0 = fidx(ix, iy);
+    size_t ff[9];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
       inb[k] = !(nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0);
       cc[k] = inb[k] ? cidx(nx, ny) : c0;
+      ff[k] = inb[k] ? fidx(nx, ny) : f0;
     }
-    cc[8] = c0;
-    batch<9>(cc, v);
+    cc[8] = c0; ff[8] = f0;
+    batch<9>(cc, ff, v);
   }
   SMX_D Sorted sorted_neighbours(int ix, int iy) {          // particle.h:43-60 == water.h:168-185
     size_t cc[9]; bool inb[8]; View v[9];
@@ -467,8 +473,8 @@ struct Sim {
   }
   template <int MODE>                                         // 0: + water frequency/track, 1: + wind frequency, 2: cells only
   SMX_D void load_block(int cx, int cy, Blk& b) {
-    const size_t c0 = cidx(cx, cy);
-    size_t cc[9];
+    const size_t c0 = cidx(cx, cy), f0 = fidx(cx, cy);
+    size_t cc[9], ff[9];
     uint32_t m = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -476,11 +482,12 @@ struct Sim {
       const bool in = !(nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0);
       m |= in ? (1u << k) : 0u;
       cc[k] = in ? (size_t)((long long)c0 + (long long)nb_dx(k) * s.dimy + nb_dy(k)) : c0;
+      ff[k] = in ? (size_t)((long long)f0 + (long long)nb_dy(k) * s.dimx + nb_dx(k)) : f0;
     }
-    cc[8] = c0;
+    cc[8] = c0; ff[8] = f0;
     b.c0 = c0; b.inb = m;
     View t[9];
-    batch<9>(cc, t);
+    batch<9>(cc, ff, t);
 #define X(i) b.v##i = t[i];
     SMX_FOR9(X)
 #undef X

@@ -11,9 +11,10 @@ struct SerialPolicy {
   SMX_D explicit SerialPolicy(const DevState& s) : live(s.ctr[C_LIVE_SECTIONS]), nfree(*s.free_count) {}
   SMX_D void finish(const DevState& s) { s.ctr[C_LIVE_SECTIONS] = live; *s.free_count = nfree; }
 
-  SMX_D bool touch(const DevState&, size_t) { return true; }
-  template <int N> SMX_D bool acquire_batch(const DevState&, const size_t (&)[N], uint32_t&) { return true; }
-  template <int N> SMX_D void log_batch(const DevState&, const size_t (&)[N], uint32_t, const Sec (&)[N]) {}
+  template <int N> struct Pre {};
+  SMX_D bool touch(const DevState&, size_t, size_t) { return true; }
+  template <int N> SMX_D void prefetch(const DevState&, const size_t (&)[N], const size_t (&)[N], Pre<N>&) {}
+  template <int N> SMX_D bool acquire_log(const DevState&, const size_t (&)[N], const Pre<N>&, const Sec (&)[N]) { return true; }
   SMX_D void pre_write_node(const DevState&, uint32_t) {}
   SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (!(v & f)) s.flags[c] = v | f; }
   SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (v & f) s.flags[c] = v & (uint8_t)~f; }

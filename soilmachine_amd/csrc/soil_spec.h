@@ -123,16 +123,17 @@ struct ScoutPolicy {
   uint32_t* out;
   size_t last = ~(size_t)0, last2 = ~(size_t)0;
   SMX_D ScoutPolicy(const SpecShared& sh_, uint32_t p) : sh(sh_), pid(p), out(sh_.scout_cells + (size_t)p * SCOUT_CAP) {}
-  SMX_D bool touch(const DevState&, size_t c) {
+  template <int N> struct Pre {};
+  SMX_D bool touch(const DevState&, size_t c, size_t = 0) {
     if (c != last && c != last2) { last2 = last; last = c; if (len < SCOUT_CAP) out[len++] = (uint32_t)c; }
     return true;
   }
-  template <int N> SMX_D bool acquire_batch(const DevState& s, const size_t (&c)[N], uint32_t&) {
+  template <int N> SMX_D void prefetch(const DevState&, const size_t (&)[N], const size_t (&)[N], Pre<N>&) {}
+  template <int N> SMX_D bool acquire_log(const DevState& s, const size_t (&c)[N], const Pre<N>&, const Sec (&)[N]) {
 #pragma unroll
     for (int i = 0; i < N; i++) touch(s, c[i]);
     return true;
   }
-  template <int N> SMX_D void log_batch(const DevState&, const size_t (&)[N], uint32_t, const Sec (&)[N]) {}
   SMX_D void finish() { sh.scout_len[pid] = len; }
   SMX_D void pre_write_node(const DevState&, uint32_t) {}
   SMX_D void set_flag(const DevState&, size_t, uint8_t) {}
@@ -186,89 +187,89 @@ struct SpecPolicy {
     return e;
   }
 
-  SMX_D bool touch(const DevState& s, size_t c) {
+  SMX_D bool touch(const DevState& s, size_t c, size_t fi) {
     if (c == last) return true;
     const uint32_t v = SMX_A_LOAD(&sh.stamp[c]);
     if (v == me) { last = c; return true; }
-    return touch_slow(s, c, v);
+    return touch_slow(s, c, fi, v);
   }
-  // A batch is acquired in STAGES so that the memory operations of all its new cells overlap: stamp loads ->
-  // (owner status, claim) loads -> CAS -> snapshot loads -> log writes. Cells already ours cost one load.
   SMX_D void add_dep(uint32_t owner) {
     bool have = false;
     for (uint32_t i = 0; i < ndeps; i++) have |= (part->deps[i] == owner);
     if (!have) { if (ndeps < (uint32_t)MAX_DEPS) part->deps[ndeps++] = owner; else dep_overflow = 1; }
   }
-  // acquire_batch: stamps of all N cells -> which are new -> may we take them (owner status, claims) -> CAS.
-  // `fresh` gets one bit per cell this call acquired; log_batch then snapshots exactly those.
-  uint32_t prevs[9];                                        // stamp values replaced by the last acquire_batch
-  uint32_t depmask = 0;                                     // bit i: prevs[i] belongs to a tentative (DONE_OLD) particle
-  template <int N> SMX_D bool acquire_batch(const DevState&, const size_t (&c)[N], uint32_t& fresh) {
-    static_assert(N <= 9, "batches are at most one 3x3 block");
-    uint32_t v[N];
-    uint32_t need = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) v[i] = SMX_A_LOAD(&sh.stamp[c[i]]);
+  // ---- batched acquisition. prefetch() issues EVERY load a batch can need in one go -- stamps, claims and the
+  // words an undo record stores besides the 32-byte section record -- for all N cells, owned or not. Reading a
+  // cell's data before owning it is safe: data only changes under an owner, and if anybody owned the cell between
+  // our stamp load and our CAS the CAS fails (a stamp never returns to an old value inside a round) and the attempt
+  // is thrown away. acquire_log() then needs at most one more round trip (owner status, only for cells taken over)
+  // before the CAS. Cells that are already ours cost nothing but the prefetch.
+  template <int N> struct Pre { uint32_t v[N], cl[N], fl[N]; float tr[N], wf[N]; };
+  template <int N> SMX_D void prefetch(const DevState& s, const size_t (&c)[N], const size_t (&f)[N], Pre<N>& p) {
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      bool nd = (v[i] != me);
+      p.v[i] = SMX_A_LOAD(&sh.stamp[c[i]]); p.cl[i] = SMX_A_LOAD(&sh.claim[c[i]]);
+      p.tr[i] = s.wtrack[f[i]]; p.wf[i] = s.windfreq[f[i]]; p.fl[i] = s.flags[c[i]];
+    }
+  }
+  template <int N> SMX_D bool acquire_log(const DevState&, const size_t (&c)[N], const Pre<N>& p, const Sec (&r)[N]) {
+    uint32_t need = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      bool nd = (p.v[i] != me);
 #pragma unroll
       for (int j = 0; j < i; j++) if (c[j] == c[i]) nd = false;   // a batch may name a cell twice (map border)
       need |= nd ? (1u << i) : 0u;
     }
-    fresh = 0; depmask = 0;
     if (!need) return true;
     bool fail = false;
+    uint32_t takeover = 0;                                  // cells last touched by a lower particle: its status decides
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      if (((need >> i) & 1) && (v[i] == POISON || v[i] > me)) {
-        if (v[i] != POISON) SMX_A_STORE(&sh.part[v[i] - 1].kill, 1u);   // a later particle got here first: undo it
-        fail_cell = (uint32_t)c[i]; fail = true;
+      if ((need >> i) & 1) {
+        if (p.v[i] == POISON || p.v[i] > me) {
+          if (p.v[i] != POISON) SMX_A_STORE(&sh.part[p.v[i] - 1].kill, 1u);   // a later particle got here first: undo it
+          fail_cell = (uint32_t)c[i]; fail = true;
+        } else if (p.cl[i] < pid) { fail_cell = (uint32_t)c[i]; fail = true; }   // yield to a lower pending particle
+        else if (p.v[i] != 0) takeover |= 1u << i;
       }
     }
     if (fail) return false;
-    uint32_t stv[N], clv[N];
+    uint32_t depmask = 0;
+    if (takeover) {
+      uint32_t stv[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      const bool nd = (need >> i) & 1;
-      stv[i] = (nd && v[i] != 0) ? SMX_A_LOAD(&sh.part[v[i] - 1].status) : ST_COMMITTED;
-      clv[i] = nd ? SMX_A_LOAD(&sh.claim[c[i]]) : NOCLAIM;
-    }
+      for (int i = 0; i < N; i++) stv[i] = ((takeover >> i) & 1) ? SMX_A_LOAD(&sh.part[p.v[i] - 1].status) : ST_COMMITTED;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      if (((need >> i) & 1) && (stv[i] == ST_PENDING || stv[i] == ST_DONE_NEW || clv[i] < pid)) { fail_cell = (uint32_t)c[i]; fail = true; }
+      for (int i = 0; i < N; i++) {
+        if (stv[i] == ST_PENDING || stv[i] == ST_DONE_NEW) { fail_cell = (uint32_t)c[i]; fail = true; }   // still running this round
+        if (stv[i] == ST_DONE_OLD) depmask |= 1u << i;
+      }
+      if (fail) return false;
     }
-    if (fail) return false;
+    uint32_t got = 0;
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < N; i++) {
       if ((need >> i) & 1) {
-        const uint32_t old = SMX_A_CAS(&sh.stamp[c[i]], v[i], me);
-        if (old == v[i]) { fresh |= 1u << i; prevs[i] = v[i]; if (stv[i] == ST_DONE_OLD && v[i] != 0) depmask |= 1u << i; }
+        const uint32_t old = SMX_A_CAS(&sh.stamp[c[i]], p.v[i], me);
+        if (old == p.v[i]) got |= 1u << i;
         else { fail_cell = (uint32_t)c[i]; ok = false; }    // somebody changed the stamp under us (rare): give up
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if ((got >> i) & 1) {
+        SpecLog* e = append((uint32_t)c[i], p.v[i]);
+        if (!e) { SMX_A_STORE(&sh.stamp[c[i]], p.v[i]); ok = false; continue; }   // log full: overflow is set, the attempt is void
+        e->rec = r[i]; e->wtrack = p.tr[i]; e->windfreq = p.wf[i]; e->flags = p.fl[i];
+        if ((depmask >> i) & 1) add_dep(p.v[i] - 1);
       }
     }
     if (ok) last = c[N - 1];
     return ok;
   }
-  template <int N> SMX_D void log_batch(const DevState& s, const size_t (&c)[N], uint32_t fresh, const Sec (&r)[N]) {
-    if (!fresh) return;
-    float tr[N], wf[N]; uint32_t fl[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      if ((fresh >> i) & 1) { const size_t fi = spec_fidx(s, c[i]); tr[i] = s.wtrack[fi]; wf[i] = s.windfreq[fi]; fl[i] = s.flags[c[i]]; }
-    }
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      if ((fresh >> i) & 1) {
-        SpecLog* e = append((uint32_t)c[i], prevs[i]);
-        if (!e) { SMX_A_STORE(&sh.stamp[c[i]], prevs[i]); continue; }   // log full: overflow is set, the attempt is void
-        e->rec = r[i]; e->wtrack = tr[i]; e->windfreq = wf[i]; e->flags = fl[i];
-        if ((depmask >> i) & 1) add_dep(prevs[i] - 1);
-      }
-    }
-  }
-  SMX_D bool touch_slow(const DevState& s, size_t c, uint32_t v) {
+  SMX_D bool touch_slow(const DevState& s, size_t c, size_t fi, uint32_t v) {
     while (true) {
       if (v == me) return true;                             // (a batch may name the same cell twice)
       if (v == POISON) { fail_cell = (uint32_t)c; return false; }
@@ -288,7 +289,6 @@ struct SpecPolicy {
       if (old != v) { v = old; continue; }
       SpecLog* e = append((uint32_t)c, v);
       if (!e) { SMX_A_STORE(&sh.stamp[c], v); fail_cell = (uint32_t)c; return false; }
-      const size_t fi = spec_fidx(s, c);
       e->rec = s.cells[c]; e->wtrack = s.wtrack[fi]; e->windfreq = s.windfreq[fi]; e->flags = s.flags[c];
       if (dep) add_dep(v - 1);
       last = c;
