@@ -111,6 +111,16 @@ struct Wind {             // WindParticle (wind.h:11-46)
   uint32_t surface, contains;
 };
 
+// (size, floor, type) of a column's top section, and the 3x3 block of such views a particle carries from step
+// to step (see Sim "the carried 3x3 block"). Namespace scope: the speculative engine checkpoints them.
+struct View { double size, floor; uint32_t type; };
+#define SMX_FOR9(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#define SMX_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+struct Blk {
+  View v0, v1, v2, v3, v4, v5, v6, v7, v8;                   // v8 = centre, vk = neighbour code k
+  size_t c0; uint32_t inb; float fr, tr;                     // inb: bit k = neighbour code k is in bounds
+};
+
 // One suspended WaterParticle::cascade invocation (water.h:151-283): centre, remaining spill budget,
 // the sorted neighbour list and the loop index.
 struct Frame { int ix, iy, spill, num, i; uint32_t codes; };
@@ -123,6 +133,8 @@ struct Sim {
   P& pol;
   bool grid_mode = false;  // inside the grid pass: newly wet cells go to the active bitmap
   bool ab = false;         // speculative execution only: this particle has been aborted
+  bool susp_ok = false;    // speculative execution only: the main loop of this particle may be suspended ...
+  int susp = 0;            // ... and has been (2 = before interact()'s block load; the block is checkpointed)
   // counters live in registers and are flushed once per kernel
   unsigned long long n_steps_w_top = 0, n_steps_w_all = 0, n_steps_wind = 0, n_nested = 0, n_floods = 0,
                      n_casc = 0, n_casc_tr = 0, n_wcasc = 0, n_overflow = 0;
@@ -158,7 +170,8 @@ struct Sim {
   // ---- batched access: announce N cells to the policy at once, then load their (size, floor, type) views with
   // all loads in flight together. One memory round trip per batch instead of one per cell: the exact engines
   // are latency-bound (DESIGN.md "Per-step latency"), so the step is organised as three batches.
-  struct View { double size, floor; uint32_t type; };
+  using View = smx::View;
+  using Blk = smx::Blk;
   SMX_D static double vh(const View& v) { return v.floor + v.size; }
   SMX_D static uint32_t vsurf(const View& v) { return v.type == EMPTY ? 0u : v.type; }
   SMX_D View load_view(size_t c) const {
@@ -440,12 +453,6 @@ struct Sim {
   // NOTE: the nine views are NAMED fields, not an array: a select chain over array elements gets folded back into
   // a variably-indexed load by the compiler, which forces the whole block into scratch memory (measured: 38
   // scratch stores per step). Named scalars cannot be indexed, so the block provably stays in registers.
-#define SMX_FOR9(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
-#define SMX_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-  struct Blk {
-    View v0, v1, v2, v3, v4, v5, v6, v7, v8;                 // v8 = centre, vk = neighbour code k
-    size_t c0; uint32_t inb; float fr, tr;                   // inb: bit k = neighbour code k is in bounds
-  };
   SMX_D static int code_rel(int dx, int dy) { const int lin = (dx + 1) * 3 + (dy + 1); return lin < 4 ? lin : (lin == 4 ? 8 : lin - 1); }
   SMX_D static View blk_get(const Blk& b, int k) {
     View r = b.v0;
@@ -695,11 +702,9 @@ struct Sim {
     Frame& f = st[depth++];
     f.ix = ix; f.iy = iy; f.spill = spill; f.num = sn.num; f.i = 0; f.codes = sn.codes;
   }
-  // One fused move()+interact() of a WaterParticle (water.h:43-121). `cur` is the 3x3 block around ipos, `nb`
-  // receives the block around the new position. Returns false when the particle's move/interact loop ends.
-  SMX_D bool water_step(Water& p, bool toplevel, const Blk& cur, Blk& nb) {
-    // ---- move (water.h:43-73)
-    View cv = cur.v8;
+  // WaterParticle::move (water.h:43-73) on the carried block `cur` around ipos. false = move() returned false.
+  SMX_D bool water_move(Water& p, bool toplevel, const Blk& cur) {
+    const View cv = cur.v8;
     const f3 n = normal_blk(p.ix, p.iy, cur);
     p.surface = vsurf(cv);
     p.evaprate = 0.01;
@@ -725,10 +730,17 @@ struct Sim {
     }
     n_steps_w_all++;
     if (toplevel) n_steps_w_top++;
-    // ---- interact (water.h:75-121)
+    return true;
+  }
+  // WaterParticle::interact (water.h:75-121): `cur` is the block around ipos, `nb` receives the block around the
+  // new position. 1 = interact() returned true, 0 = false, -1 = the new block could not be acquired (speculative
+  // engine): nothing of interact() has happened yet, so the particle can be resumed exactly here.
+  SMX_D int water_interact(Water& p, const Blk& cur, Blk& nb) {
+    View cv = cur.v8;
+    const float fr = cur.fr;
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-    load_block<0>(nx, ny, nb);                           // THE memory round trip of this step
-    if (ab) return false;
+    load_block<0>(nx, ny, nb);                               // THE memory round trip of this step
+    if (ab) return -1;
     const SoilP& param = soils[p.surface];
     const double hb = bilinear_blk(p.pos, nx, ny, nb);
     double c_eq = param.solubility * (vh(cv) - hb) * (double)s.scale / 80.0;
@@ -746,34 +758,42 @@ struct Sim {
       p.sediment += soils[p.contains].equrate * cdiff;
       add_v(p.ix, p.iy, cc, cv, -soils[p.contains].equrate * cdiff * p.volume, p.contains);
     }
-    if (ab) return false;
+    if (ab) return 0;
     const int rdx = p.ix - nx, rdy = p.iy - ny;              // the column just eroded may lie inside the new block
     if (rdx >= -1 && rdx <= 1 && rdy >= -1 && rdy <= 1) blk_put(nb, code_rel(rdx, rdy), cv);
     cascade_blk(nx, ny, nb);                                 // Particle::cascade(pos, .., 0) (:113)
-    if (ab) return false;
+    if (ab) return 0;
     p.sediment /= (1.0 - p.evaprate);
     if (p.sediment > 1.0) p.sediment = 1.0;
     p.volume *= (1.0 - p.evaprate);
     p.ix = nx; p.iy = ny;                                    // (the reference recomputes round(pos) in the next move())
-    return p.volume > 0.01;
+    return p.volume > 0.01 ? 1 : 0;
   }
-  // while(particle.move(..) && particle.interact(..)); (SoilMachine.cpp:293, water.h:259); the two blocks ping-pong
-  SMX_D void water_loop(Water& p, bool toplevel) {
+  // while(particle.move(..) && particle.interact(..)); (SoilMachine.cpp:293, water.h:259); the two blocks ping-pong.
+  // resume = true: continue a suspended particle at its interact() (the block around ipos comes from the checkpoint)
+  SMX_D void water_loop(Water& p, bool toplevel, bool resume = false) {
     Blk A, B;
-    p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    load_block<0>(p.ix, p.iy, A);
-    if (ab) return;
+    if (resume) pol.load_blk(A);
+    else {
+      p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
+      load_block<0>(p.ix, p.iy, A);
+      if (ab) return;
+    }
     while (true) {
-      if (!water_step(p, toplevel, A, B)) return;
-      if (!water_step(p, toplevel, B, A)) return;
+      if (!resume && !water_move(p, toplevel, A)) return;
+      resume = false;
+      int r = water_interact(p, A, B);
+      if (r <= 0) { if (r < 0 && susp_ok) { susp = 2; pol.save_blk(A); } return; }
+      if (!water_move(p, toplevel, B)) return;
+      r = water_interact(p, B, A);
+      if (r <= 0) { if (r < 0 && susp_ok) { susp = 2; pol.save_blk(B); } return; }
     }
   }
-  // One fused move()+interact() of a WindParticle (wind.h:54-136); same block scheme as water_step.
-  SMX_D bool wind_step(Wind& p, const Blk& cur, Blk& nb) {
+  // WindParticle::move (wind.h:54-92) on the carried block; false = move() returned false
+  SMX_D bool wind_move(Wind& p, const Blk& cur) {
     const f3 pspeed = {-2.f, 0.f, 1.f};
     const double gravity = 0.25, winddominance = 0.2, windfriction = 0.8;
-    // ---- move (wind.h:54-92)
-    View cv = cur.v8;
+    const View cv = cur.v8;
     const f3 n = normal_blk(p.ix, p.iy, cur);
     p.surface = vsurf(cv);
     const size_t fi = fidx(p.ix, p.iy);
@@ -794,10 +814,15 @@ struct Sim {
     if (!(p.pos.x >= 0.0f && p.pos.y >= 0.0f) || !((int)p.pos.x < s.dimx - 1 && (int)p.pos.y < s.dimy - 1)) return false;
     if (sqrtf(dot3(p.speed, p.speed)) < 0.01) return false;
     n_steps_wind++;
-    // ---- interact (wind.h:94-136)
+    return true;
+  }
+  // WindParticle::interact (wind.h:94-136). 1 = go on (interact() always returns true), 0 = aborted somewhere
+  // inside (speculative engine), -1 = the new block could not be acquired: resumable exactly here.
+  SMX_D int wind_interact(Wind& p, const Blk& cur, Blk& nb) {
+    View cv = cur.v8;
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
     load_block<1>(nx, ny, nb);
-    if (ab) return false;
+    if (ab) return -1;
     const SoilP& param = soils[p.surface];
     const double hb = bilinear_blk(p.pos, nx, ny, nb);
     View nv = nb.v8;
@@ -830,30 +855,39 @@ struct Sim {
         if (!any) { n_casc++; continue; }
       }
       changed |= particle_cascade<1>(at);
-      if (ab) return false;
+      if (ab) return 0;
     }
     p.ix = nx; p.iy = ny;
     if (changed) load_block<1>(nx, ny, nb);               // material moved inside the block: refresh the views
-    return !ab;
+    return ab ? 0 : 1;
   }
-  SMX_D void wind_loop(Wind& p) {                            // SoilMachine.cpp:306
-    if (soils[p.contains].suspension == 0.0) return;         // wind.h:56-57 (contains never changes: checked once)
+  SMX_D void wind_loop(Wind& p, bool resume = false) {       // SoilMachine.cpp:306
     Blk A, B;
-    p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
-    load_block<1>(p.ix, p.iy, A);
-    if (ab) return;
+    if (resume) pol.load_blk(A);
+    else {
+      if (soils[p.contains].suspension == 0.0) return;       // wind.h:56-57 (contains never changes: checked once)
+      p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y);
+      load_block<1>(p.ix, p.iy, A);
+      if (ab) return;
+    }
     while (true) {
-      if (!wind_step(p, A, B)) return;
-      if (!wind_step(p, B, A)) return;
+      if (!resume && !wind_move(p, A)) return;
+      resume = false;
+      int r = wind_interact(p, A, B);
+      if (r <= 0) { if (r < 0 && susp_ok) { susp = 2; pol.save_blk(A); } return; }
+      if (!wind_move(p, B)) return;
+      r = wind_interact(p, B, A);
+      if (r <= 0) { if (r < 0 && susp_ok) { susp = 2; pol.save_blk(B); } return; }
     }
   }
   // Runs one WaterParticle to completion INCLUDING everything it spawns (SoilMachine.cpp:292-296, water.h:258-262),
   // then drains the cascade frame stack. `start_with_particle` = false: only drain the frames already pushed.
-  SMX_D void water_drive(Water p, bool toplevel, bool start_with_particle, Frame* st, int& depth) {
+  SMX_D void water_drive(Water& p, bool toplevel, bool start_with_particle, Frame* st, int& depth, bool resume = false) {
     bool have = start_with_particle;
     while (true) {
       if (have) {
-        water_loop(p, toplevel);                            // while(move && interact);
+        water_loop(p, toplevel, resume);                    // while(move && interact);
+        resume = false;
         if (ab) return;
         if constexpr (P::READ_ONLY) {                       // scout: claim where a flood would act, then stop
           const int fx = (int)p.pos.x, fy = (int)p.pos.y;
@@ -905,6 +939,7 @@ struct Sim {
         p.spill = f.spill;
         p.volume = transfer / 0.015;
         toplevel = false;
+        susp_ok = false;                                   // nested particles run inside their parent: not resumable
         have = true;
         if (ab) return;
       } else {                                              // :266-276
@@ -933,7 +968,7 @@ struct Sim {
     p.surface = surface(p.ix, p.iy);
     p.contains = soils[p.surface].transports;
   }
-  SMX_D void wind_run(Wind& p) { wind_loop(p); }             // SoilMachine.cpp:305-306
+  SMX_D void wind_run(Wind& p, bool resume = false) { wind_loop(p, resume); }   // SoilMachine.cpp:305-306
 };
 
 }  // namespace smx

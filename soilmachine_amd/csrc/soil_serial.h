@@ -12,6 +12,8 @@ struct SerialPolicy {
   SMX_D void finish(const DevState& s) { s.ctr[C_LIVE_SECTIONS] = live; *s.free_count = nfree; }
 
   template <int N> struct Pre {};
+  SMX_D void save_blk(const Blk&) {}
+  SMX_D void load_blk(Blk&) {}
   SMX_D bool touch(const DevState&, size_t, size_t) { return true; }
   template <int N> SMX_D void prefetch(const DevState&, const size_t (&)[N], const size_t (&)[N], Pre<N>&) {}
   template <int N> SMX_D bool acquire_log(const DevState&, const size_t (&)[N], const Pre<N>&, const Sec (&)[N]) { return true; }

@@ -24,6 +24,10 @@
 //   * rand()       : spawn draws are the phase's stream at offset 2*(id + nested particles of lower ids); the
 //                    nested count of unfinished lower particles is speculated to be 0 and validated at every
 //                    boundary.
+//   * suspend      : a particle that cannot acquire the block of its next step (claimed by a lower pending
+//                    particle, or held by one that is still running) does not throw its work away: it keeps its
+//                    cells, checkpoints {particle, carried block, log cursor} and resumes at that very step in the
+//                    next round. Work is done once; a round only costs the distance the particles advance in it.
 // Progress: the lowest pending particle can only be stopped by higher particles, which yield to its claims;
 // the host falls back to the serial walker if the committed prefix stalls.
 #pragma once
@@ -34,10 +38,16 @@
 #define SMX_A_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define SMX_A_ADD(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
 #define SMX_A_MIN(p, v) smx::host_atomic_min((p), (v))
+#define SMX_A_MAX(p, v) smx::host_atomic_max((p), (v))
 namespace smx {
 inline uint32_t host_atomic_min(uint32_t* p, uint32_t v) {
   uint32_t o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
   while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return o;
+}
+inline uint32_t host_atomic_max(uint32_t* p, uint32_t v) {
+  uint32_t o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
   return o;
 }
 inline uint32_t host_atomic_cas(uint32_t* p, uint32_t expected, uint32_t desired) {
@@ -51,12 +61,13 @@ inline uint32_t host_atomic_cas(uint32_t* p, uint32_t expected, uint32_t desired
 #define SMX_A_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SMX_A_ADD(p, v) atomicAdd((p), (v))
 #define SMX_A_MIN(p, v) atomicMin((p), (v))
+#define SMX_A_MAX(p, v) atomicMax((p), (v))
 #define SMX_A_CAS(p, e, d) atomicCAS((p), (e), (d))
 #endif
 
 namespace smx {
 
-constexpr uint32_t ST_PENDING = 0, ST_DONE_NEW = 1, ST_DONE_OLD = 2, ST_COMMITTED = 3;
+constexpr uint32_t ST_PENDING = 0, ST_DONE_NEW = 1, ST_DONE_OLD = 2, ST_COMMITTED = 3, ST_SUSPENDED = 4;
 constexpr uint32_t POISON = 0xFFFFFFFEu;      // stamp of a cell released by a particle that aborted in this round
 constexpr uint32_t NOCLAIM = 0xFFFFFFFFu;
 constexpr uint32_t NODE_ENTRY = 0x80000000u;  // log entry describes pool node (cell & 0x7fffffff), not a cell
@@ -84,8 +95,15 @@ struct SpecPart {                             // one particle of the phase
   uint32_t deps[MAX_DEPS];
 };
 
+struct SpecCkpt {                             // checkpoint of a suspended particle (resumes at interact())
+  Water w; Wind d; Blk blk;
+  uint32_t nlog, nchunks, ndeps, dep_overflow, nalloc, nfree, nested_drawn, nnode;
+  long long live_delta;
+  unsigned long long ctr[SPEC_NCTR];
+};
+
 enum SpecCtrl { SC_NPENDING = 0, SC_BASE, SC_N, SC_NESTED_COMMITTED, SC_NODE_CURSOR, SC_NRECLAIM, SC_NFREE_START,
-                SC_ROUNDS, SC_ABORTS, SC_KILLS, SC_RECLAIM_LOST, SC_CHUNK_CURSOR, SC_SKIPPED, SC_EXECUTED, SC_COUNT = 16 };
+                SC_ROUNDS, SC_ABORTS, SC_KILLS, SC_RECLAIM_LOST, SC_CHUNK_CURSOR, SC_SKIPPED, SC_EXECUTED, SC_SUSPENDS, SC_ROUND_MAXSTEPS, SC_SUM_MAXSTEPS, SC_COUNT = 20 };
 
 struct SpecShared {
   uint32_t* stamp;
@@ -104,6 +122,8 @@ struct SpecShared {
   uint32_t reclaim_cap;
   uint32_t* scout_cells;    // [n][SCOUT_CAP] cells of the read-only scout run (predicted footprint)
   uint32_t* scout_len;      // [n]
+  SpecCkpt* ckpt;           // [n]
+  uint32_t mode;            // bit0: blocked particles sit the round out (select pass); bit1: suspend/resume
 };
 
 SMX_D SpecLog* spec_entry(const SpecShared& sh, uint32_t pid, uint32_t k) {
@@ -124,6 +144,8 @@ struct ScoutPolicy {
   size_t last = ~(size_t)0, last2 = ~(size_t)0;
   SMX_D ScoutPolicy(const SpecShared& sh_, uint32_t p) : sh(sh_), pid(p), out(sh_.scout_cells + (size_t)p * SCOUT_CAP) {}
   template <int N> struct Pre {};
+  SMX_D void save_blk(const Blk&) {}
+  SMX_D void load_blk(Blk&) {}
   SMX_D bool touch(const DevState&, size_t c, size_t = 0) {
     if (c != last && c != last2) { last2 = last; last = c; if (len < SCOUT_CAP) out[len++] = (uint32_t)c; }
     return true;
@@ -158,9 +180,30 @@ struct SpecPolicy {
   unsigned long long ctr[SPEC_NCTR];
   size_t last = ~(size_t)0;
 
-  SMX_D SpecPolicy(const SpecShared& sh_, uint32_t p) : sh(sh_), pid(p), me(p + 1), part(sh_.part + p) {
+  SMX_D SpecPolicy(const SpecShared& sh_, uint32_t p, bool resume = false) : sh(sh_), pid(p), me(p + 1), part(sh_.part + p) {
     nchunks = part->nchunks;
     for (int i = 0; i < SPEC_NCTR; i++) ctr[i] = 0;
+    if (resume) {                                           // continue the undo log etc. of the suspended attempt
+      const SpecCkpt& k = sh.ckpt[pid];
+      nlog = k.nlog; nchunks = k.nchunks; ndeps = k.ndeps; dep_overflow = k.dep_overflow; nalloc = k.nalloc; nfree = k.nfree;
+      nested_drawn = k.nested_drawn; nnode = k.nnode; live_delta = k.live_delta;
+      for (int i = 0; i < SPEC_NCTR; i++) ctr[i] = k.ctr[i];
+      if (nlog % LOG_CHUNK) chunk = sh.arena + (size_t)sh.chunk_tab[(size_t)pid * MAX_CHUNKS + nlog / LOG_CHUNK] * LOG_CHUNK;
+    }
+  }
+  SMX_D void save_blk(const Blk& b) { sh.ckpt[pid].blk = b; }
+  SMX_D void load_blk(Blk& b) { b = sh.ckpt[pid].blk; }
+  // the particle could not acquire the block of its next step: keep everything, continue next round
+  SMX_D void suspend(const DevState&) {
+    SpecCkpt& k = sh.ckpt[pid];
+    k.nlog = nlog; k.nchunks = nchunks; k.ndeps = ndeps; k.dep_overflow = dep_overflow; k.nalloc = nalloc; k.nfree = nfree;
+    k.nested_drawn = nested_drawn; k.nnode = nnode; k.live_delta = live_delta;
+    for (int i = 0; i < SPEC_NCTR; i++) k.ctr[i] = ctr[i];
+    part->nlog = nlog; part->nchunks = nchunks; part->ndeps = ndeps; part->dep_overflow = dep_overflow;
+    part->nalloc = nalloc; part->nfree = nfree; part->nnode = nnode; part->fail_cell = fail_cell; part->nested = 0;
+    part->aborted = 0; part->attempts++;
+    SMX_A_ADD(&sh.ctrl[SC_SUSPENDS], 1u);
+    SMX_A_STORE(&part->status, ST_SUSPENDED);
   }
 
   SpecLog* chunk = nullptr;                                 // arena chunk that receives the next log entries
@@ -208,7 +251,10 @@ struct SpecPolicy {
   template <int N> SMX_D void prefetch(const DevState& s, const size_t (&c)[N], const size_t (&f)[N], Pre<N>& p) {
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      p.v[i] = SMX_A_LOAD(&sh.stamp[c[i]]); p.cl[i] = SMX_A_LOAD(&sh.claim[c[i]]);
+      // PLAIN loads (L1-cacheable): claims do not change during the kernel; a stale stamp is harmless -- a cell
+      // somebody else took meanwhile makes our CAS fail, and a cell we own but whose cached stamp is older than
+      // our own CAS is recognised by the CAS returning `me`
+      p.v[i] = sh.stamp[c[i]]; p.cl[i] = sh.claim[c[i]];
       p.tr[i] = s.wtrack[f[i]]; p.wf[i] = s.windfreq[f[i]]; p.fl[i] = s.flags[c[i]];
     }
   }
@@ -239,10 +285,10 @@ struct SpecPolicy {
     if (takeover) {
       uint32_t stv[N];
 #pragma unroll
-      for (int i = 0; i < N; i++) stv[i] = ((takeover >> i) & 1) ? SMX_A_LOAD(&sh.part[p.v[i] - 1].status) : ST_COMMITTED;
+      for (int i = 0; i < N; i++) stv[i] = ((takeover >> i) & 1) ? sh.part[p.v[i] - 1].status : ST_COMMITTED;   // plain: finished states are final
 #pragma unroll
       for (int i = 0; i < N; i++) {
-        if (stv[i] == ST_PENDING || stv[i] == ST_DONE_NEW) { fail_cell = (uint32_t)c[i]; fail = true; }   // still running this round
+        if (stv[i] == ST_PENDING || stv[i] == ST_DONE_NEW || stv[i] == ST_SUSPENDED) { fail_cell = (uint32_t)c[i]; fail = true; }   // not finished before this round
         if (stv[i] == ST_DONE_OLD) depmask |= 1u << i;
       }
       if (fail) return false;
@@ -254,7 +300,8 @@ struct SpecPolicy {
       if ((need >> i) & 1) {
         const uint32_t old = SMX_A_CAS(&sh.stamp[c[i]], p.v[i], me);
         if (old == p.v[i]) got |= 1u << i;
-        else { fail_cell = (uint32_t)c[i]; ok = false; }    // somebody changed the stamp under us (rare): give up
+        else if (old != me) { fail_cell = (uint32_t)c[i]; ok = false; }   // somebody took it meanwhile: give up
+        // (old == me: the cached stamp was older than our own earlier acquisition -- already ours and logged)
       }
     }
 #pragma unroll
@@ -281,7 +328,7 @@ struct SpecPolicy {
       bool dep = false;
       if (v != 0) {                                         // last touched by a lower particle
         const uint32_t st = SMX_A_LOAD(&sh.part[v - 1].status);
-        if (st == ST_PENDING || st == ST_DONE_NEW) { fail_cell = (uint32_t)c; return false; }   // still running this round
+        if (st == ST_PENDING || st == ST_DONE_NEW || st == ST_SUSPENDED) { fail_cell = (uint32_t)c; return false; }   // not finished before this round
         dep = (st == ST_DONE_OLD);
       }
       if (SMX_A_LOAD(&sh.claim[c]) < pid) { fail_cell = (uint32_t)c; return false; }   // yield to a lower pending particle
@@ -348,6 +395,7 @@ struct SpecPolicy {
     part->ndeps = 0; part->dep_overflow = 0; part->nalloc = 0; part->nfree = 0; part->nested = 0;
     part->aborted = 1; part->attempts++;
     SMX_A_ADD(&sh.ctrl[SC_ABORTS], 1u);
+    SMX_A_STORE(&part->status, ST_PENDING);
   }
   SMX_D void finish_done(const DevState&) {
     part->nlog = nlog; part->nchunks = nchunks; part->ndeps = ndeps; part->dep_overflow = dep_overflow;
@@ -393,7 +441,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
     if (tid == 0) w.changed = 0;
     sync();
     for (uint32_t i = tid; i < cnt; i += nt) {             // dependencies (always lower ids)
-      if ((w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD) && !w.kl[i]) {
+      if ((w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED) && !w.kl[i]) {
         const SpecPart& q = sh.part[base + i];
         bool bad = false;
         for (uint32_t k = 0; k < q.ndeps; k++) { const uint32_t d = q.deps[k]; if (d >= base && w.kl[d - base]) { bad = true; break; } }
@@ -405,9 +453,9 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
       uint32_t nest = ctrl[SC_NESTED_COMMITTED];
       bool any = false;
       for (uint32_t i = 0; i < cnt; i++) {
-        if (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD) {
+        if (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED) {
           if (!w.kl[i] && ((w.dov[i] && any) || w.noff[i] != nest)) { w.kl[i] = 1; w.changed = 1; }
-          if (w.kl[i]) any = true; else nest += w.nested[i];
+          if (w.kl[i]) any = true; else nest += w.nested[i];   // (a suspended particle has spawned nothing yet)
         }
       }
     }
@@ -418,7 +466,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
   if (tid == 0) {
     uint32_t m = 0;
     for (uint32_t i = cnt; i-- > 0;) {
-      const bool done = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD);
+      const bool done = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED);   // holds cells + log
       if ((done && w.kl[i]) || (!done && w.ab[i])) w.list[m++] = (uint16_t)i;
     }
     w.nlist = m;
@@ -427,7 +475,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
   for (uint32_t j = 0; j < w.nlist; j++) {
     const uint32_t i = w.list[j], p = base + i;
     SpecPart& q = sh.part[p];
-    const bool done = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD);
+    const bool done = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED);
     const uint32_t nl = q.nlog;
     if (done) {                                            // killed: restore data and stamps
       // duplicate NODE entries must be unwound newest-first: thread 0 handles node entries, cells are unique
@@ -480,6 +528,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
     uint32_t np = 0, nest = ctrl[SC_NESTED_COMMITTED];
     for (uint32_t i = b; i < cnt; i++) {
       if (w.st[i] == ST_PENDING) { w.noff[i] = nest; sh.pending[np++] = base + i; }
+      else if (w.st[i] == ST_SUSPENDED) sh.pending[np++] = base + i;   // resumes with the offset it started with
       else nest += w.nested[i];
     }
     // particles beyond the window become eligible as the window slides: they keep noff from the last in-window state
@@ -489,6 +538,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
     ctrl[SC_BASE] = newbase;
     ctrl[SC_NPENDING] = np;
     ctrl[SC_ROUNDS]++;
+    ctrl[SC_SUM_MAXSTEPS] += ctrl[SC_ROUND_MAXSTEPS]; ctrl[SC_ROUND_MAXSTEPS] = 0;
   }
   sync();
   for (uint32_t i = tid; i < cnt; i += nt) {
@@ -502,7 +552,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
 SMX_D void spec_abandon(const DevState& s, const SpecShared& sh) {
   uint32_t* ctrl = sh.ctrl;
   const uint32_t n = ctrl[SC_N], base = ctrl[SC_BASE];
-  for (uint32_t p = base; p < n; p++) if (sh.part[p].status == ST_DONE_OLD || sh.part[p].status == ST_DONE_NEW) sh.part[p].kill = 1;
+  for (uint32_t p = base; p < n; p++) if (sh.part[p].status == ST_DONE_OLD || sh.part[p].status == ST_DONE_NEW || sh.part[p].status == ST_SUSPENDED) sh.part[p].kill = 1;
   for (uint32_t p = n; p-- > base;) {
     SpecPart& q = sh.part[p];
     if (q.kill) {
@@ -643,20 +693,33 @@ SMX_D void spec_scout_one(const DevState& s, const SoilP* soils, const SpecShare
 
 template <bool WIND>
 SMX_D void spec_exec_one(const DevState& s, const SoilP* soils, const SpecShared& sh, uint32_t pid) {
-  if (sh.part[pid].blocked) { SMX_A_ADD(&sh.ctrl[SC_SKIPPED], 1u); return; }
+  if ((sh.mode & 1u) && sh.part[pid].blocked) { SMX_A_ADD(&sh.ctrl[SC_SKIPPED], 1u); return; }
   SMX_A_ADD(&sh.ctrl[SC_EXECUTED], 1u);
-  SpecPolicy pol(sh, pid);
+  const bool resume = sh.part[pid].status == ST_SUSPENDED;
+  SpecPolicy pol(sh, pid, resume);
   Sim<SpecPolicy> sim(s, soils, pol);
-  int d1, d2;
-  pol.spawn_draws(d1, d2);                    // 1st draw -> y, 2nd -> x (water.h:13, wind.h:15 under g++)
-  const int ry = d1 % s.dimy, rx = d2 % s.dimx;
+  sim.susp_ok = (sh.mode & 2u) != 0;
   if constexpr (WIND) {
-    Wind p; sim.wind_init(p, rx, ry);
-    if (!sim.ab) sim.wind_run(p);
+    Wind p;
+    if (resume) p = sh.ckpt[pid].d;
+    else {
+      int d1, d2; pol.spawn_draws(d1, d2);                  // 1st draw -> y, 2nd -> x (wind.h:15 under g++)
+      sim.wind_init(p, d2 % s.dimx, d1 % s.dimy);
+    }
+    if (!sim.ab) sim.wind_run(p, resume);
+    SMX_A_MAX(&sh.ctrl[SC_ROUND_MAXSTEPS], (uint32_t)sim.n_steps_wind);
+    if (sim.susp && !pol.overflow) { sim.flush_counters(); sh.ckpt[pid].d = p; pol.suspend(s); return; }
   } else {
     Frame st[MAX_FRAMES]; int depth = 0;
-    Water p; sim.water_init(p, rx, ry);
-    if (!sim.ab) sim.water_drive(p, true, true, st, depth);
+    Water p;
+    if (resume) p = sh.ckpt[pid].w;
+    else {
+      int d1, d2; pol.spawn_draws(d1, d2);                  // water.h:13
+      sim.water_init(p, d2 % s.dimx, d1 % s.dimy);
+    }
+    if (!sim.ab) sim.water_drive(p, true, true, st, depth, resume);
+    SMX_A_MAX(&sh.ctrl[SC_ROUND_MAXSTEPS], (uint32_t)sim.n_steps_w_all);
+    if (sim.susp && !pol.overflow) { sim.flush_counters(); sh.ckpt[pid].w = p; pol.suspend(s); return; }
   }
   if (sim.ab || pol.overflow) { pol.self_rollback(s); return; }
   sim.flush_counters();

@@ -439,7 +439,7 @@ void smx_destroy(smx_ctx* ctx) {
     hipFree(sh.stamp); hipFree(sh.claim); hipFree(sh.ctrl); hipFree(sh.reclaim); hipHostFree(ctx->h_ctrl);
     if (ctx->spec_cap) {
       hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
-      hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len);
+      hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len); hipFree(sh.ckpt);
     }
   }
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -656,7 +656,7 @@ static int spec_alloc(smx_ctx* ctx, uint32_t n) {
   SpecShared& sh = ctx->sh;
   if (ctx->spec_cap) {
     hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
-    hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len);
+    hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len); hipFree(sh.ckpt);
   } else {
     HIPCHK(hipMalloc(&sh.stamp, ctx->ncells * 4)); HIPCHK(hipMalloc(&sh.claim, ctx->ncells * 4));
     HIPCHK(hipMalloc(&sh.ctrl, SC_COUNT * 4));
@@ -672,6 +672,8 @@ static int spec_alloc(smx_ctx* ctx, uint32_t n) {
   HIPCHK(hipMalloc(&sh.pending, (size_t)cap * 4));
   sh.ndraws = 2 * cap + 2 * SPEC_MAXNEST; HIPCHK(hipMalloc(&sh.draws, (size_t)sh.ndraws * 4));
   HIPCHK(hipMalloc(&sh.scout_cells, (size_t)cap * SCOUT_CAP * 4)); HIPCHK(hipMalloc(&sh.scout_len, (size_t)cap * 4));
+  HIPCHK(hipMalloc(&sh.ckpt, (size_t)cap * sizeof(SpecCkpt)));
+  { const char* e = getenv("SMX_SPEC_MODE"); sh.mode = e ? (uint32_t)atoi(e) : 3u; }
   ctx->spec_cap = cap;
   return 0;
 }
@@ -692,7 +694,7 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
   for (int round = 0;; round++) {
     HIPCHK(hipMemsetAsync(sh.claim, 0xFF, ctx->ncells * 4, st));
     hipLaunchKernelGGL(k_spec_claim, dim3(np), dim3(64), 0, st, sh);
-    hipLaunchKernelGGL(k_spec_select, dim3(np), dim3(64), 0, st, sh);
+    if (sh.mode & 1u) hipLaunchKernelGGL(k_spec_select, dim3(np), dim3(64), 0, st, sh);
     {
       PhaseTimer tk(ctx, wind ? 5 : 4);
       if (wind) hipLaunchKernelGGL(k_spec_exec<true>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);

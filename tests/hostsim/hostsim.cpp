@@ -206,6 +206,7 @@ struct SpecBuffers {
   std::vector<uint32_t> stamp, claim, chunk_tab, alloc_log, free_log, pending, ctrl, reclaim, scout_cells, scout_len;
   std::vector<SpecPart> part;
   std::vector<SpecLog> arena;
+  std::vector<SpecCkpt> ckpt;
   std::vector<uint32_t> draws;
   SpecShared sh;
 };
@@ -224,6 +225,7 @@ static void spec_setup(hs_ctx* c, SpecBuffers& b, uint32_t n) {
   sh.pending = b.pending.data(); sh.ctrl = b.ctrl.data(); sh.draws = b.draws.data(); sh.ndraws = (uint32_t)b.draws.size();
   sh.reclaim = b.reclaim.data(); sh.reclaim_cap = (uint32_t)b.reclaim.size();
   sh.scout_cells = b.scout_cells.data(); sh.scout_len = b.scout_len.data();
+  b.ckpt.resize(n); sh.ckpt = b.ckpt.data(); sh.mode = 2u;
 }
 template <class F> static void parallel_for(uint32_t n, int nthreads, F f, unsigned shuffle_seed) {
   std::vector<uint32_t> order(n);
@@ -243,19 +245,21 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
   const SpecShared& sh = b.sh;
   spec_begin(s, sh, n);
   uint32_t last_base = 0, stall = 0; int fell_back = 0;
+  b.sh.mode = (uint32_t)(scout >> 4);                       // scout argument: bit0 = trajectory scout, bits 4.. = engine mode
+  scout &= 1;
   if (scout) parallel_for(n, nthreads, [&](uint32_t i) { spec_scout_one<WIND>(s, s.soils, sh, i); }, shuffle ? shuffle + 1 : 0);
   while (true) {
     std::fill(b.claim.begin(), b.claim.end(), NOCLAIM);
     const uint32_t np = sh.ctrl[SC_NPENDING];
     parallel_for(np, nthreads, [&](uint32_t i) { spec_claim_one(sh, sh.pending[i], 0u, 1u); }, shuffle ? shuffle + 1 : 0);
-    parallel_for(np, nthreads, [&](uint32_t i) { const uint32_t pid = sh.pending[i]; sh.part[pid].blocked = spec_blocked(sh, pid, 0u, 1u) ? 1u : 0u; }, 0);
+    if (sh.mode & 1u) parallel_for(np, nthreads, [&](uint32_t i) { const uint32_t pid = sh.pending[i]; sh.part[pid].blocked = spec_blocked(sh, pid, 0u, 1u) ? 1u : 0u; }, 0);
     parallel_for(np, nthreads, [&](uint32_t i) { spec_exec_one<WIND>(s, s.soils, sh, sh.pending[i]); }, shuffle ? shuffle + 2 + sh.ctrl[SC_ROUNDS] : 0);
     { static SpecWork* w = new SpecWork(); spec_boundary_team(s, sh, *w, 0u, 1u, []() {}); }
     if (sh.ctrl[SC_NPENDING] == 0 && sh.ctrl[SC_BASE] == n) break;
     if (sh.ctrl[SC_BASE] == last_base) stall++; else { stall = 0; last_base = sh.ctrl[SC_BASE]; }
     if (stall >= 8 || sh.ctrl[SC_NESTED_COMMITTED] > SPEC_MAXNEST - 64) { fell_back = 1; break; }
   }
-  if (stats) { stats[0] = sh.ctrl[SC_ROUNDS]; stats[1] = sh.ctrl[SC_ABORTS]; stats[2] = sh.ctrl[SC_KILLS]; stats[3] = (uint32_t)fell_back; stats[4] = sh.ctrl[SC_EXECUTED]; }
+  if (stats) { stats[0] = sh.ctrl[SC_ROUNDS]; stats[1] = sh.ctrl[SC_ABORTS]; stats[2] = sh.ctrl[SC_KILLS]; stats[3] = (uint32_t)fell_back; stats[4] = sh.ctrl[SC_EXECUTED]; stats[5] = sh.ctrl[SC_SUM_MAXSTEPS]; }
   if (fell_back) {
     spec_abandon(s, sh);
     const uint32_t base = sh.ctrl[SC_BASE];
@@ -271,8 +275,8 @@ int hs_spec_water(hs_ctx* c, int n, int nthreads, int scout, unsigned shuffle, u
 int hs_spec_wind(hs_ctx* c, int n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) { return spec_phase<true>(c, (uint32_t)n, nthreads, scout, shuffle, stats); }
 void hs_spec_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int nthreads, int scout, unsigned shuffle, uint32_t* stats) {
   uint32_t st[8] = {0};
-  if (dowater) { hs_spec_water(c, nwater, nthreads, scout, shuffle, st); if (stats) for (int i = 0; i < 5; i++) stats[i] += st[i]; hs_grid(c); }
-  if (dowind) { hs_spec_wind(c, nwind, nthreads, 0, shuffle, st); if (stats) for (int i = 0; i < 5; i++) stats[5 + i] += st[i]; }
+  if (dowater) { hs_spec_water(c, nwater, nthreads, scout, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[i] += st[i]; hs_grid(c); }
+  if (dowind) { hs_spec_wind(c, nwind, nthreads, scout & ~1, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[6 + i] += st[i]; }
   if (dowater) hs_freq(c);
 }
 }  // extern "C"

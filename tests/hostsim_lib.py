@@ -98,9 +98,10 @@ class HostSim:
     def tick(self, nwater, nwind, dowater=True, dowind=True):
         self.L.hs_tick(self.h, nwater, nwind, int(dowater), int(dowind))
 
-    def spec_tick(self, nwater, nwind, dowater=True, dowind=True, nthreads=8, scout=1, shuffle=0):
+    def spec_tick(self, nwater, nwind, dowater=True, dowind=True, nthreads=8, scout=1 | (3 << 4), shuffle=0):
         """One tick with the speculative engine emulated by `nthreads` host threads.
-        Returns stats: [rounds, aborts, kills, fell_back, reclaim_lost] for water then wind."""
-        st = np.zeros(10, np.uint32)
+        `scout`: bit0 = read-only trajectory scout, bits 4.. = engine mode (1 blocked-filter, 2 suspend/resume).
+        Returns stats: [rounds, aborts, kills, fell_back, executed, critical-path steps] for water then wind."""
+        st = np.zeros(12, np.uint32)
         self.L.hs_spec_tick(self.h, nwater, nwind, int(dowater), int(dowind), nthreads, scout, shuffle, _p(st))
         return st

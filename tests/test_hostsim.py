@@ -52,3 +52,45 @@ def test_device_sources_reproduce_reference_digests(case):
     oc, hc = o.counters(), hs.counters()
     for k in ("steps_water_all", "nested_particles", "floods", "cascade_calls", "cascade_transfers", "wcascade_calls"):
         assert oc[k] == hc[k], k
+
+
+# ---------------------------------------------------------------- speculative engine (threads emulate the waves)
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", ["default64", "rgps64", "rocksand48x80"])
+def test_speculative_protocol_is_exact(case, mode):
+    """stamps / claims / forwarding / kill closure / rollback / suspend-resume: whatever interleaving the 8 threads
+    produce and whichever engine mode is on, the state after every tick equals the reference's."""
+    soil, seed, dowind, ticks = SNAP_CASES[case]
+    cfg = load_cfg(soil)
+    d = DIG[case]
+    dimx, dimy = case_dims(d, cfg)
+    o = Oracle(cfg, dimx, dimy, seed=seed)
+    o.initialize()
+    hs = HostSim(cfg, dimx, dimy, seed=seed)
+    hs.load(o.snapshot())
+    t = 0
+    for tk in ticks:
+        while t < tk:
+            hs.spec_tick(d["nwater"], d["nwind"], True, dowind, nthreads=8, scout=1 | (mode << 4), shuffle=11 + t)
+            t += 1
+        bad = compare(hs.snapshot(), golden_snapshot(case, tk))
+        assert not bad, f"{case} mode {mode} tick {tk}: {bad}"
+    c = hs.counters()
+    assert c["steps_water_top"] == d["steps_water_top"] and c["steps_wind"] == d["steps_wind"]
+
+
+def test_speculative_protocol_larger_map_has_parallelism():
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 512
+    o = Oracle(cfg, n, n, seed=0)
+    o.initialize()
+    hs = HostSim(cfg, n, n, seed=0)
+    hs.load(o.snapshot())
+    st = hs.spec_tick(cfg.NWATER, cfg.NWIND, nthreads=8)
+    o.tick(cfg.NWATER, cfg.NWIND, True, True)
+    assert not compare(hs.snapshot(), o.snapshot())
+    rounds_w, executed_w, fell_back = int(st[0]), int(st[4]), int(st[3])
+    assert fell_back == 0 and rounds_w < cfg.NWATER // 4          # far fewer rounds than particles
+    oc, hc = o.counters(), hs.counters()
+    for k in ("steps_water_all", "steps_wind", "nested_particles", "cascade_transfers", "rand_calls"):
+        assert oc[k] == hc[k], k
