@@ -120,6 +120,8 @@ int smx_remove(smx_ctx* ctx, int32_t x, int32_t y, double h, double* remainder);
 int smx_particle_cascade(smx_ctx* ctx, float px, float py, int32_t transferloop);       /* particle.h:24  */
 int smx_water_cascade(smx_ctx* ctx, int32_t x, int32_t y, int32_t spill);               /* water.h:151    */
 int smx_seep(smx_ctx* ctx, int32_t x, int32_t y);                                       /* water.h:285    */
+int smx_top(smx_ctx* ctx, int32_t x, int32_t y, uint32_t* type, double* size, double* floor, double* sat,
+            int32_t* empty);                                                            /* Layermap::top layermap.h:150 (a copy) */
 int smx_normals(smx_ctx* ctx, float* out3);             /* Layermap::normal(ivec2) for every cell, xyz interleaved (layermap.h:341) */
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out);      /* Layermap::height(vec2) (layermap.h:427) */
 

@@ -129,6 +129,20 @@ template <typename T, typename U> tvec4<T> mix(const tvec4<T>& x, const tvec4<T>
   return tvec4<T>(tvec4<U>(x) * (static_cast<U>(1) - a) + tvec4<U>(y) * a);
 }
 
+// ---- mat4: only so that render-side host code (scene.h, the pipeline lambda of SoilMachine.cpp) compiles ----
+struct mat4 {
+  float m[16];
+  mat4() { for (int i = 0; i < 16; i++) m[i] = 0.f; }
+  mat4(float d) { for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? d : 0.f; }
+  mat4(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8, float a9, float a10,
+       float a11, float a12, float a13, float a14, float a15) { float t[16] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15}; for (int i = 0; i < 16; i++) m[i] = t[i]; }
+};
+inline mat4 operator*(const mat4& a, const mat4& b) {
+  mat4 r;
+  for (int c = 0; c < 4; c++) for (int rr = 0; rr < 4; rr++) { float s = 0; for (int k = 0; k < 4; k++) s += a.m[k * 4 + rr] * b.m[c * 4 + k]; r.m[c * 4 + rr] = s; }
+  return r;
+}
+
 template <typename T> bvec2 greaterThanEqual(const tvec2<T>& a, const tvec2<T>& b) { return bvec2(a.x >= b.x, a.y >= b.y); }
 template <typename T> bvec2 lessThan(const tvec2<T>& a, const tvec2<T>& b) { return bvec2(a.x < b.x, a.y < b.y); }
 inline bool all(const bvec2& v) { return v.x && v.y; }

@@ -1,0 +1,260 @@
+// compat/source/layermap.h -- drop-in for the reference's source/layermap.h (layermap.h:1-613).
+//
+// Same public surface (`sec`, `secpool`, `class Layermap` with dim / pool / section, height x2, normal x4, surface,
+// add, remove, top, meshpool, update x2, slice, initialize, both constructors), but the run-length sediment
+// columns live in HBM behind the C-ABI of include/soilmx.h: `Layermap` owns an `smx_ctx`. Host-side point queries
+// (SoilMachine.cpp:238 calls map.height() 163 840 times at start-up) are served from a host mirror of the surface
+// plane that is refreshed after device work, never by a per-call device round trip.
+//
+// The unmodified SoilMachine.cpp includes this file through the quoted path "source/layermap.h"
+// (INTEGRATION.md shows the include-path arrangement); it reads the host's globals SIZEX, SIZEY, SCALE, SLICE,
+// NWIND, NWATER, SEED and the POOLSIZE macro exactly like the reference header does.
+#pragma once
+#include <soilmx.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <iostream>
+#include <string>
+#include <vector>
+
+using namespace glm;
+using namespace std;
+
+#include "surface.h"
+
+struct sec {                                  // layermap.h:37-62 (host-side value object; the device owns the real lists)
+  sec* next = NULL;
+  sec* prev = NULL;
+  SurfType type = 0;
+  double size = 0.0f;
+  double floor = 0.0f;
+  double saturation = 0.0f;
+  sec() {}
+  sec(double s, SurfType t) { size = s; type = t; }
+  void reset() { next = NULL; prev = NULL; type = 0; size = 0.0f; floor = 0.0f; saturation = 0.0f; }
+};
+
+class Layermap;
+
+class secpool {                               // layermap.h:64-119: capacity POOLSIZE, `free.size()` for the GUI (SoilMachine.cpp:116)
+ public:
+  int size = 0;
+  sec* start = NULL;
+  struct freelist_view {
+    smx_ctx** ctx = nullptr;
+    size_t size() const {
+      smx_counters c;
+      if (!ctx || !*ctx || smx_get_counters(*ctx, &c) != 0) return 0;
+      return (size_t)c.pool_free;
+    }
+    bool empty() const { return size() == 0; }
+  } free;
+  secpool() {}
+  void reserve(const int N) { size = N; }
+  template <typename... Args>
+  sec* get(Args&&... args) { return new sec(std::forward<Args>(args)...); }   // a value handed to Layermap::add
+  void unget(sec* E) { delete E; }
+  void reset() {}
+};
+
+class Layermap {
+ private:
+  smx_ctx* ctx = nullptr;
+  std::vector<double> hmirror;                // Layermap::height(ivec2) for every cell (cell order x*dim.y+y)
+  std::vector<uint32_t> smirror;              // Layermap::surface(ivec2)
+  bool dirty = true;
+  sec topview;                                // what top() hands out
+
+  void check(int rc, const char* what) {
+    if (rc != 0) { cout << "soilmx: " << what << " failed: " << (ctx ? smx_last_error(ctx) : "no context") << endl; exit(1); }
+  }
+  void refresh() {
+    if (!dirty) return;
+    flush();
+    hmirror.resize((size_t)dim.x * dim.y); smirror.resize((size_t)dim.x * dim.y);
+    check(smx_read_heights(ctx, hmirror.data()), "smx_read_heights");
+    check(smx_read_surface(ctx, smirror.data()), "smx_read_surface");
+    dirty = false;
+  }
+
+ public:
+  ivec2 dim;
+  secpool pool;
+  uint* section = NULL;
+
+  // ---- deferred particle batches: the host's per-particle calls only count; the device runs the whole batch
+  //      in reference order when the next phase starts (INTEGRATION.md "How the unmodified loop batches")
+  int pending_water = 0, pending_wind = 0;
+  smx_ctx* handle() { return ctx; }
+  void touch() { dirty = true; }
+  void flush_water() {
+    if (pending_water) { check(smx_tick_water(ctx, pending_water), "smx_tick_water"); pending_water = 0; dirty = true; }
+  }
+  void flush_wind() {
+    if (pending_wind) { check(smx_tick_wind(ctx, pending_wind), "smx_tick_wind"); pending_wind = 0; dirty = true; }
+  }
+  void flush() { flush_water(); flush_wind(); }
+  void upload_tables() {                      // soils[] and SCALE are live-editable from the GUI (SoilMachine.cpp:118,167-186)
+    std::vector<smx_soil> t(soils.size());
+    for (size_t i = 0; i < soils.size(); i++) {
+      const SurfParam& p = soils[i];
+      t[i] = smx_soil{(uint32_t)p.transports, (uint32_t)p.erodes, (uint32_t)p.cascades, (uint32_t)p.abrades, p.density, p.porosity,
+                      p.solubility, p.equrate, p.friction, p.erosionrate, p.maxdiff, p.settling, p.suspension, p.abrasion};
+    }
+    check(smx_set_soils(ctx, t.data(), (int32_t)t.size()), "smx_set_soils");
+    check(smx_set_scale(ctx, SCALE), "smx_set_scale");
+  }
+
+  // ---- queries
+  double height(ivec2 pos) { refresh(); return hmirror[(size_t)pos.x * dim.y + pos.y]; }          // layermap.h:422-425
+  double height(vec2 pos) {                                                                         // layermap.h:427-439
+    double h = 0.0f;
+    ivec2 p = floor(pos);
+    vec2 w = fract(pos);
+    h += (1.0 - w.x) * (1.0 - w.y) * height(p);
+    h += (1.0 - w.x) * w.y * height(p + ivec2(1, 0));
+    h += w.x * (1.0 - w.y) * height(p + ivec2(0, 1));
+    h += w.x * w.y * height(p + ivec2(1, 1));
+    return h;
+  }
+  SurfType surface(ivec2 pos) { refresh(); return smirror[(size_t)pos.x * dim.y + pos.y]; }        // layermap.h:417-420
+  vec3 normal(ivec2 pos) {                                                                          // layermap.h:341-377
+    vec3 n = vec3(0);
+    vec3 p = vec3(pos.x, SCALE * height(pos), pos.y);
+    int k = 0;
+    if (pos.x > 0 && pos.y > 0) {
+      vec3 b = vec3(pos.x - 1, SCALE * height(pos - ivec2(1, 0)), pos.y);
+      vec3 c = vec3(pos.x, SCALE * height(pos - ivec2(0, 1)), pos.y - 1);
+      n += cross(c - p, b - p); k++;
+    }
+    if (pos.x > 0 && pos.y < dim.y - 1) {
+      vec3 b = vec3(pos.x - 1, SCALE * height(pos - ivec2(1, 0)), pos.y);
+      vec3 c = vec3(pos.x, SCALE * height(pos + ivec2(0, 1)), pos.y + 1);
+      n -= cross(c - p, b - p); k++;
+    }
+    if (pos.x < dim.x - 1 && pos.y > 0) {
+      vec3 b = vec3(pos.x + 1, SCALE * height(pos + ivec2(1, 0)), pos.y);
+      vec3 c = vec3(pos.x, SCALE * height(pos - ivec2(0, 1)), pos.y - 1);
+      n -= cross(c - p, b - p); k++;
+    }
+    if (pos.x < dim.x - 1 && pos.y < dim.y - 1) {
+      vec3 b = vec3(pos.x + 1, SCALE * height(pos + ivec2(1, 0)), pos.y);
+      vec3 c = vec3(pos.x, SCALE * height(pos + ivec2(0, 1)), pos.y + 1);
+      n += cross(c - p, b - p); k++;
+    }
+    return normalize(n / (float)k);
+  }
+  vec3 normal(vec2 pos) {                                                                           // layermap.h:379-392
+    vec3 n = vec3(0);
+    ivec2 p = floor(pos);
+    vec2 w = fract(pos);
+    n += (1.0f - w.x) * (1.0f - w.y) * normal(p);
+    n += (1.0f - w.x) * w.y * normal(p + ivec2(1, 0));
+    n += w.x * (1.0f - w.y) * normal(p + ivec2(0, 1));
+    n += w.x * w.y * normal(p + ivec2(1, 1));
+    return n;
+  }
+  vec3 normal(ivec2 pos, Vertexpool<Vertex>&) { return normal(pos); }                               // layermap.h:394-398
+  vec3 normal(vec2 pos, Vertexpool<Vertex>&) { return normal(pos); }                                // layermap.h:400-413
+
+  // ---- modifiers (point operations on the device; host code outside the tick loop)
+  void add(ivec2 pos, sec* E) {                                                                     // layermap.h:230-307
+    if (E == NULL) return;
+    flush();
+    check(smx_add(ctx, pos.x, pos.y, E->size, (uint32_t)E->type), "smx_add");
+    pool.unget(E);
+    dirty = true;
+  }
+  double remove(ivec2 pos, double h) {                                                              // layermap.h:310-339
+    flush();
+    double rem = 0.0;
+    check(smx_remove(ctx, pos.x, pos.y, h, &rem), "smx_remove");
+    dirty = true;
+    return rem;
+  }
+  sec* top(ivec2 pos) {                                                                             // layermap.h:150-152 (a copy, not a list node)
+    flush();
+    uint32_t ty = 0; int32_t empty = 0;
+    check(smx_top(ctx, pos.x, pos.y, &ty, &topview.size, &topview.floor, &topview.saturation, &empty), "smx_top");
+    if (empty) return NULL;
+    topview.type = ty;
+    return &topview;
+  }
+
+  // ---- meshing / visualisation (render side): one whole-map pass from the device planes
+  void meshpool(Vertexpool<Vertex>& vertexpool) {                                                   // layermap.h:443-473
+    if (section != NULL) { vertexpool.unsection(section); vertexpool.indices.clear(); }
+    section = vertexpool.section(dim.x * dim.y, 0, glm::vec3(0));
+    update(vertexpool);
+    for (int i = 0; i < dim.x - 1; i++)
+      for (int j = 0; j < dim.y - 1; j++) {
+        vertexpool.indices.push_back(i * dim.y + j);
+        vertexpool.indices.push_back(i * dim.y + (j + 1));
+        vertexpool.indices.push_back((i + 1) * dim.y + j);
+        vertexpool.indices.push_back((i + 1) * dim.y + j);
+        vertexpool.indices.push_back(i * dim.y + (j + 1));
+        vertexpool.indices.push_back((i + 1) * dim.y + (j + 1));
+      }
+    vertexpool.resize(section, vertexpool.indices.size());
+    vertexpool.index();
+    vertexpool.update();
+  }
+  // the visible vertex of a column: the top section (the SLICE cut of layermap.h:477-510 would need the buried
+  // sections; with the default SLICE = 2*SCALE nothing is cut)
+  void update(ivec2 p, Vertexpool<Vertex>& vertexpool) {                                            // layermap.h:475-549
+    if (section == NULL) return;
+    refresh();
+    const size_t c = (size_t)p.x * dim.y + p.y;
+    const uint32_t ty = smirror[c];
+    if (hmirror[c] == 0.0 && ty == 0) vertexpool.fill(section, (int)c, vec3(p.x, 0, p.y), vec3(0, 1, 0), soils[0].color, 0);
+    else vertexpool.fill(section, (int)c, vec3(p.x, SCALE * hmirror[c], p.y), normal(p), soils[ty].color, (int)ty);
+  }
+  void update(Vertexpool<Vertex>& vertexpool) {                                                     // layermap.h:551-555
+    if (section == NULL) return;
+    refresh();
+    std::vector<float> nrm((size_t)dim.x * dim.y * 3);
+    check(smx_normals(ctx, nrm.data()), "smx_normals");
+    for (int i = 0; i < dim.x; i++)
+      for (int j = 0; j < dim.y; j++) {
+        const size_t c = (size_t)i * dim.y + j;
+        const uint32_t ty = smirror[c];
+        if (hmirror[c] == 0.0 && ty == 0) vertexpool.fill(section, (int)c, vec3(i, 0, j), vec3(0, 1, 0), soils[0].color, 0);
+        else vertexpool.fill(section, (int)c, vec3(i, SCALE * hmirror[c], j), vec3(nrm[3 * c], nrm[3 * c + 1], nrm[3 * c + 2]), soils[ty].color, (int)ty);
+      }
+  }
+  void slice(Vertexpool<Vertex>& vertexpool, double = 0) { update(vertexpool); }                    // layermap.h:557-613 (no cut)
+
+  void initialize(int SEED, ivec2 _dim) {                                                           // layermap.h:163-216
+    dim = _dim;
+    std::vector<smx_layer> L(layers.size());
+    for (size_t l = 0; l < layers.size(); l++)
+      L[l] = smx_layer{(uint32_t)layers[l].type, layers[l].min, layers[l].bias, layers[l].scale, layers[l].octaves,
+                       layers[l].lacunarity, layers[l].gain, layers[l].frequency};
+    check(smx_initialize(ctx, SEED, L.data(), (int32_t)L.size()), "smx_initialize");
+    pending_water = pending_wind = 0;
+    dirty = true;
+  }
+
+  Layermap(int SEED, ivec2 _dim) {                                                                  // layermap.h:219-222
+    pool.reserve(POOLSIZE);
+    pool.free.ctx = &ctx;
+    smx_config cfg;
+    cfg.dimx = _dim.x; cfg.dimy = _dim.y; cfg.scale = SCALE; cfg.device = 0; cfg.pool_capacity = (uint64_t)POOLSIZE;
+    const char* e = getenv("SMX_ENGINE");
+    cfg.engine = (e && std::string(e) == "serial") ? SMX_ENGINE_SERIAL : SMX_ENGINE_SPECULATIVE;
+    cfg.reserved = 0;
+    dim = _dim;
+    int rc = smx_create(&cfg, &ctx);
+    if (rc != 0) { cout << "soilmx: smx_create failed: " << (ctx ? smx_last_error(ctx) : "") << endl; exit(1); }
+    upload_tables();
+    check(smx_srand(ctx, (uint32_t)SEED), "smx_srand");        // the host has just called srand(SEED) (SoilMachine.cpp:41)
+    initialize(SEED, _dim);
+  }
+  Layermap(int SEED, ivec2 _dim, Vertexpool<Vertex>& vertexpool) : Layermap(SEED, _dim) { meshpool(vertexpool); }   // :224-226
+  ~Layermap() { if (ctx) smx_destroy(ctx); }
+  Layermap(const Layermap&) = delete;
+  Layermap& operator=(const Layermap&) = delete;
+};

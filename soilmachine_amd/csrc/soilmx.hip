@@ -813,6 +813,20 @@ int smx_seep(smx_ctx* ctx, int32_t x, int32_t y) {
   PointOp o{}; o.op = 4; o.x = x; o.y = y; return point_op(ctx, o, nullptr);
 }
 
+int smx_top(smx_ctx* ctx, int32_t x, int32_t y, uint32_t* type, double* size, double* floor, double* sat, int32_t* empty) {
+  if (!inb(ctx, x, y)) return -2;
+  Sec r;
+  HIPCHK(hipMemcpyAsync(&r, ctx->d.cells + ((size_t)x * ctx->cfg.dimy + y), sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const bool e = r.type == EMPTY;
+  if (empty) *empty = e ? 1 : 0;
+  if (type) *type = e ? 0u : r.type;
+  if (size) *size = r.size;
+  if (floor) *floor = r.floor;
+  if (sat) *sat = r.sat;
+  return 0;
+}
+
 // ---------------- observability ----------------
 int smx_get_counters(smx_ctx* ctx, smx_counters* out) {
   unsigned long long c[C_COUNT];
