@@ -88,16 +88,10 @@ def main():
     ap.add_argument("--cpu-ticks", type=int, default=1)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    from soilmachine_amd import distrib
+    rank, local_rank, world = distrib.env_rank()
+    dist = distrib.init(world, local_rank, use_cuda=torch.cuda.is_available())
 
     from soilmachine_amd import capi
     from soilmachine_amd.machine import SoilMachine
@@ -109,7 +103,7 @@ def main():
     n = args.size
     engine = {"auto": capi.ENGINE_SPECULATIVE, "serial": capi.ENGINE_SERIAL, "spec": capi.ENGINE_SPECULATIVE}[args.engine]
     pool = 3 * n * n
-    seed = rank                       # replicas: independent worlds, SEED = rank (rank 0 == BASELINE's SEED 0)
+    seed = distrib.replica_seed(rank)   # replicas: independent worlds, SEED = rank (rank 0 == BASELINE's SEED 0)
     sm = SoilMachine(cfg, n, seed=seed, nwater=nwater, nwind=nwind, pool=pool, device=local_rank, engine=engine)
     m = sm.map
 
@@ -134,14 +128,8 @@ def main():
     steps_w = c1["steps_water_all"] - c0["steps_water_all"]
     steps_d = c1["steps_wind"] - c0["steps_wind"]
     steps = steps_w + steps_d
-    tmax, total_steps = dt, steps
-    if dist is not None:
-        dev = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ss = torch.tensor([float(steps)], dtype=torch.float64, device=dev)
-        dist.all_reduce(ss, op=dist.ReduceOp.SUM)
-        tmax, total_steps = float(tt.item()), float(ss.item())
+    dev = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
+    tmax, total_steps = distrib.aggregate(dist, dt, steps, dev)
 
     if rank == 0:
         # dominant kernel = the particle kernel with the largest summed HIP-event time (every launch is bracketed
@@ -154,8 +142,15 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, nbytes, kname = kernels[dom]
         ach = (nbytes / max(launches, 1)) / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None                                        # HBM bytes per launch from the PMC passes (profiles/r01_pmc.json)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if pmc.get("workload_size") == n and kname in pmc.get("kernels", {}):
+                traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_ms": ms / max(launches, 1), "launches": launches,
                     "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
                     "note": "exact engine: the particle kernels are instruction-issue / dependent-latency bound, "

@@ -76,7 +76,6 @@ constexpr int MAX_CHUNKS = 1024;              // chunks per particle (524288 tou
 constexpr int MAX_DEPS = 28;
 constexpr int MAX_NODELOG = 2048;             // node allocations / frees per particle attempt
 constexpr int SPEC_NCTR = 9;
-constexpr uint32_t SCOUT_CAP = 16384;         // cells one scouted footprint can hold (longer ones are truncated)
 
 struct alignas(64) SpecLog {                  // undo record of one touched cell (or one modified pool node)
   uint32_t cell, prev;                        // cell index, stamp value it replaced
@@ -120,7 +119,8 @@ struct SpecShared {
   uint32_t ndraws;
   uint32_t* reclaim;        // pool nodes that return to the free stack at phase end
   uint32_t reclaim_cap;
-  uint32_t* scout_cells;    // [n][SCOUT_CAP] cells of the read-only scout run (predicted footprint)
+  uint32_t* scout_cells;    // [n][scout_cap] cells of the read-only scout run (predicted footprint)
+  uint32_t scout_cap;       // cells one scouted footprint can hold (longer ones are truncated)
   uint32_t* scout_len;      // [n]
   SpecCkpt* ckpt;           // [n]
   uint32_t mode;            // bit0: blocked particles sit the round out (select pass); bit1: suspend/resume
@@ -142,12 +142,12 @@ struct ScoutPolicy {
   uint32_t pid, len = 0;
   uint32_t* out;
   size_t last = ~(size_t)0, last2 = ~(size_t)0;
-  SMX_D ScoutPolicy(const SpecShared& sh_, uint32_t p) : sh(sh_), pid(p), out(sh_.scout_cells + (size_t)p * SCOUT_CAP) {}
+  SMX_D ScoutPolicy(const SpecShared& sh_, uint32_t p) : sh(sh_), pid(p), out(sh_.scout_cells + (size_t)p * sh_.scout_cap) {}
   template <int N> struct Pre {};
   SMX_D void save_blk(const Blk&) {}
   SMX_D void load_blk(Blk&) {}
   SMX_D bool touch(const DevState&, size_t c, size_t = 0) {
-    if (c != last && c != last2) { last2 = last; last = c; if (len < SCOUT_CAP) out[len++] = (uint32_t)c; }
+    if (c != last && c != last2) { last2 = last; last = c; if (len < sh.scout_cap) out[len++] = (uint32_t)c; }
     return true;
   }
   template <int N> SMX_D void prefetch(const DevState&, const size_t (&)[N], const size_t (&)[N], Pre<N>&) {}
@@ -654,7 +654,7 @@ template <class F>
 SMX_D void spec_for_footprint(const SpecShared& sh, uint32_t pid, uint32_t lane, uint32_t nl, F f) {
   const SpecPart& q = sh.part[pid];
   const uint32_t sl = sh.scout_len[pid];
-  const uint32_t* sc = sh.scout_cells + (size_t)pid * SCOUT_CAP;
+  const uint32_t* sc = sh.scout_cells + (size_t)pid * sh.scout_cap;
   for (uint32_t k = lane; k < sl; k += nl) if (!f(sc[k])) return;
   if (q.attempts != 0) {
     for (uint32_t k = lane; k < q.nlog; k += nl) {

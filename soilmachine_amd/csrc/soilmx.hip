@@ -671,9 +671,11 @@ static int spec_alloc(smx_ctx* ctx, uint32_t n) {
   HIPCHK(hipMalloc(&sh.alloc_log, (size_t)cap * MAX_NODELOG * 4)); HIPCHK(hipMalloc(&sh.free_log, (size_t)cap * MAX_NODELOG * 4));
   HIPCHK(hipMalloc(&sh.pending, (size_t)cap * 4));
   sh.ndraws = 2 * cap + 2 * SPEC_MAXNEST; HIPCHK(hipMalloc(&sh.draws, (size_t)sh.ndraws * 4));
-  HIPCHK(hipMalloc(&sh.scout_cells, (size_t)cap * SCOUT_CAP * 4)); HIPCHK(hipMalloc(&sh.scout_len, (size_t)cap * 4));
+  // scouted footprints: water paths are a few thousand cells, wind paths up to ~10^5
+  sh.scout_cap = cap <= 2048 ? 131072u : 16384u;
+  HIPCHK(hipMalloc(&sh.scout_cells, (size_t)cap * sh.scout_cap * 4)); HIPCHK(hipMalloc(&sh.scout_len, (size_t)cap * 4));
   HIPCHK(hipMalloc(&sh.ckpt, (size_t)cap * sizeof(SpecCkpt)));
-  { const char* e = getenv("SMX_SPEC_MODE"); sh.mode = e ? (uint32_t)atoi(e) : 3u; }
+  sh.mode = 3u;
   ctx->spec_cap = cap;
   return 0;
 }
@@ -683,12 +685,19 @@ static int spec_alloc(smx_ctx* ctx, uint32_t n) {
 static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
   if (n <= 0) return 0;
   if (spec_alloc(ctx, (uint32_t)n)) return -1;
+  // engine mode per phase: water = blocked-filter + suspend/resume, wind = suspend/resume only (long wind particles
+  // are nearly always "blocked somewhere": better to let them run up to the contested cell) -- host-sim measurements
+  static const uint32_t mode_water = [] { const char* e = getenv("SMX_SPEC_MODE"); return e ? (uint32_t)atoi(e) : 3u; }();
+  static const uint32_t mode_wind = [] { const char* e = getenv("SMX_SPEC_MODE_WIND"); return e ? (uint32_t)atoi(e) : 2u; }();
+  ctx->sh.mode = wind ? mode_wind : mode_water;
   const SpecShared& sh = ctx->sh;
   hipStream_t st = ctx->stream;
   HIPCHK(hipMemsetAsync(sh.stamp, 0, ctx->ncells * 4, st));
   hipLaunchKernelGGL(k_spec_begin, dim3(1), dim3(256), 0, st, ctx->d, sh, (uint32_t)n);
   const uint32_t L = (uint32_t)spec_lanes();
+  static const bool wind_scout = [] { const char* e = getenv("SMX_WIND_SCOUT"); return e ? atoi(e) != 0 : true; }();
   if (!wind) hipLaunchKernelGGL(k_spec_scout<false>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+  else if (wind_scout) hipLaunchKernelGGL(k_spec_scout<true>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
   uint32_t np = (uint32_t)n > SPEC_WINDOW ? SPEC_WINDOW : (uint32_t)n, last_base = 0, stall = 0;
   bool fallback = false;
   for (int round = 0;; round++) {

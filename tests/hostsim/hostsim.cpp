@@ -218,7 +218,7 @@ static void spec_setup(hs_ctx* c, SpecBuffers& b, uint32_t n) {
   b.alloc_log.assign((size_t)n * MAX_NODELOG, 0); b.free_log.assign((size_t)n * MAX_NODELOG, 0);
   b.pending.assign(n, 0); b.ctrl.assign(SC_COUNT, 0); b.reclaim.assign(1 << 20, 0);
   b.draws.assign(2 * n + 2 * SPEC_MAXNEST, 0);
-  b.scout_cells.assign((size_t)n * SCOUT_CAP, 0); b.scout_len.assign(n, 0);
+  b.sh.scout_cap = 65536; b.scout_cells.assign((size_t)n * b.sh.scout_cap, 0); b.scout_len.assign(n, 0);
   SpecShared& sh = b.sh;
   sh.stamp = b.stamp.data(); sh.claim = b.claim.data(); sh.part = b.part.data(); sh.chunk_tab = b.chunk_tab.data();
   sh.arena = b.arena.data(); sh.arena_chunks = arena_chunks; sh.alloc_log = b.alloc_log.data(); sh.free_log = b.free_log.data();
@@ -275,8 +275,11 @@ int hs_spec_water(hs_ctx* c, int n, int nthreads, int scout, unsigned shuffle, u
 int hs_spec_wind(hs_ctx* c, int n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) { return spec_phase<true>(c, (uint32_t)n, nthreads, scout, shuffle, stats); }
 void hs_spec_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int nthreads, int scout, unsigned shuffle, uint32_t* stats) {
   uint32_t st[8] = {0};
-  if (dowater) { hs_spec_water(c, nwater, nthreads, scout, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[i] += st[i]; hs_grid(c); }
-  if (dowind) { hs_spec_wind(c, nwind, nthreads, scout & ~1, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[6 + i] += st[i]; }
+  if (dowater) { hs_spec_water(c, nwater, nthreads, scout & 0xff, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[i] += st[i]; hs_grid(c); }
+  // scout: bit0 trajectory scout, bits 4-5 water engine mode, bits 8-9 wind engine mode (0 = same as water)
+  const int wmode = (scout >> 8) & 3;
+  const int wscout = wmode ? ((scout & 1) | (wmode << 4)) : (scout & 0xff);
+  if (dowind) { hs_spec_wind(c, nwind, nthreads, wscout, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[6 + i] += st[i]; }
   if (dowater) hs_freq(c);
 }
 }  // extern "C"
