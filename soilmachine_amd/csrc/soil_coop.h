@@ -1,0 +1,267 @@
+// soil_coop.h -- wave-cooperative block access (device only).
+//
+// One particle per wavefront. The particle's physics is a scalar dependent chain and runs on lane 0; but the one
+// memory round trip of a step -- the 3x3 block around the new position (soil_core.h "the carried 3x3 block") -- is
+// nine independent cells, and so is everything the speculative engine does per cell (stamp check, claim check,
+// owner status, CAS, undo-log record). Here lanes 0..8 each take ONE cell: address arithmetic, loads, the
+// acquisition protocol of soil_spec.h and the 64-byte log write happen as single wave instructions instead of
+// nine scalar copies; the nine (size, floor, type) views are then handed to lane 0 with v_readlane. Control flow
+// stays wave-uniform: decisions are taken by lane 0 and broadcast with v_readfirstlane.
+// (PMC before: 2 300 instructions and 67 loads per speculative water step, of which ~1 100 are the physics.)
+#pragma once
+#include "soil_core.h"
+#include "soil_serial.h"
+#include "soil_spec.h"
+
+namespace smx {
+
+#ifdef SMX_HOSTSIM
+// host emulation (tests/hostsim): a "wave" of one lane -- exercises the loop structure, not the lane protocol
+SMX_D int coop_lane() { return 0; }
+SMX_D int rfl(int v) { return v; }
+template <class P, int MODE>
+SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) { sim.template load_block<MODE>(cx, cy, b); return !sim.ab; }
+#else
+SMX_D int coop_lane() { return (int)(threadIdx.x & 63u); }
+SMX_D int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <int K> SMX_D uint32_t rl32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, K); }
+template <int K> SMX_D float rlf(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), K)); }
+template <int K> SMX_D double rl64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), K), hi = __builtin_amdgcn_readlane((int)(b >> 32), K);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Fetch (and, for the speculative engine, acquire + log) the 3x3 block around (cx, cy). Called by ALL lanes with
+// wave-uniform arguments; `b` is valid in every lane afterwards (lane 0 is the one that uses it). Returns false
+// (uniform) if the block could not be acquired -- then nothing of it is held by this particle.
+template <class P, int MODE>
+SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) {
+  const DevState& s = sim.s;
+  const int lane = coop_lane();
+  const int k = lane < 8 ? lane : 8;
+  const int dx = lane < 8 ? nb_dx(k) : 0, dy = lane < 8 ? nb_dy(k) : 0;
+  const int nx = cx + dx, ny = cy + dy;
+  const bool in = !(nx >= s.dimx || ny >= s.dimy || nx < 0 || ny < 0);
+  const bool valid = lane < 9 && in;                         // lanes 9.. shadow the centre and take no part
+  const size_t c0 = (size_t)cx * s.dimy + cy, f0 = (size_t)cy * s.dimx + cx;
+  const size_t c = valid ? (size_t)nx * s.dimy + ny : c0;
+  const size_t fi = valid ? (size_t)ny * s.dimx + nx : f0;
+  const Sec r = s.cells[c];
+  float fr = 0.f, tr = 0.f;
+  if constexpr (MODE == 0) { fr = s.wfreq[f0]; tr = s.wtrack[f0]; }
+  else if constexpr (MODE == 1) { tr = s.windfreq[f0]; }
+  bool ok = true;
+  if constexpr (std::is_same<P, SpecPolicy>::value) {
+    SpecPolicy& pol = sim.pol;
+    const SpecShared& sh = pol.sh;
+    const uint32_t me = pol.me, pid = pol.pid;
+    const uint32_t v = sh.stamp[c], cl = sh.claim[c], fl = s.flags[c];
+    const float utr = s.wtrack[fi], uwf = s.windfreq[fi];
+    const bool need = valid && v != me;
+    const bool failA = need && (v == POISON || v > me || cl < pid);
+    if (need && v != POISON && v > me) SMX_A_STORE(&sh.part[v - 1].kill, 1u);   // a later particle got here first: undo it
+    const bool takeover = need && !failA && v != 0;
+    uint32_t st = ST_COMMITTED;
+    if (takeover) st = sh.part[v - 1].status;
+    const bool failB = takeover && (st == ST_PENDING || st == ST_DONE_NEW || st == ST_SUSPENDED);
+    const bool dep = takeover && st == ST_DONE_OLD;
+    const unsigned long long fm = __ballot(failA || failB);
+    if (fm) {
+      const uint32_t fc = (uint32_t)__shfl((int)(uint32_t)c, __builtin_ctzll(fm));
+      if (lane == 0) pol.fail_cell = fc;
+      return false;
+    }
+    uint32_t old = v;
+    if (need) old = SMX_A_CAS(&sh.stamp[c], v, me);
+    const bool got = need && old == v;
+    const bool failC = need && old != v && old != me;           // somebody took it meanwhile
+    const unsigned long long gm = __ballot(got);
+    const uint32_t cnt = (uint32_t)__popcll(gm);
+    if (cnt) {
+      // lane 0 makes sure the log chunks for entries [base, base+cnt) exist
+      uint32_t base = 0, cidA = 0, cidB = 0, ovf = 0;
+      if (lane == 0) {
+        base = pol.nlog;
+        const uint32_t first = base / LOG_CHUNK, last = (base + cnt - 1) / LOG_CHUNK;
+        for (uint32_t ch = first; ch <= last; ch++) {
+          if (ch >= pol.nchunks) {
+            if (ch >= (uint32_t)MAX_CHUNKS) { ovf = 1; break; }
+            const uint32_t cid = SMX_A_ADD(&sh.ctrl[SC_CHUNK_CURSOR], 1u);
+            if (cid >= sh.arena_chunks) { ovf = 1; break; }
+            sh.chunk_tab[(size_t)pid * MAX_CHUNKS + ch] = cid;
+            pol.nchunks = ch + 1;
+          }
+        }
+        if (!ovf) { cidA = sh.chunk_tab[(size_t)pid * MAX_CHUNKS + first]; cidB = sh.chunk_tab[(size_t)pid * MAX_CHUNKS + last]; }
+        else pol.overflow = 1;
+      }
+      base = (uint32_t)rfl((int)base); cidA = (uint32_t)rfl((int)cidA); cidB = (uint32_t)rfl((int)cidB); ovf = (uint32_t)rfl((int)ovf);
+      if (ovf) {                                             // log full: give the cells back, the attempt is void
+        if (got) SMX_A_STORE(&sh.stamp[c], v);
+        if (lane == 0) pol.fail_cell = (uint32_t)c0;
+        return false;
+      }
+      if (got) {
+        const uint32_t e = base + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull));
+        const uint32_t cid = (e / LOG_CHUNK == base / LOG_CHUNK) ? cidA : cidB;
+        SpecLog* ent = sh.arena + (size_t)cid * LOG_CHUNK + (e % LOG_CHUNK);
+        ent->cell = (uint32_t)c; ent->prev = v; ent->rec = r; ent->wtrack = utr; ent->windfreq = uwf; ent->flags = fl;
+      }
+      if (lane == 0) {
+        pol.nlog = base + cnt;
+        if (pol.nlog % LOG_CHUNK) pol.chunk = sh.arena + (size_t)cidB * LOG_CHUNK;
+      }
+      unsigned long long dm = __ballot(dep && got);
+      while (dm) {                                           // cells taken over from tentative particles: dependencies
+        const int dk = __builtin_ctzll(dm);
+        dm &= dm - 1;
+        const uint32_t owner = (uint32_t)__shfl((int)v, dk) - 1u;
+        if (lane == 0) pol.add_dep(owner);
+      }
+    }
+    const unsigned long long cm = __ballot(failC);
+    if (cm) {
+      const uint32_t fc = (uint32_t)__shfl((int)(uint32_t)c, __builtin_ctzll(cm));
+      if (lane == 0) pol.fail_cell = fc;
+      ok = false;
+    }
+    if (ok && lane == 0) pol.last = c0;
+  }
+  // hand the nine views to lane 0 (v_readlane with constant lane numbers; executed by every lane)
+  // (the asm pins the broadcast values in VGPRs: left to itself the compiler keeps all 27 of them, for both
+  // ping-pong blocks, in SGPRs -- they are wave-uniform -- and then spills hundreds of SGPRs inside the step loop)
+#define X(i) b.v##i.size = rl64<i>(r.size); b.v##i.floor = rl64<i>(r.floor); b.v##i.type = rl32<i>(r.type); \
+  asm volatile("" : "+v"(b.v##i.size), "+v"(b.v##i.floor), "+v"(b.v##i.type));
+  SMX_FOR9(X)
+#undef X
+  b.c0 = c0;
+  b.inb = (uint32_t)(__ballot(in && lane < 8) & 0xffull);
+  b.fr = fr; b.tr = tr;
+  return ok;
+}
+
+#endif  // SMX_HOSTSIM
+
+// while(move && interact) for the wave: soil_core.h water_loop with the block fetches done cooperatively
+template <class P>
+SMX_D void water_loop_coop(Sim<P>& sim, Water& p, bool toplevel, bool resume) {
+  const bool l0 = coop_lane() == 0;
+  Blk A, B;
+  if (resume) { if (l0) sim.pol.load_blk(A); }
+  else {
+    int cx = 0, cy = 0;
+    if (l0) { p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y); cx = p.ix; cy = p.iy; }
+    cx = rfl(cx); cy = rfl(cy);
+    if (!coop_load_block<P, 0>(sim, cx, cy, A)) { if (l0) sim.ab = true; return; }
+  }
+  while (true) {
+#define SMX_COOP_WATER_STEP(CUR, NXT)                                                                         \
+    {                                                                                                         \
+      int go = 1;                                                                                             \
+      if (l0 && !resume) go = sim.water_move(p, toplevel, CUR) ? 1 : 0;                                       \
+      resume = false;                                                                                         \
+      if (!rfl(go)) return;                                                                                   \
+      int nx = 0, ny = 0;                                                                                     \
+      if (l0) { nx = (int)roundf(p.pos.x); ny = (int)roundf(p.pos.y); }                                       \
+      nx = rfl(nx); ny = rfl(ny);                                                                             \
+      const bool ok = coop_load_block<P, 0>(sim, nx, ny, NXT);                                                \
+      int r = -1;                                                                                             \
+      if (l0) { if (ok) r = sim.water_interact(p, CUR, NXT, true); else sim.ab = true; }                      \
+      r = rfl(r);                                                                                             \
+      if (r <= 0) { if (l0 && r < 0 && sim.susp_ok) { sim.susp = 2; sim.pol.save_blk(CUR); } return; }        \
+    }
+    SMX_COOP_WATER_STEP(A, B)
+    SMX_COOP_WATER_STEP(B, A)
+#undef SMX_COOP_WATER_STEP
+  }
+}
+
+template <class P>
+SMX_D void wind_loop_coop(Sim<P>& sim, Wind& p, bool resume) {
+  const bool l0 = coop_lane() == 0;
+  Blk A, B;
+  if (resume) { if (l0) sim.pol.load_blk(A); }
+  else {
+    int live = 0, cx = 0, cy = 0;
+    if (l0) {
+      live = !(sim.soils[p.contains].suspension == 0.0);     // wind.h:56-57
+      p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y); cx = p.ix; cy = p.iy;
+    }
+    if (!rfl(live)) return;
+    cx = rfl(cx); cy = rfl(cy);
+    if (!coop_load_block<P, 1>(sim, cx, cy, A)) { if (l0) sim.ab = true; return; }
+  }
+  while (true) {
+#define SMX_COOP_WIND_STEP(CUR, NXT)                                                                          \
+    {                                                                                                         \
+      int go = 1;                                                                                             \
+      if (l0 && !resume) go = sim.wind_move(p, CUR) ? 1 : 0;                                                  \
+      resume = false;                                                                                         \
+      if (!rfl(go)) return;                                                                                   \
+      int nx = 0, ny = 0;                                                                                     \
+      if (l0) { nx = (int)roundf(p.pos.x); ny = (int)roundf(p.pos.y); }                                       \
+      nx = rfl(nx); ny = rfl(ny);                                                                             \
+      const bool ok = coop_load_block<P, 1>(sim, nx, ny, NXT);                                                \
+      int r = -1;                                                                                             \
+      if (l0) { if (ok) r = sim.wind_interact(p, CUR, NXT, true); else sim.ab = true; }                       \
+      r = rfl(r);                                                                                             \
+      if (r <= 0) { if (l0 && r < 0 && sim.susp_ok) { sim.susp = 2; sim.pol.save_blk(CUR); } return; }        \
+    }
+    SMX_COOP_WIND_STEP(A, B)
+    SMX_COOP_WIND_STEP(B, A)
+#undef SMX_COOP_WIND_STEP
+  }
+}
+
+// What follows a top-level particle's loop -- flood, water-table cascade, nested particles (water.h:123-283) -- is
+// rare, long and scalar. It is kept OUT of line: inlined and specialised into the wave kernel it pushed the step
+// loop's register allocation over the edge (and the -O3 build of exactly that variant produced wrong maps on
+// gfx950 while -O2 and the out-of-line build are bit-exact; see DESIGN.md "Cooperative block access").
+template <class P>
+__attribute__((noinline)) SMX_D void coop_water_tail(Sim<P>& sim, Water& p) {
+  Frame st[MAX_FRAMES]; int depth = 0;
+  sim.water_drive(p, true, true, st, depth, false, true);
+}
+
+// one particle of a speculative phase, executed by a whole wave (cf. spec_exec_one in soil_spec.h)
+template <bool WIND>
+SMX_D void spec_exec_one_coop(const DevState& s, const SoilP* soils, const SpecShared& sh, uint32_t pid) {
+  const bool l0 = coop_lane() == 0;
+  if ((sh.mode & 1u) && sh.part[pid].blocked) { if (l0) SMX_A_ADD(&sh.ctrl[SC_SKIPPED], 1u); return; }
+  if (l0) SMX_A_ADD(&sh.ctrl[SC_EXECUTED], 1u);
+  const bool resume = sh.part[pid].status == ST_SUSPENDED;
+  SpecPolicy pol(sh, pid, resume);
+  Sim<SpecPolicy> sim(s, soils, pol);
+  sim.susp_ok = (sh.mode & 2u) != 0;
+  if constexpr (WIND) {
+    Wind p;
+    p.pos = {0.f, 0.f}; p.speed = {0.f, 0.f, 0.f}; p.sediment = p.height = p.sheight = 0.0; p.ix = p.iy = 0; p.surface = p.contains = 0;
+    if (l0) {
+      if (resume) p = sh.ckpt[pid].d;
+      else { int d1, d2; pol.spawn_draws(d1, d2); sim.wind_init(p, d2 % s.dimx, d1 % s.dimy); }
+    }
+    if (!rfl(l0 && sim.ab ? 1 : 0)) wind_loop_coop(sim, p, resume);
+    if (!l0) return;
+    SMX_A_MAX(&sh.ctrl[SC_ROUND_MAXSTEPS], (uint32_t)sim.n_steps_wind);
+    if (sim.susp && !pol.overflow) { sim.flush_counters(); sh.ckpt[pid].d = p; pol.suspend(s); return; }
+  } else {
+    Water p;
+    p.pos = {0.f, 0.f}; p.speed = {0.f, 0.f}; p.volume = p.sediment = p.evaprate = 0.0; p.spill = 0; p.ix = p.iy = 0;
+    p.friction = 0.f; p.surface = p.contains = 0;
+    if (l0) {
+      if (resume) p = sh.ckpt[pid].w;
+      else { int d1, d2; pol.spawn_draws(d1, d2); sim.water_init(p, d2 % s.dimx, d1 % s.dimy); }
+    }
+    if (!rfl(l0 && sim.ab ? 1 : 0)) water_loop_coop(sim, p, true, resume);
+    if (!l0) return;
+    if (!sim.ab && !sim.susp) coop_water_tail(sim, p);
+    SMX_A_MAX(&sh.ctrl[SC_ROUND_MAXSTEPS], (uint32_t)sim.n_steps_w_all);
+    if (sim.susp && !pol.overflow) { sim.flush_counters(); sh.ckpt[pid].w = p; pol.suspend(s); return; }
+  }
+  if (sim.ab || pol.overflow) { pol.self_rollback(s); return; }
+  sim.flush_counters();
+  pol.finish_done(s);
+}
+
+}  // namespace smx

@@ -735,12 +735,15 @@ struct Sim {
   // WaterParticle::interact (water.h:75-121): `cur` is the block around ipos, `nb` receives the block around the
   // new position. 1 = interact() returned true, 0 = false, -1 = the new block could not be acquired (speculative
   // engine): nothing of interact() has happened yet, so the particle can be resumed exactly here.
-  SMX_D int water_interact(Water& p, const Blk& cur, Blk& nb) {
+  // `loaded`: the caller has already fetched `nb` (the wave-cooperative loop of soil_coop.h)
+  SMX_D int water_interact(Water& p, const Blk& cur, Blk& nb, bool loaded = false) {
     View cv = cur.v8;
     const float fr = cur.fr;
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-    load_block<0>(nx, ny, nb);                               // THE memory round trip of this step
-    if (ab) return -1;
+    if (!loaded) {
+      load_block<0>(nx, ny, nb);                             // THE memory round trip of this step
+      if (ab) return -1;
+    }
     const SoilP& param = soils[p.surface];
     const double hb = bilinear_blk(p.pos, nx, ny, nb);
     double c_eq = param.solubility * (vh(cv) - hb) * (double)s.scale / 80.0;
@@ -818,11 +821,13 @@ struct Sim {
   }
   // WindParticle::interact (wind.h:94-136). 1 = go on (interact() always returns true), 0 = aborted somewhere
   // inside (speculative engine), -1 = the new block could not be acquired: resumable exactly here.
-  SMX_D int wind_interact(Wind& p, const Blk& cur, Blk& nb) {
+  SMX_D int wind_interact(Wind& p, const Blk& cur, Blk& nb, bool loaded = false) {
     View cv = cur.v8;
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
-    load_block<1>(nx, ny, nb);
-    if (ab) return -1;
+    if (!loaded) {
+      load_block<1>(nx, ny, nb);
+      if (ab) return -1;
+    }
     const SoilP& param = soils[p.surface];
     const double hb = bilinear_blk(p.pos, nx, ny, nb);
     View nv = nb.v8;
@@ -882,11 +887,14 @@ struct Sim {
   }
   // Runs one WaterParticle to completion INCLUDING everything it spawns (SoilMachine.cpp:292-296, water.h:258-262),
   // then drains the cascade frame stack. `start_with_particle` = false: only drain the frames already pushed.
-  SMX_D void water_drive(Water& p, bool toplevel, bool start_with_particle, Frame* st, int& depth, bool resume = false) {
+  // `loop_done`: the particle's move/interact loop has already been run by the caller (soil_coop.h)
+  SMX_D void water_drive(Water& p, bool toplevel, bool start_with_particle, Frame* st, int& depth, bool resume = false,
+                         bool loop_done = false) {
     bool have = start_with_particle;
     while (true) {
       if (have) {
-        water_loop(p, toplevel, resume);                    // while(move && interact);
+        if (!loop_done) water_loop(p, toplevel, resume);    // while(move && interact);
+        loop_done = false;
         resume = false;
         if (ab) return;
         if constexpr (P::READ_ONLY) {                       // scout: claim where a flood would act, then stop

@@ -24,6 +24,8 @@
 #include "soil_core.h"
 #include "soil_serial.h"
 #include "soil_spec.h"
+#include <type_traits>
+#include "soil_coop.h"
 #include "soil_noise.h"
 
 using namespace smx;
@@ -171,6 +173,13 @@ __global__ void __launch_bounds__(64) k_spec_exec(DevState s, SpecShared sh, uin
   const uint32_t i = blockIdx.x * lanes + threadIdx.x;
   if (threadIdx.x >= lanes || i >= sh.ctrl[SC_NPENDING]) return;
   spec_exec_one<WIND>(s, soils_sh, sh, sh.pending[i]);
+}
+// one particle per WAVE: lanes 0..8 share the block fetch / acquisition of every step (soil_coop.h)
+template <bool WIND>
+__global__ void __launch_bounds__(64) k_spec_exec_coop(DevState s, SpecShared sh) {
+  SMX_LOAD_SOILS(soils_sh)
+  if (blockIdx.x >= sh.ctrl[SC_NPENDING]) return;
+  spec_exec_one_coop<WIND>(s, soils_sh, sh, sh.pending[blockIdx.x]);
 }
 __global__ void __launch_bounds__(256) k_spec_boundary(DevState s, SpecShared sh) {
   __shared__ SpecWork w;
@@ -706,8 +715,14 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
     if (sh.mode & 1u) hipLaunchKernelGGL(k_spec_select, dim3(np), dim3(64), 0, st, sh);
     {
       PhaseTimer tk(ctx, wind ? 5 : 4);
-      if (wind) hipLaunchKernelGGL(k_spec_exec<true>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
-      else hipLaunchKernelGGL(k_spec_exec<false>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+      static const bool coop = [] { const char* e = getenv("SMX_COOP"); return e ? atoi(e) != 0 : true; }();
+      if (coop) {
+        if (wind) hipLaunchKernelGGL(k_spec_exec_coop<true>, dim3(np), dim3(64), 0, st, ctx->d, sh);
+        else hipLaunchKernelGGL(k_spec_exec_coop<false>, dim3(np), dim3(64), 0, st, ctx->d, sh);
+      } else {
+        if (wind) hipLaunchKernelGGL(k_spec_exec<true>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+        else hipLaunchKernelGGL(k_spec_exec<false>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+      }
     }
     hipLaunchKernelGGL(k_spec_boundary, dim3(1), dim3(256), 0, st, ctx->d, sh);
     HIPCHK(hipMemcpyAsync(ctx->h_ctrl, sh.ctrl, SC_COUNT * 4, hipMemcpyDeviceToHost, st));

@@ -6,6 +6,7 @@
 // it lives under tests/, is built by tests/hostsim_lib.py, and soilmachine_amd/ has no reference to it.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -15,6 +16,8 @@
 #include "../../soilmachine_amd/csrc/soil_core.h"
 #include "../../soilmachine_amd/csrc/soil_serial.h"
 #include "../../soilmachine_amd/csrc/soil_spec.h"
+#include <type_traits>
+#include "../../soilmachine_amd/csrc/soil_coop.h"
 #include <thread>
 #include <algorithm>
 #include <random>
@@ -253,7 +256,8 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
     const uint32_t np = sh.ctrl[SC_NPENDING];
     parallel_for(np, nthreads, [&](uint32_t i) { spec_claim_one(sh, sh.pending[i], 0u, 1u); }, shuffle ? shuffle + 1 : 0);
     if (sh.mode & 1u) parallel_for(np, nthreads, [&](uint32_t i) { const uint32_t pid = sh.pending[i]; sh.part[pid].blocked = spec_blocked(sh, pid, 0u, 1u) ? 1u : 0u; }, 0);
-    parallel_for(np, nthreads, [&](uint32_t i) { spec_exec_one<WIND>(s, s.soils, sh, sh.pending[i]); }, shuffle ? shuffle + 2 + sh.ctrl[SC_ROUNDS] : 0);
+    const bool coop = (sh.mode & 4u) != 0;                   // mode bit 2 (host only): the wave-loop structure of soil_coop.h
+    parallel_for(np, nthreads, [&](uint32_t i) { if (coop) spec_exec_one_coop<WIND>(s, s.soils, sh, sh.pending[i]); else spec_exec_one<WIND>(s, s.soils, sh, sh.pending[i]); }, shuffle ? shuffle + 2 + sh.ctrl[SC_ROUNDS] : 0);
     { static SpecWork* w = new SpecWork(); spec_boundary_team(s, sh, *w, 0u, 1u, []() {}); }
     if (sh.ctrl[SC_NPENDING] == 0 && sh.ctrl[SC_BASE] == n) break;
     if (sh.ctrl[SC_BASE] == last_base) stall++; else { stall = 0; last_base = sh.ctrl[SC_BASE]; }
@@ -278,7 +282,7 @@ void hs_spec_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int
   if (dowater) { hs_spec_water(c, nwater, nthreads, scout & 0xff, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[i] += st[i]; hs_grid(c); }
   // scout: bit0 trajectory scout, bits 4-5 water engine mode, bits 8-9 wind engine mode (0 = same as water)
   const int wmode = (scout >> 8) & 3;
-  const int wscout = wmode ? ((scout & 1) | (wmode << 4)) : (scout & 0xff);
+  const int wscout = wmode ? ((scout & 1) | (wmode << 4) | (scout & 0x40)) : (scout & 0xff);
   if (dowind) { hs_spec_wind(c, nwind, nthreads, wscout, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[6 + i] += st[i]; }
   if (dowater) hs_freq(c);
 }

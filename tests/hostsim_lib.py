@@ -100,7 +100,8 @@ class HostSim:
 
     def spec_tick(self, nwater, nwind, dowater=True, dowind=True, nthreads=8, scout=1 | (3 << 4), shuffle=0):
         """One tick with the speculative engine emulated by `nthreads` host threads.
-        `scout`: bit0 = read-only trajectory scout, bits 4.. = engine mode (1 blocked-filter, 2 suspend/resume).
+        `scout`: bit0 = read-only trajectory scout, bits 4.. = engine mode (1 blocked-filter, 2 suspend/resume,
+        4 = run the particles through the wave-loop structure of soil_coop.h).
         Returns stats: [rounds, aborts, kills, fell_back, executed, critical-path steps] for water then wind."""
         st = np.zeros(12, np.uint32)
         self.L.hs_spec_tick(self.h, nwater, nwind, int(dowater), int(dowind), nthreads, scout, shuffle, _p(st))

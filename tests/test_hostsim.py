@@ -55,7 +55,7 @@ def test_device_sources_reproduce_reference_digests(case):
 
 
 # ---------------------------------------------------------------- speculative engine (threads emulate the waves)
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 7])            # bit 2: the wave-loop structure of soil_coop.h
 @pytest.mark.parametrize("case", ["default64", "rgps64", "rocksand48x80"])
 def test_speculative_protocol_is_exact(case, mode):
     """stamps / claims / forwarding / kill closure / rollback / suspend-resume: whatever interleaving the 8 threads
