@@ -526,8 +526,16 @@ struct Sim {
     const float fx = floorf(pos.x), fy = floorf(pos.y);
     const int dx = (int)fx - cx, dy = (int)fy - cy;          // in {-1, 0}: the 2x2 block lies inside the 3x3 block
     const float wx = pos.x - fx, wy = pos.y - fy;
-    const double h00 = vh(blk_get(b, code_rel(dx, dy))), h10 = vh(blk_get(b, code_rel(dx + 1, dy)));
-    const double h01 = vh(blk_get(b, code_rel(dx, dy + 1))), h11 = vh(blk_get(b, code_rel(dx + 1, dy + 1)));
+    // the four corners are picked from the nine column heights with ten two-way selects (first the column pair by
+    // dx, then the row pair by dy) -- a generic blk_get() per corner costs four nine-way select chains per step
+    const bool lx = dx < 0, ly = dy < 0;
+    const double hmm = vh(b.v0), hm0 = vh(b.v1), hmp = vh(b.v2);   // x-1: y-1, y, y+1
+    const double h0m = vh(b.v3), h00c = vh(b.v8), h0p = vh(b.v4);  // x
+    const double hpm = vh(b.v5), hp0 = vh(b.v6), hpp = vh(b.v7);   // x+1
+    const double am = lx ? hmm : h0m, a0 = lx ? hm0 : h00c, ap = lx ? hmp : h0p;   // column floor(x)
+    const double bm = lx ? h0m : hpm, b0 = lx ? h00c : hp0, bp = lx ? h0p : hpp;   // column floor(x)+1
+    const double h00 = ly ? am : a0, h01 = ly ? a0 : ap;
+    const double h10 = ly ? bm : b0, h11 = ly ? b0 : bp;
     double h = 0.0;
     h += (1.0 - wx) * (1.0 - wy) * h00;
     h += (1.0 - wx) * wy * h10;                             // crossed weights as in the reference (:434-435)
@@ -821,7 +829,7 @@ struct Sim {
   }
   // WindParticle::interact (wind.h:94-136). 1 = go on (interact() always returns true), 0 = aborted somewhere
   // inside (speculative engine), -1 = the new block could not be acquired: resumable exactly here.
-  SMX_D int wind_interact(Wind& p, const Blk& cur, Blk& nb, bool loaded = false) {
+  SMX_D int wind_interact(Wind& p, Blk& cur, Blk& nb, bool loaded = false) {
     View cv = cur.v8;
     const int nx = (int)roundf(p.pos.x), ny = (int)roundf(p.pos.y);
     if (!loaded) {
@@ -851,19 +859,31 @@ struct Sim {
       changed = dep > 0.0;
       ncasc = 2;                                             // cascade(ipos); cascade(npos)
     }
+    // The two columns just changed lie in both carried blocks: patch the register copies so that they stay exact
+    // images of the map. The usual outcome of the cascades that follow -- a grain of dust moves nothing -- is then
+    // decided on registers, and the step needs no memory round trip beyond the block load it started with.
+    const int rdx = p.ix - nx, rdy = p.iy - ny;              // ipos seen from npos
+    const bool near = rdx >= -1 && rdx <= 1 && rdy >= -1 && rdy <= 1;
+    if (changed) {
+      cur.v8 = cv;
+      if (ncasc == 2 && !(rdx == 0 && rdy == 0)) {
+        nb.v8 = nv;
+        if (near) blk_put(cur, code_rel(-rdx, -rdy), nv);
+      }
+      if (near) blk_put(nb, code_rel(rdx, rdy), cv);        // (npos == ipos: the centre of nb)
+    }
+    bool stale = false;                                      // a cascade moved material: the map is ahead of the blocks
     for (int q = 0; q < ncasc; q++) {
       const f2 at = (q == 0) ? f2{(float)p.ix, (float)p.iy} : f2{(float)nx, (float)ny};
-      // while nothing has moved in this step, `cur` / `nb` are exact copies of the blocks around ipos / npos: the
-      // common "nothing to move" outcome is decided on them without any memory access
-      if (!changed) {
+      if (!stale) {
         const bool any = (q == 0) ? cascade_precheck(cur) : cascade_precheck(nb);
         if (!any) { n_casc++; continue; }
       }
-      changed |= particle_cascade<1>(at);
+      stale |= particle_cascade<1>(at);
       if (ab) return 0;
     }
     p.ix = nx; p.iy = ny;
-    if (changed) load_block<1>(nx, ny, nb);               // material moved inside the block: refresh the views
+    if (stale) load_block<1>(nx, ny, nb);                 // refresh the views
     return ab ? 0 : 1;
   }
   SMX_D void wind_loop(Wind& p, bool resume = false) {       // SoilMachine.cpp:306
