@@ -32,6 +32,8 @@ template <int K> SMX_D double rl64(double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+SMX_D uint32_t sh_cap(const ScoutPolicy& p) { return p.sh.scout_cap; }
+
 // Fetch (and, for the speculative engine, acquire + log) the 3x3 block around (cx, cy). Called by ALL lanes with
 // wave-uniform arguments; `b` is valid in every lane afterwards (lane 0 is the one that uses it). Returns false
 // (uniform) if the block could not be acquired -- then nothing of it is held by this particle.
@@ -128,6 +130,18 @@ SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) {
     }
     if (ok && lane == 0) pol.last = c0;
   }
+  if constexpr (std::is_same<P, ScoutPolicy>::value) {       // read-only scout: the block's cells go to the footprint list
+    ScoutPolicy& pol = sim.pol;
+    const unsigned long long vm = __ballot(valid);
+    const uint32_t base = (uint32_t)rfl((int)pol.len);
+    const uint32_t e = base + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull));
+    if (valid && e < sh_cap(pol)) pol.out[e] = (uint32_t)c;
+    if (lane == 0) {
+      const uint32_t nl = base + (uint32_t)__popcll(vm);
+      pol.len = nl < sh_cap(pol) ? nl : sh_cap(pol);
+      pol.last2 = pol.last; pol.last = c0;
+    }
+  }
   // hand the nine views to lane 0 (v_readlane with constant lane numbers; executed by every lane)
   // (the asm pins the broadcast values in VGPRs: left to itself the compiler keeps all 27 of them, for both
   // ping-pong blocks, in SGPRs -- they are wave-uniform -- and then spills hundreds of SGPRs inside the step loop)
@@ -222,6 +236,30 @@ template <class P>
 __attribute__((noinline)) SMX_D void coop_water_tail(Sim<P>& sim, Water& p) {
   Frame st[MAX_FRAMES]; int depth = 0;
   sim.water_drive(p, true, true, st, depth, false, true);
+}
+
+// round 0: the read-only trajectory of one particle, walked by a whole wave (cf. spec_scout_one in soil_spec.h)
+template <bool WIND>
+SMX_D void spec_scout_one_coop(const DevState& s, const SoilP* soils, const SpecShared& sh, uint32_t pid) {
+  const bool l0 = coop_lane() == 0;
+  ScoutPolicy pol(sh, pid);
+  Sim<ScoutPolicy> sim(s, soils, pol);
+  const uint32_t k = 2u * pid + 2u * sh.part[pid].noff;
+  const int ry = (int)(sh.draws[k] >> 1) % s.dimy, rx = (int)(sh.draws[k + 1] >> 1) % s.dimx;
+  if constexpr (WIND) {
+    Wind p;
+    p.pos = {0.f, 0.f}; p.speed = {0.f, 0.f, 0.f}; p.sediment = p.height = p.sheight = 0.0; p.ix = p.iy = 0; p.surface = p.contains = 0;
+    if (l0) sim.wind_init(p, rx, ry);
+    wind_loop_coop(sim, p, false);
+  } else {
+    Water p;
+    p.pos = {0.f, 0.f}; p.speed = {0.f, 0.f}; p.volume = p.sediment = p.evaprate = 0.0; p.spill = 0; p.ix = p.iy = 0;
+    p.friction = 0.f; p.surface = p.contains = 0;
+    if (l0) sim.water_init(p, rx, ry);
+    water_loop_coop(sim, p, true, false);
+    if (l0) coop_water_tail(sim, p);                         // (read-only: claims where a flood would act, water.h:123)
+  }
+  if (l0) pol.finish();
 }
 
 // one particle of a speculative phase, executed by a whole wave (cf. spec_exec_one in soil_spec.h)

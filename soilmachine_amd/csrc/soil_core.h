@@ -549,8 +549,21 @@ struct Sim {
   SMX_D bool cascade_precheck(const Blk& b) const {
     const double sc = (double)(float)s.scale;
     const View& ctr = b.v8;
-    bool any = false;
     const double hC = vh(ctr);
+    // One surface type in the whole block (the usual case): every neighbour has the same limit, and because
+    // x -> x*sc*0.0125 is monotonic the eight comparisons collapse into one on the largest |dh| -- the same
+    // answer as the loop below, bit for bit. (Out-of-bounds slots hold copies of a centre record: |dh| = 0, or, if
+    // the centre has changed since, a spurious "maybe" that the exact loop of cascade_loop() then dismisses.)
+    bool same = true;
+    double dmax = 0.0;
+#define X(k) same &= (b.v##k.type == ctr.type); dmax = fmax(dmax, fabs(hC - vh(b.v##k)));
+    SMX_FOR8(X)
+#undef X
+    if (same) {
+      const double lim = (double)soils[vsurf(ctr)].maxdiff * 0.9999;
+      return !(dmax * sc * 0.0125 < lim);
+    }
+    bool any = false;
 #define X(k)                                                                                   \
     if ((b.inb >> k) & 1) {                                                                    \
       const double dh = hC - vh(b.v##k);                                                       \

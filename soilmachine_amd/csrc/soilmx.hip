@@ -155,6 +155,12 @@ __global__ void __launch_bounds__(64) k_spec_scout(DevState s, SpecShared sh, ui
   if (threadIdx.x >= lanes || pid >= n) return;
   spec_scout_one<WIND>(s, soils_sh, sh, pid);
 }
+template <bool WIND>
+__global__ void __launch_bounds__(64) k_spec_scout_coop(DevState s, SpecShared sh) {
+  SMX_LOAD_SOILS(soils_sh)
+  if (blockIdx.x >= sh.ctrl[SC_N]) return;
+  spec_scout_one_coop<WIND>(s, soils_sh, sh, blockIdx.x);
+}
 // one wave per pending particle walks its predicted footprint: publish claims, then (next kernel) test them
 __global__ void __launch_bounds__(64) k_spec_claim(SpecShared sh) {
   if (blockIdx.x >= sh.ctrl[SC_NPENDING]) return;
@@ -705,8 +711,14 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
   hipLaunchKernelGGL(k_spec_begin, dim3(1), dim3(256), 0, st, ctx->d, sh, (uint32_t)n);
   const uint32_t L = (uint32_t)spec_lanes();
   static const bool wind_scout = [] { const char* e = getenv("SMX_WIND_SCOUT"); return e ? atoi(e) != 0 : true; }();
-  if (!wind) hipLaunchKernelGGL(k_spec_scout<false>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
-  else if (wind_scout) hipLaunchKernelGGL(k_spec_scout<true>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+  static const bool coop_scout = [] { const char* e = getenv("SMX_COOP"); return e ? atoi(e) != 0 : true; }();
+  if (coop_scout) {
+    if (!wind) hipLaunchKernelGGL(k_spec_scout_coop<false>, dim3(n), dim3(64), 0, st, ctx->d, sh);
+    else if (wind_scout) hipLaunchKernelGGL(k_spec_scout_coop<true>, dim3(n), dim3(64), 0, st, ctx->d, sh);
+  } else {
+    if (!wind) hipLaunchKernelGGL(k_spec_scout<false>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+    else if (wind_scout) hipLaunchKernelGGL(k_spec_scout<true>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+  }
   uint32_t np = (uint32_t)n > SPEC_WINDOW ? SPEC_WINDOW : (uint32_t)n, last_base = 0, stall = 0;
   bool fallback = false;
   for (int round = 0;; round++) {

@@ -250,7 +250,7 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
   uint32_t last_base = 0, stall = 0; int fell_back = 0;
   b.sh.mode = (uint32_t)(scout >> 4);                       // scout argument: bit0 = trajectory scout, bits 4.. = engine mode
   scout &= 1;
-  if (scout) parallel_for(n, nthreads, [&](uint32_t i) { spec_scout_one<WIND>(s, s.soils, sh, i); }, shuffle ? shuffle + 1 : 0);
+  if (scout) parallel_for(n, nthreads, [&](uint32_t i) { if (b.sh.mode & 4u) spec_scout_one_coop<WIND>(s, s.soils, sh, i); else spec_scout_one<WIND>(s, s.soils, sh, i); }, shuffle ? shuffle + 1 : 0);
   while (true) {
     std::fill(b.claim.begin(), b.claim.end(), NOCLAIM);
     const uint32_t np = sh.ctrl[SC_NPENDING];
