@@ -20,7 +20,7 @@ namespace smx {
 SMX_D int coop_lane() { return 0; }
 SMX_D int rfl(int v) { return v; }
 template <class P, int MODE>
-SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) { sim.template load_block<MODE>(cx, cy, b); return !sim.ab; }
+SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b, bool = false, int = 0, int = 0) { sim.template load_block<MODE>(cx, cy, b); return !sim.ab; }
 #else
 SMX_D int coop_lane() { return (int)(threadIdx.x & 63u); }
 SMX_D int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -38,7 +38,7 @@ SMX_D uint32_t sh_cap(const ScoutPolicy& p) { return p.sh.scout_cap; }
 // wave-uniform arguments; `b` is valid in every lane afterwards (lane 0 is the one that uses it). Returns false
 // (uniform) if the block could not be acquired -- then nothing of it is held by this particle.
 template <class P, int MODE>
-SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) {
+SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b, bool have_prev = false, int pcx = 0, int pcy = 0) {
   const DevState& s = sim.s;
   const int lane = coop_lane();
   const int k = lane < 8 ? lane : 8;
@@ -55,32 +55,46 @@ SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) {
   else if constexpr (MODE == 1) { tr = s.windfreq[f0]; }
   bool ok = true;
   if constexpr (std::is_same<P, SpecPolicy>::value) {
+    // Acquisition in ONE memory round trip for the usual cell. Cells of the previous block (have_prev: the block
+    // around (pcx, pcy) is held entirely by this particle) need nothing but their record. For every other cell
+    // the record, the claim, the undo words AND a compare-and-swap of the stamp from 0 ("untouched in this
+    // phase") to `me` are issued together:
+    //   old == 0     the cell is ours (a stamp never returns to 0 inside a phase, so the record read alongside is
+    //                the untouched one) -- unless a lower pending particle claims it: then it is handed back
+    //   old == me    ours already (revisited)
+    //   otherwise    the owner decides, as in SpecPolicy::acquire_log: later particle / poisoned -> fail; finished
+    //                lower particle -> status load + second CAS (two more trips; rare outside the late rounds)
     SpecPolicy& pol = sim.pol;
     const SpecShared& sh = pol.sh;
     const uint32_t me = pol.me, pid = pol.pid;
-    const uint32_t v = sh.stamp[c], cl = sh.claim[c], fl = s.flags[c];
-    const float utr = s.wtrack[fi], uwf = s.windfreq[fi];
-    const bool need = valid && v != me;
-    const bool failA = need && (v == POISON || v > me || cl < pid);
-    if (need && v != POISON && v > me) SMX_A_STORE(&sh.part[v - 1].kill, 1u);   // a later particle got here first: undo it
-    const bool takeover = need && !failA && v != 0;
+    const bool mine = valid && have_prev && (uint32_t)(nx - pcx + 1) <= 2u && (uint32_t)(ny - pcy + 1) <= 2u;
+    const bool need = valid && !mine;
+    uint32_t cl = NOCLAIM, fl = 0u, old = me;
+    float utr = 0.f, uwf = 0.f;
+    if (need) {
+      cl = sh.claim[c]; fl = s.flags[c]; utr = s.wtrack[fi]; uwf = s.windfreq[fi];
+      old = SMX_A_CAS(&sh.stamp[c], 0u, me);
+    }
+    const bool fresh = need && old == 0u;
+    const bool other = need && old != 0u && old != me;
+    const bool failA = other && (old == POISON || old > me);
+    if (failA && old != POISON) SMX_A_STORE(&sh.part[old - 1].kill, 1u);   // a later particle got here first: undo it
+    const bool failCl = (fresh || (other && !failA)) && cl < pid;           // yield to a lower pending particle
+    if (fresh && failCl) SMX_A_STORE(&sh.stamp[c], 0u);
+    const bool takeover = other && !failA && !failCl;
     uint32_t st = ST_COMMITTED;
-    if (takeover) st = sh.part[v - 1].status;
+    if (takeover) st = sh.part[old - 1].status;
     const bool failB = takeover && (st == ST_PENDING || st == ST_DONE_NEW || st == ST_SUSPENDED);
     const bool dep = takeover && st == ST_DONE_OLD;
-    const unsigned long long fm = __ballot(failA || failB);
-    if (fm) {
-      const uint32_t fc = (uint32_t)__shfl((int)(uint32_t)c, __builtin_ctzll(fm));
-      if (lane == 0) pol.fail_cell = fc;
-      return false;
-    }
-    uint32_t old = v;
-    if (need) old = SMX_A_CAS(&sh.stamp[c], v, me);
-    const bool got = need && old == v;
-    const bool failC = need && old != v && old != me;           // somebody took it meanwhile
+    const unsigned long long fm = __ballot(failA || failCl || failB);
+    uint32_t old2 = old;
+    if (!fm && takeover) old2 = SMX_A_CAS(&sh.stamp[c], old, me);
+    const bool got = (fresh && !failCl) || (takeover && !fm && old2 == old);
+    const bool failC = takeover && !fm && old2 != old && old2 != me;          // somebody took it meanwhile
+    const uint32_t prev = fresh ? 0u : old;
     const unsigned long long gm = __ballot(got);
     const uint32_t cnt = (uint32_t)__popcll(gm);
-    if (cnt) {
+    if (cnt) {                                               // (cells acquired are logged even if the block fails)
       // lane 0 makes sure the log chunks for entries [base, base+cnt) exist
       uint32_t base = 0, cidA = 0, cidB = 0, ovf = 0;
       if (lane == 0) {
@@ -100,7 +114,7 @@ SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) {
       }
       base = (uint32_t)rfl((int)base); cidA = (uint32_t)rfl((int)cidA); cidB = (uint32_t)rfl((int)cidB); ovf = (uint32_t)rfl((int)ovf);
       if (ovf) {                                             // log full: give the cells back, the attempt is void
-        if (got) SMX_A_STORE(&sh.stamp[c], v);
+        if (got) SMX_A_STORE(&sh.stamp[c], prev);
         if (lane == 0) pol.fail_cell = (uint32_t)c0;
         return false;
       }
@@ -108,7 +122,7 @@ SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) {
         const uint32_t e = base + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull));
         const uint32_t cid = (e / LOG_CHUNK == base / LOG_CHUNK) ? cidA : cidB;
         SpecLog* ent = sh.arena + (size_t)cid * LOG_CHUNK + (e % LOG_CHUNK);
-        ent->cell = (uint32_t)c; ent->prev = v; ent->rec = r; ent->wtrack = utr; ent->windfreq = uwf; ent->flags = fl;
+        ent->cell = (uint32_t)c; ent->prev = prev; ent->rec = r; ent->wtrack = utr; ent->windfreq = uwf; ent->flags = fl;
       }
       if (lane == 0) {
         pol.nlog = base + cnt;
@@ -118,17 +132,17 @@ SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b) {
       while (dm) {                                           // cells taken over from tentative particles: dependencies
         const int dk = __builtin_ctzll(dm);
         dm &= dm - 1;
-        const uint32_t owner = (uint32_t)__shfl((int)v, dk) - 1u;
+        const uint32_t owner = (uint32_t)__shfl((int)old, dk) - 1u;
         if (lane == 0) pol.add_dep(owner);
       }
     }
-    const unsigned long long cm = __ballot(failC);
-    if (cm) {
-      const uint32_t fc = (uint32_t)__shfl((int)(uint32_t)c, __builtin_ctzll(cm));
+    const unsigned long long bad = fm | __ballot(failC);
+    if (bad) {
+      const uint32_t fc = (uint32_t)__shfl((int)(uint32_t)c, __builtin_ctzll(bad));
       if (lane == 0) pol.fail_cell = fc;
-      ok = false;
+      return false;
     }
-    if (ok && lane == 0) pol.last = c0;
+    if (lane == 0) pol.last = c0;
   }
   if constexpr (std::is_same<P, ScoutPolicy>::value) {       // read-only scout: the block's cells go to the footprint list
     ScoutPolicy& pol = sim.pol;
@@ -162,12 +176,12 @@ template <class P>
 SMX_D void water_loop_coop(Sim<P>& sim, Water& p, bool toplevel, bool resume) {
   const bool l0 = coop_lane() == 0;
   Blk A, B;
-  if (resume) { if (l0) sim.pol.load_blk(A); }
+  int ucx = 0, ucy = 0;                                      // centre of the block the particle holds (wave-uniform)
+  if (resume) { if (l0) { sim.pol.load_blk(A); ucx = p.ix; ucy = p.iy; } ucx = rfl(ucx); ucy = rfl(ucy); }
   else {
-    int cx = 0, cy = 0;
-    if (l0) { p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y); cx = p.ix; cy = p.iy; }
-    cx = rfl(cx); cy = rfl(cy);
-    if (!coop_load_block<P, 0>(sim, cx, cy, A)) { if (l0) sim.ab = true; return; }
+    if (l0) { p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y); ucx = p.ix; ucy = p.iy; }
+    ucx = rfl(ucx); ucy = rfl(ucy);
+    if (!coop_load_block<P, 0>(sim, ucx, ucy, A)) { if (l0) sim.ab = true; return; }
   }
   while (true) {
 #define SMX_COOP_WATER_STEP(CUR, NXT)                                                                         \
@@ -179,10 +193,11 @@ SMX_D void water_loop_coop(Sim<P>& sim, Water& p, bool toplevel, bool resume) {
       int nx = 0, ny = 0;                                                                                     \
       if (l0) { nx = (int)roundf(p.pos.x); ny = (int)roundf(p.pos.y); }                                       \
       nx = rfl(nx); ny = rfl(ny);                                                                             \
-      const bool ok = coop_load_block<P, 0>(sim, nx, ny, NXT);                                                \
+      const bool ok = coop_load_block<P, 0>(sim, nx, ny, NXT, true, ucx, ucy);                                \
       int r = -1;                                                                                             \
       if (l0) { if (ok) r = sim.water_interact(p, CUR, NXT, true); else sim.ab = true; }                      \
       r = rfl(r);                                                                                             \
+      ucx = nx; ucy = ny;                                                                                     \
       if (r <= 0) { if (l0 && r < 0 && sim.susp_ok) { sim.susp = 2; sim.pol.save_blk(CUR); } return; }        \
     }
     SMX_COOP_WATER_STEP(A, B)
@@ -195,16 +210,17 @@ template <class P>
 SMX_D void wind_loop_coop(Sim<P>& sim, Wind& p, bool resume) {
   const bool l0 = coop_lane() == 0;
   Blk A, B;
-  if (resume) { if (l0) sim.pol.load_blk(A); }
+  int ucx = 0, ucy = 0;
+  if (resume) { if (l0) { sim.pol.load_blk(A); ucx = p.ix; ucy = p.iy; } ucx = rfl(ucx); ucy = rfl(ucy); }
   else {
-    int live = 0, cx = 0, cy = 0;
+    int live = 0;
     if (l0) {
       live = !(sim.soils[p.contains].suspension == 0.0);     // wind.h:56-57
-      p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y); cx = p.ix; cy = p.iy;
+      p.ix = (int)roundf(p.pos.x); p.iy = (int)roundf(p.pos.y); ucx = p.ix; ucy = p.iy;
     }
     if (!rfl(live)) return;
-    cx = rfl(cx); cy = rfl(cy);
-    if (!coop_load_block<P, 1>(sim, cx, cy, A)) { if (l0) sim.ab = true; return; }
+    ucx = rfl(ucx); ucy = rfl(ucy);
+    if (!coop_load_block<P, 1>(sim, ucx, ucy, A)) { if (l0) sim.ab = true; return; }
   }
   while (true) {
 #define SMX_COOP_WIND_STEP(CUR, NXT)                                                                          \
@@ -216,10 +232,11 @@ SMX_D void wind_loop_coop(Sim<P>& sim, Wind& p, bool resume) {
       int nx = 0, ny = 0;                                                                                     \
       if (l0) { nx = (int)roundf(p.pos.x); ny = (int)roundf(p.pos.y); }                                       \
       nx = rfl(nx); ny = rfl(ny);                                                                             \
-      const bool ok = coop_load_block<P, 1>(sim, nx, ny, NXT);                                                \
+      const bool ok = coop_load_block<P, 1>(sim, nx, ny, NXT, true, ucx, ucy);                                \
       int r = -1;                                                                                             \
       if (l0) { if (ok) r = sim.wind_interact(p, CUR, NXT, true); else sim.ab = true; }                       \
       r = rfl(r);                                                                                             \
+      ucx = nx; ucy = ny;                                                                                     \
       if (r <= 0) { if (l0 && r < 0 && sim.susp_ok) { sim.susp = 2; sim.pol.save_blk(CUR); } return; }        \
     }
     SMX_COOP_WIND_STEP(A, B)
