@@ -66,7 +66,7 @@ SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b, bool have_prev =
     //                lower particle -> status load + second CAS (two more trips; rare outside the late rounds)
     SpecPolicy& pol = sim.pol;
     const SpecShared& sh = pol.sh;
-    const uint32_t me = pol.me, pid = pol.pid;
+    const uint32_t me = pol.me, pid = pol.pid, cbase = sh.ctrl[SC_BASE];
     const bool mine = valid && have_prev && (uint32_t)(nx - pcx + 1) <= 2u && (uint32_t)(ny - pcy + 1) <= 2u;
     const bool need = valid && !mine;
     uint32_t cl = NOCLAIM, fl = 0u, old = me;
@@ -82,8 +82,9 @@ SMX_D bool coop_load_block(Sim<P>& sim, int cx, int cy, Blk& b, bool have_prev =
     const bool failCl = (fresh || (other && !failA)) && cl < pid;           // yield to a lower pending particle
     if (fresh && failCl) SMX_A_STORE(&sh.stamp[c], 0u);
     const bool takeover = other && !failA && !failCl;
+    // owners below the committed prefix (ctrl[SC_BASE], fixed while this kernel runs) need no status load
     uint32_t st = ST_COMMITTED;
-    if (takeover) st = sh.part[old - 1].status;
+    if (takeover && old - 1u >= cbase) st = sh.part[old - 1].status;
     const bool failB = takeover && (st == ST_PENDING || st == ST_DONE_NEW || st == ST_SUSPENDED);
     const bool dep = takeover && st == ST_DONE_OLD;
     const unsigned long long fm = __ballot(failA || failCl || failB);

@@ -586,45 +586,104 @@ struct Sim {
 #undef X
     return sort8(hs);
   }
-  // the neighbour loop (particle.h:62-99) from index i on; the block is kept exact (views written back).
+  // Which neighbours can possibly move material against the CURRENT centre: bit k is clear only if neighbour k is
+  // provably below its limit (the conservative test of cascade_precheck, per neighbour), i.e. the loop body would
+  // `continue` on it (particle.h:76-79) without touching anything.
+  SMX_D uint32_t cascade_candidates(const Blk& b) const {
+    const double sc = (double)(float)s.scale;
+    const View& ctr = b.v8;
+    const double hC = vh(ctr);
+    bool same = true;
+#define X(k) same &= (b.v##k.type == ctr.type);
+    SMX_FOR8(X)
+#undef X
+    uint32_t m = 0;
+    if (same) {
+      const double lim = (double)soils[vsurf(ctr)].maxdiff * 0.9999;
+#define X(k) m |= (!(fabs(hC - vh(b.v##k)) * sc * 0.0125 < lim)) ? (1u << k) : 0u;
+      SMX_FOR8(X)
+#undef X
+      return m & b.inb;
+    }
+#define X(k)                                                                                   \
+    if ((b.inb >> k) & 1) {                                                                    \
+      const double dh = hC - vh(b.v##k);                                                       \
+      const uint32_t ty = dh > 0 ? vsurf(ctr) : vsurf(b.v##k);                                 \
+      const double lim = (double)soils[ty].maxdiff * 0.9999;                                   \
+      if (!(fabs(dh) * sc * 0.0125 < lim)) m |= 1u << k;                                       \
+    }
+    SMX_FOR8(X)
+#undef X
+    return m;
+  }
+  // one neighbour of the loop (particle.h:62-99); the block is kept exact (views written back).
+  // 0: nothing moved, 1: material moved, 2: moved and a section was exhausted (the caller may recurse there)
+  SMX_D int cascade_visit(int ix, int iy, Blk& b, View& ctr, int k, bool& moved) {
+    const double sc = (double)(float)s.scale, d80 = (double)80.0f;
+    View nb = blk_get(b, k);
+    const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
+    const size_t cn = cidx(nx, ny);
+    const float diff = (float)((vh(ctr) - vh(nb)) * sc / d80);
+    if (diff == 0) return 0;
+    const bool down = diff > 0;                             // the centre is the higher column
+    const View& T = down ? ctr : nb;
+    const uint32_t type = vsurf(T);
+    const float excess = fabsf(diff) - soils[type].maxdiff;
+    if (excess <= 0) return 0;
+    float transfer = soils[type].settling * excess / 2.0f;
+    const double tsize = T.size;
+    if ((double)transfer > tsize) transfer = (float)tsize;
+    const uint32_t casc = soils[type].cascades;
+    bool recascade = false;
+    if (down) { if (remove_v(ix, iy, b.c0, ctr, (double)transfer) != 0) recascade = true; add_v(nx, ny, cn, nb, (double)transfer, casc); }
+    else { if (remove_v(nx, ny, cn, nb, (double)transfer) != 0) recascade = true; add_v(ix, iy, b.c0, ctr, (double)transfer, casc); }
+    n_casc_tr++;
+    moved = true;
+    blk_put(b, k, nb);
+    b.v8 = ctr;
+    return recascade ? 2 : 1;
+  }
+  // the neighbour loop from sorted index i on. Neighbours that are provably below their limit are skipped without
+  // being looked at (the candidate mask is refreshed whenever the centre has changed).
   // Stops early (returning the neighbour code) when a section was exhausted and the caller may recurse there.
   SMX_D int cascade_loop(int ix, int iy, Blk& b, const Sorted& sn, int& i, bool may_recurse, bool& moved) {
-    const double sc = (double)(float)s.scale, d80 = (double)80.0f;
     View ctr = b.v8;
+    uint32_t cand = cascade_candidates(b);
     for (; i < sn.num; i++) {
       const int k = (sn.codes >> (4 * i)) & 15;
-      View nb = blk_get(b, k);
-      const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
-      const size_t cn = cidx(nx, ny);
-      const float diff = (float)((vh(ctr) - vh(nb)) * sc / d80);
-      if (diff == 0) continue;
-      const bool down = diff > 0;                           // the centre is the higher column
-      const View& T = down ? ctr : nb;
-      const uint32_t type = vsurf(T);
-      const float excess = fabsf(diff) - soils[type].maxdiff;
-      if (excess <= 0) continue;
-      float transfer = soils[type].settling * excess / 2.0f;
-      const double tsize = T.size;
-      if ((double)transfer > tsize) transfer = (float)tsize;
-      const uint32_t casc = soils[type].cascades;
-      bool recascade = false;
-      if (down) { if (remove_v(ix, iy, b.c0, ctr, (double)transfer) != 0) recascade = true; add_v(nx, ny, cn, nb, (double)transfer, casc); }
-      else { if (remove_v(nx, ny, cn, nb, (double)transfer) != 0) recascade = true; add_v(ix, iy, b.c0, ctr, (double)transfer, casc); }
-      n_casc_tr++;
-      moved = true;
-      blk_put(b, k, nb);
-      b.v8 = ctr;
+      if (!((cand >> k) & 1)) continue;
+      const int r = cascade_visit(ix, iy, b, ctr, k, moved);
       if (ab) return -1;
-      if (recascade && may_recurse) { i++; return k; }
+      if (r) cand = cascade_candidates(b);
+      if (r == 2 && may_recurse) { i++; return k; }
     }
     return -1;
   }
-  SMX_D void cascade_blk(int ix, int iy, Blk& b) {          // Particle::cascade(pos, .., 0) on a loaded block
+  // Particle::cascade(pos, .., 0) on a loaded block -- the water step's cascade. No sort: the visiting order
+  // (entry-time height descending, neighbour code ascending: particle.h:43-60, a stable sort of the code-ordered
+  // list) only matters among the neighbours that can move anything, so the loop repeatedly picks, among the
+  // current candidates, the first one AFTER the neighbour visited last. Typical cost: one visit, two mask scans.
+  SMX_D void cascade_blk(int ix, int iy, Blk& b) {
     n_casc++;
     if (!cascade_precheck(b)) return;
-    const Sorted sn = cascade_sort(b);
-    int i = 0; bool moved = false;
-    cascade_loop(ix, iy, b, sn, i, false, moved);
+#define X(k) const double e##k = vh(b.v##k);              /* entry-time heights */
+    SMX_FOR8(X)
+#undef X
+    double lh = INFINITY; int lc = -1;                       // the neighbour visited last
+    View ctr = b.v8;
+    bool moved = false;
+    while (true) {
+      uint32_t cand = cascade_candidates(b);
+      if (!cand) return;
+      double bh = -INFINITY; int bk = -1;
+#define X(k) if (((cand >> k) & 1) && (e##k < lh || (e##k == lh && k > lc)) && e##k > bh) { bh = e##k; bk = k; }
+      SMX_FOR8(X)
+#undef X
+      if (bk < 0) return;
+      lh = bh; lc = bk;
+      cascade_visit(ix, iy, b, ctr, bk, moved);
+      if (ab) return;
+    }
   }
   // Particle::cascade(pos, .., LOOP) (particle.h:24-101), LOOP = recursion budget (transferloop): water 0, wind 1
   // (wind.h:112,126,129). The one level of recursion is an explicit parent frame, so the neighbour loop exists
@@ -662,6 +721,52 @@ struct Sim {
       load_block<2>(ix, iy, b);
       if (ab) return moved;
       enter = false;
+    }
+  }
+
+  // Particle::cascade(pos, .., 1) -- the wind step's cascades (wind.h:112,126,129) -- on a block held in registers,
+  // in the sort-free form of cascade_blk. `o` is the other carried block, around (ox, oy): every column changed
+  // here is patched there too, so both stay exact images of the map. The one level of recursion the budget
+  // allows (a section was exhausted: particle.h:96-97) runs on the map itself (particle_cascade<0>); the parent
+  // then re-reads its block and goes on. Returns false if that happened: `b` is still exact, `o` no longer is.
+  SMX_D bool cascade_blk1(int ix, int iy, Blk& b, int ox, int oy, Blk& o, bool& moved) {
+    n_casc++;
+#define X(k) const double e##k = vh(b.v##k);              /* entry-time heights */
+    SMX_FOR8(X)
+#undef X
+    double lh = INFINITY; int lc = -1;                       // the neighbour visited last
+    View ctr = b.v8;
+    int budget = 1;
+    bool o_exact = true;
+    while (true) {
+      const uint32_t cand = cascade_candidates(b);
+      if (!cand) return o_exact;
+      double bh = -INFINITY; int bk = -1;
+#define X(k) if (((cand >> k) & 1) && (e##k < lh || (e##k == lh && k > lc)) && e##k > bh) { bh = e##k; bk = k; }
+      SMX_FOR8(X)
+#undef X
+      if (bk < 0) return o_exact;
+      lh = bh; lc = bk;
+      const int r = cascade_visit(ix, iy, b, ctr, bk, moved);
+      if (ab) return false;
+      if (r) {                                               // the two columns that changed, seen from the other block
+        const int kx = ix + nb_dx(bk), ky = iy + nb_dy(bk);
+        const int cdx = ix - ox, cdy = iy - oy, ndx = kx - ox, ndy = ky - oy;
+        if (cdx >= -1 && cdx <= 1 && cdy >= -1 && cdy <= 1) blk_put(o, code_rel(cdx, cdy), b.v8);
+        if (ndx >= -1 && ndx <= 1 && ndy >= -1 && ndy <= 1) blk_put(o, code_rel(ndx, ndy), blk_get(b, bk));
+      }
+      if (r == 2 && budget > 0) {                            // cascade(npos, .., --transferloop)
+        --budget;
+        const f2 cp = {(float)(ix + nb_dx(bk)), (float)(iy + nb_dy(bk))};
+        moved |= particle_cascade<0>(cp);
+        if (ab) return false;
+        const float fr = b.fr, tr = b.tr;
+        load_block<2>(ix, iy, b);                            // back in the parent: its block may have changed
+        b.fr = fr; b.tr = tr;
+        if (ab) return false;
+        ctr = b.v8;
+        o_exact = false;
+      }
     }
   }
 
@@ -889,18 +994,18 @@ struct Sim {
       }
       if (near) blk_put(nb, code_rel(rdx, rdy), cv);        // (npos == ipos: the centre of nb)
     }
-    bool stale = false;                                      // a cascade moved material: the map is ahead of the blocks
-    for (int q = 0; q < ncasc; q++) {
-      const f2 at = (q == 0) ? f2{(float)p.ix, (float)p.iy} : f2{(float)nx, (float)ny};
-      if (!stale) {
-        const bool any = (q == 0) ? cascade_precheck(cur) : cascade_precheck(nb);
-        if (!any) { n_casc++; continue; }
-      }
-      stale |= particle_cascade<1>(at);
+    bool nb_exact = true, mv = false;                        // nb is an exact image of the map around npos
+    if (ncasc >= 1) {                                        // cascade(ipos)
+      if (cascade_precheck(cur)) nb_exact = cascade_blk1(p.ix, p.iy, cur, nx, ny, nb, mv); else n_casc++;
+      if (ab) return 0;
+    }
+    if (ncasc == 2) {                                        // cascade(npos)
+      if (!nb_exact) { load_block<1>(nx, ny, nb); if (ab) return 0; nb_exact = true; }
+      if (cascade_precheck(nb)) cascade_blk1(nx, ny, nb, p.ix, p.iy, cur, mv); else n_casc++;
       if (ab) return 0;
     }
     p.ix = nx; p.iy = ny;
-    if (stale) load_block<1>(nx, ny, nb);                 // refresh the views
+    if (!nb_exact) load_block<1>(nx, ny, nb);             // refresh the views
     return ab ? 0 : 1;
   }
   SMX_D void wind_loop(Wind& p, bool resume = false) {       // SoilMachine.cpp:306

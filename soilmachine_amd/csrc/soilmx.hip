@@ -25,6 +25,7 @@
 #include "soil_serial.h"
 #include "soil_spec.h"
 #include <type_traits>
+#include <chrono>
 #include "soil_coop.h"
 #include "soil_noise.h"
 
@@ -721,6 +722,10 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
   }
   uint32_t np = (uint32_t)n > SPEC_WINDOW ? SPEC_WINDOW : (uint32_t)n, last_base = 0, stall = 0;
   bool fallback = false;
+  static const bool trace_rounds = [] { const char* e = getenv("SMX_TRACE_ROUNDS"); return e && atoi(e) != 0; }();
+  uint32_t prev_exec = 0, prev_sum = 0;
+  if (trace_rounds) HIPCHK(hipStreamSynchronize(st));
+  auto t_round = std::chrono::steady_clock::now();
   for (int round = 0;; round++) {
     HIPCHK(hipMemsetAsync(sh.claim, 0xFF, ctx->ncells * 4, st));
     hipLaunchKernelGGL(k_spec_claim, dim3(np), dim3(64), 0, st, sh);
@@ -740,6 +745,13 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
     HIPCHK(hipMemcpyAsync(ctx->h_ctrl, sh.ctrl, SC_COUNT * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const uint32_t* c = ctx->h_ctrl;
+    if (trace_rounds) {                                                   // SMX_TRACE_ROUNDS=1: one line per round on stderr
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[soilmx] %s round %3d: %7.3f ms  pending-in %4u  base %4u  executed %5u  longest %6u steps  aborts %u kills %u suspends %u\n",
+              wind ? "wind " : "water", round, std::chrono::duration<double, std::milli>(now - t_round).count(), np, c[SC_BASE],
+              c[SC_EXECUTED] - prev_exec, c[SC_SUM_MAXSTEPS] - prev_sum, c[SC_ABORTS], c[SC_KILLS], c[SC_SUSPENDS]);
+      prev_exec = c[SC_EXECUTED]; prev_sum = c[SC_SUM_MAXSTEPS]; t_round = now;
+    }
     if (c[SC_N] == 0) { fallback = true; break; }                       // no pool headroom: nothing was executed
     if (c[SC_BASE] == (uint32_t)n) break;
     np = c[SC_NPENDING];
