@@ -135,10 +135,11 @@ def main():
         # dominant kernel = the particle kernel with the largest summed HIP-event time (every launch is bracketed
         # by its own event pair on the context's stream inside libsoilmx)
         spec = engine == capi.ENGINE_SPECULATIVE
+        kspec = "k_spec_exec" if os.environ.get("SMX_COOP", "1") == "0" else "k_spec_exec_coop"   # soilmx.hip spec_phase
         kernels = {"water": (tm["ms_kernel_water"], tm["launches_kernel_water"], steps_w * B_WATER_STEP,
-                             "k_spec_exec<water>" if spec else "k_water_serial"),
+                             f"{kspec}<water>" if spec else "k_water_serial"),
                    "wind": (tm["ms_kernel_wind"], tm["launches_kernel_wind"], steps_d * B_WIND_STEP,
-                            "k_spec_exec<wind>" if spec else "k_wind_serial")}
+                            f"{kspec}<wind>" if spec else "k_wind_serial")}
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, nbytes, kname = kernels[dom]
         ach = (nbytes / max(launches, 1)) / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else 0.0

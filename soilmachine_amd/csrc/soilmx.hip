@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(64) k_spec_exec_coop(DevState s, SpecShared sh
   if (blockIdx.x >= sh.ctrl[SC_NPENDING]) return;
   spec_exec_one_coop<WIND>(s, soils_sh, sh, sh.pending[blockIdx.x]);
 }
-__global__ void __launch_bounds__(256) k_spec_boundary(DevState s, SpecShared sh) {
+__global__ void __launch_bounds__(1024) k_spec_boundary(DevState s, SpecShared sh) {   // ONE workgroup: the round barrier
   __shared__ SpecWork w;
   spec_boundary_team(s, sh, w, threadIdx.x, blockDim.x, []() { __syncthreads(); });
 }
@@ -741,7 +741,7 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
         else hipLaunchKernelGGL(k_spec_exec<false>, dim3((np + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
       }
     }
-    hipLaunchKernelGGL(k_spec_boundary, dim3(1), dim3(256), 0, st, ctx->d, sh);
+    hipLaunchKernelGGL(k_spec_boundary, dim3(1), dim3(1024), 0, st, ctx->d, sh);
     HIPCHK(hipMemcpyAsync(ctx->h_ctrl, sh.ctrl, SC_COUNT * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const uint32_t* c = ctx->h_ctrl;

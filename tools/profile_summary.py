@@ -25,7 +25,9 @@ if __name__ == "__main__":
     wa, wn = counters(write_csv)
     sa, sn = counters(sq_csv)
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
-    names = {"k_spec_exec<true>": "k_spec_exec<wind>", "k_spec_exec<false>": "k_spec_exec<water>"}
+    names = {"k_spec_exec<true>": "k_spec_exec<wind>", "k_spec_exec<false>": "k_spec_exec<water>",
+             "k_spec_exec_coop<true>": "k_spec_exec_coop<wind>", "k_spec_exec_coop<false>": "k_spec_exec_coop<water>",
+             "k_spec_scout_coop<true>": "k_spec_scout_coop<wind>", "k_spec_scout_coop<false>": "k_spec_scout_coop<water>"}
     pmc = {"workload_size": 4096, "unit_note": "FETCH_SIZE/WRITE_SIZE are KiB as reported by rocprofv3 on gfx950; narrow scattered accesses are "
            "uncalibrated (MI355X_MICROARCH.md §HBM says wide streams read 2x the reported FETCH_SIZE) -- bytes below use the raw value x 1024",
            "kernels": {}}
