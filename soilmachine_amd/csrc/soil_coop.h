@@ -247,13 +247,24 @@ SMX_D void wind_loop_coop(Sim<P>& sim, Wind& p, bool resume) {
 }
 
 // What follows a top-level particle's loop -- flood, water-table cascade, nested particles (water.h:123-283) -- is
-// rare, long and scalar. It is kept OUT of line: inlined and specialised into the wave kernel it pushed the step
-// loop's register allocation over the edge (and the -O3 build of exactly that variant produced wrong maps on
-// gfx950 while -O2 and the out-of-line build are bit-exact; see DESIGN.md "Cooperative block access").
+// rare, long and scalar, and is kept OUT of line. Two reasons, both measured on gfx950:
+//  * inlined and specialised into the wave kernel it pushed the step loop's register allocation over the edge, and
+//    the -O3 build of exactly that variant produced wrong maps (DESIGN.md "A compiler note");
+//  * it must not take the step loop's objects by reference: an object whose address escapes into a call lives in
+//    scratch memory for its whole life, and the loop then pays a scratch access for every touch of the particle
+//    and of the policy's cursors (PMC: 78 vector-memory loads per water step, 63 % of wave cycles waiting).
+// So policy and particle travel BY VALUE, the tail builds its own Sim, and the results come back by value.
+template <class P> struct TailRes { P pol; Water p; bool ab; uint32_t steps; };
 template <class P>
-__attribute__((noinline)) SMX_D void coop_water_tail(Sim<P>& sim, Water& p) {
+__attribute__((noinline)) SMX_D TailRes<P> coop_water_tail(DevState s, const SoilP* soils, P pol, Water p) {
+  TailRes<P> r{pol, p, false, 0u};
+  Sim<P> sim(s, soils, r.pol);
   Frame st[MAX_FRAMES]; int depth = 0;
-  sim.water_drive(p, true, true, st, depth, false, true);
+  sim.water_drive(r.p, true, true, st, depth, false, true);
+  r.ab = sim.ab;
+  r.steps = (uint32_t)sim.n_steps_w_all;
+  sim.flush_counters();
+  return r;
 }
 
 // round 0: the read-only trajectory of one particle, walked by a whole wave (cf. spec_scout_one in soil_spec.h)
@@ -275,7 +286,11 @@ SMX_D void spec_scout_one_coop(const DevState& s, const SoilP* soils, const Spec
     p.friction = 0.f; p.surface = p.contains = 0;
     if (l0) sim.water_init(p, rx, ry);
     water_loop_coop(sim, p, true, false);
-    if (l0) coop_water_tail(sim, p);                         // (read-only: claims where a flood would act, water.h:123)
+    if (l0) {                                                // (read-only: claims where a flood would act, water.h:123)
+      TailRes<ScoutPolicy> r = coop_water_tail<ScoutPolicy>(s, soils, pol, p);
+      r.pol.finish();
+    }
+    return;
   }
   if (l0) pol.finish();
 }
@@ -311,7 +326,14 @@ SMX_D void spec_exec_one_coop(const DevState& s, const SoilP* soils, const SpecS
     }
     if (!rfl(l0 && sim.ab ? 1 : 0)) water_loop_coop(sim, p, true, resume);
     if (!l0) return;
-    if (!sim.ab && !sim.susp) coop_water_tail(sim, p);
+    if (!sim.ab && !sim.susp) {
+      const uint32_t steps = (uint32_t)sim.n_steps_w_all;
+      sim.flush_counters();                                  // the loop's counters travel inside the policy
+      TailRes<SpecPolicy> r = coop_water_tail<SpecPolicy>(s, soils, pol, p);
+      SMX_A_MAX(&sh.ctrl[SC_ROUND_MAXSTEPS], steps + r.steps);
+      if (r.ab || r.pol.overflow) r.pol.self_rollback(s); else r.pol.finish_done(s);
+      return;
+    }
     SMX_A_MAX(&sh.ctrl[SC_ROUND_MAXSTEPS], (uint32_t)sim.n_steps_w_all);
     if (sim.susp && !pol.overflow) { sim.flush_counters(); sh.ckpt[pid].w = p; pol.suspend(s); return; }
   }
