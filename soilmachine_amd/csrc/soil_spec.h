@@ -419,8 +419,11 @@ struct SpecWork {                             // staged per-particle state, inde
   uint8_t st[SPEC_WINDOW], kl[SPEC_WINDOW], ab[SPEC_WINDOW], dov[SPEC_WINDOW];
   uint16_t nested[SPEC_WINDOW];               // <= SPEC_MAXNEST
   uint32_t noff[SPEC_WINDOW];
-  uint16_t list[SPEC_WINDOW];                 // particles that need a rollback / stamp release (descending)
+  uint16_t list[SPEC_WINDOW];                 // particles that need a rollback / stamp release (descending);
+                                              // reused by the commit step: nfree of the committed prefix
   uint32_t nlist, changed, base, end;
+  uint32_t ncommit, rbase;                    // particles committed now; running (uncapped) reclaim cursor
+  unsigned long long acc[SPEC_NCTR + 3];      // commit sums: ctr[0..NCTR), live_delta, nested, freed nodes
 };
 
 template <class SyncF>
@@ -460,7 +463,9 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
       }
     }
     sync();
-    if (!w.changed) break;
+    const bool again = w.changed != 0;                     // everybody reads the verdict before thread 0 resets it
+    sync();
+    if (!again) break;
   }
   // ---- 2. rollback list, highest id first
   if (tid == 0) {
@@ -470,15 +475,18 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
       if ((done && w.kl[i]) || (!done && w.ab[i])) w.list[m++] = (uint16_t)i;
     }
     w.nlist = m;
+    w.rbase = ctrl[SC_NRECLAIM];                           // reclaim cursor of this pass (written back once, at the end)
   }
   sync();
+  // The whole team works on one particle at a time (descending ids): cells and reclaimed nodes are spread over
+  // the threads; thread 0 only unwinds the (rare) buried-section records, whose duplicates must go newest-first.
   for (uint32_t j = 0; j < w.nlist; j++) {
     const uint32_t i = w.list[j], p = base + i;
     SpecPart& q = sh.part[p];
     const bool done = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED);
     const uint32_t nl = q.nlog;
     if (done) {                                            // killed: restore data and stamps
-      // duplicate NODE entries must be unwound newest-first: thread 0 handles node entries, cells are unique
+      const uint32_t na = q.nalloc, rb = w.rbase;
       for (uint32_t k = tid; k < nl; k += nt) {
         const SpecLog* e = spec_entry(sh, p, k);
         if (e->cell & NODE_ENTRY) continue;
@@ -486,16 +494,18 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
         s.cells[c] = e->rec; s.wtrack[fi] = e->wtrack; s.windfreq[fi] = e->windfreq; s.flags[c] = (uint8_t)e->flags;
         sh.stamp[c] = e->prev;
       }
-      if (tid == 0) {
-        if (q.nnode)                                        // buried sections changed by seep(): oldest snapshot must win
-          for (uint32_t k = nl; k-- > 0;) {
-            const SpecLog* e = spec_entry(sh, p, k);
-            if (e->cell & NODE_ENTRY) s.pool[e->cell & ~NODE_ENTRY] = e->rec;
-          }
-        for (uint32_t k = 0; k < q.nalloc; k++) {
-          const uint32_t r = ctrl[SC_NRECLAIM]++;
-          if (r < sh.reclaim_cap) sh.reclaim[r] = sh.alloc_log[(size_t)p * MAX_NODELOG + k]; else ctrl[SC_RECLAIM_LOST]++;
+      for (uint32_t k = tid; k < na; k += nt)              // nodes it allocated go back to the pool at phase end
+        if (rb + k < sh.reclaim_cap) sh.reclaim[rb + k] = sh.alloc_log[(size_t)p * MAX_NODELOG + k];
+      if (tid == 0 && q.nnode)                              // buried sections changed by seep(): oldest snapshot must win
+        for (uint32_t k = nl; k-- > 0;) {
+          const SpecLog* e = spec_entry(sh, p, k);
+          if (e->cell & NODE_ENTRY) s.pool[e->cell & ~NODE_ENTRY] = e->rec;
         }
+      sync();                                              // everybody has read q.nalloc / w.rbase
+      if (tid == 0) {
+        const uint32_t cap = sh.reclaim_cap, hi = rb + na;
+        if (hi > cap) ctrl[SC_RECLAIM_LOST] += hi - (rb > cap ? rb : cap);
+        w.rbase = hi;
         q.nalloc = 0; q.nfree = 0; q.ndeps = 0; q.dep_overflow = 0; q.nested = 0; q.overflow = 0;
         ctrl[SC_KILLS]++;
         w.st[i] = ST_PENDING; w.nested[i] = 0;
@@ -509,22 +519,46 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
     }
     sync();
   }
-  // ---- 3. promote, commit the finished prefix, pending list
+  // ---- 3. promote, commit the finished prefix (team-parallel: counters by LDS sums, freed nodes by ranges)
   if (tid == 0) {
     uint32_t b = 0;                                        // number of particles committed now
     for (uint32_t i = 0; i < cnt; i++) if (w.st[i] == ST_DONE_NEW) w.st[i] = ST_DONE_OLD;
-    while (b < cnt && w.st[b] == ST_DONE_OLD) {
-      SpecPart& q = sh.part[base + b];
-      w.st[b] = ST_COMMITTED;
-      for (int k = 0; k < SPEC_NCTR; k++) s.ctr[k] += q.ctr[k];
-      s.ctr[C_LIVE_SECTIONS] += (unsigned long long)q.live_delta;
-      ctrl[SC_NESTED_COMMITTED] += q.nested;
-      for (uint32_t k = 0; k < q.nfree; k++) {
-        const uint32_t r = ctrl[SC_NRECLAIM]++;
-        if (r < sh.reclaim_cap) sh.reclaim[r] = sh.free_log[(size_t)(base + b) * MAX_NODELOG + k]; else ctrl[SC_RECLAIM_LOST]++;
-      }
-      b++;
+    while (b < cnt && w.st[b] == ST_DONE_OLD) w.st[b++] = ST_COMMITTED;
+    w.ncommit = b;
+    for (int k = 0; k < SPEC_NCTR + 3; k++) w.acc[k] = 0;
+  }
+  sync();
+  const uint32_t b = w.ncommit;
+  for (uint32_t i = tid; i < b; i += nt) w.list[i] = (uint16_t)sh.part[base + i].nfree;   // <= MAX_NODELOG
+  sync();
+  {
+    unsigned long long a[SPEC_NCTR + 2];
+    for (int k = 0; k < SPEC_NCTR + 2; k++) a[k] = 0;
+    bool any = false;
+    const uint32_t rb = w.rbase;
+    for (uint32_t i = tid; i < b; i += nt) {
+      const SpecPart& q = sh.part[base + i];
+      for (int k = 0; k < SPEC_NCTR; k++) a[k] += q.ctr[k];
+      a[SPEC_NCTR] += (unsigned long long)q.live_delta; a[SPEC_NCTR + 1] += q.nested;
+      any = true;
+      uint32_t off = rb;                                   // deterministic: particle i's nodes follow those of 0..i-1
+      for (uint32_t k = 0; k < i; k++) off += w.list[k];
+      const uint32_t nf = w.list[i];
+      for (uint32_t k = 0; k < nf; k++)
+        if (off + k < sh.reclaim_cap) sh.reclaim[off + k] = sh.free_log[(size_t)(base + i) * MAX_NODELOG + k];
     }
+    if (any) for (int k = 0; k < SPEC_NCTR + 2; k++) if (a[k]) SMX_A_ADD(&w.acc[k], a[k]);
+  }
+  sync();
+  if (tid == 0) {
+    for (int k = 0; k < SPEC_NCTR; k++) if (w.acc[k]) s.ctr[k] += w.acc[k];
+    if (w.acc[SPEC_NCTR]) s.ctr[C_LIVE_SECTIONS] += w.acc[SPEC_NCTR];
+    ctrl[SC_NESTED_COMMITTED] += (uint32_t)w.acc[SPEC_NCTR + 1];
+    uint32_t rb = w.rbase, nfreed = 0;
+    for (uint32_t i = 0; i < b; i++) nfreed += w.list[i];
+    const uint32_t cap = sh.reclaim_cap, hi = rb + nfreed;
+    if (hi > cap) ctrl[SC_RECLAIM_LOST] += hi - (rb > cap ? rb : cap);
+    ctrl[SC_NRECLAIM] = hi;
     uint32_t np = 0, nest = ctrl[SC_NESTED_COMMITTED];
     for (uint32_t i = b; i < cnt; i++) {
       if (w.st[i] == ST_PENDING) { w.noff[i] = nest; sh.pending[np++] = base + i; }
@@ -650,28 +684,53 @@ SMX_D void spec_end(const DevState& s, const SpecShared& sh, uint32_t nparticles
 // A pending particle's predicted footprint = cells of its scout run + cells its previous attempt really touched +
 // the cell that attempt failed at. spec_claim_one publishes it (claim[c] = min pending id); spec_blocked asks
 // whether a LOWER pending particle wants any of those cells -- then this particle sits the round out.
+// The walk is batched four cells deep: `f` gets four cells at a time (NOCLAIM = none) so that the index loads of
+// a batch -- and whatever f loads per cell -- are in flight together (the lists were written by earlier kernels
+// and come from HBM); f returning false ends the walk.
 template <class F>
 SMX_D void spec_for_footprint(const SpecShared& sh, uint32_t pid, uint32_t lane, uint32_t nl, F f) {
   const SpecPart& q = sh.part[pid];
   const uint32_t sl = sh.scout_len[pid];
   const uint32_t* sc = sh.scout_cells + (size_t)pid * sh.scout_cap;
-  for (uint32_t k = lane; k < sl; k += nl) if (!f(sc[k])) return;
+  for (uint32_t k = lane; k < sl; k += 4u * nl) {
+    const uint32_t k1 = k + nl, k2 = k + 2u * nl, k3 = k + 3u * nl;
+    const uint32_t c[4] = {sc[k], k1 < sl ? sc[k1] : NOCLAIM, k2 < sl ? sc[k2] : NOCLAIM, k3 < sl ? sc[k3] : NOCLAIM};
+    if (!f(c)) return;
+  }
   if (q.attempts != 0) {
-    for (uint32_t k = lane; k < q.nlog; k += nl) {
-      const SpecLog* e = spec_entry(sh, pid, k);
-      if (e->cell & NODE_ENTRY) continue;
-      if (!f(e->cell)) return;
+    const uint32_t nlog = q.nlog;
+    for (uint32_t k = lane; k < nlog; k += 4u * nl) {
+      uint32_t c[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; u++) {
+        const uint32_t ku = k + u * nl;
+        c[u] = ku < nlog ? spec_entry(sh, pid, ku)->cell : NOCLAIM;
+        if (c[u] & NODE_ENTRY) c[u] = NOCLAIM;             // a pool-node record, not a cell
+      }
+      if (!f(c)) return;
     }
-    if (lane == 0 && q.fail_cell != NOCLAIM) f(q.fail_cell);
+    if (lane == 0 && q.fail_cell != NOCLAIM) { const uint32_t c[4] = {q.fail_cell, NOCLAIM, NOCLAIM, NOCLAIM}; f(c); }
   }
 }
-// (lane, nl): the footprint is walked by a team of nl lanes, lane `lane` takes every nl-th cell
+// (lane, nl): the footprint is walked by a team of nl lanes, lane `lane` takes every nl-th cell.
+// The minimum is an unconditional atomic whose result nobody waits for (most cells have a single claimant, so a
+// load-and-compare in front of it only adds a round trip).
 SMX_D void spec_claim_one(const SpecShared& sh, uint32_t pid, uint32_t lane, uint32_t nl) {
-  spec_for_footprint(sh, pid, lane, nl, [&](uint32_t c) { if (SMX_A_LOAD(&sh.claim[c]) > pid) SMX_A_MIN(&sh.claim[c], pid); return true; });
+  spec_for_footprint(sh, pid, lane, nl, [&](const uint32_t (&c)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (c[u] != NOCLAIM) (void)SMX_A_MIN(&sh.claim[c[u]], pid);
+    return true;
+  });
 }
 SMX_D bool spec_blocked(const SpecShared& sh, uint32_t pid, uint32_t lane, uint32_t nl) {
   bool blocked = false;
-  spec_for_footprint(sh, pid, lane, nl, [&](uint32_t c) { if (SMX_A_LOAD(&sh.claim[c]) < pid) { blocked = true; return false; } return true; });
+  spec_for_footprint(sh, pid, lane, nl, [&](const uint32_t (&c)[4]) {
+    uint32_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = c[u] != NOCLAIM ? SMX_A_LOAD(&sh.claim[c[u]]) : NOCLAIM;
+    if (v[0] < pid || v[1] < pid || v[2] < pid || v[3] < pid) { blocked = true; return false; }
+    return true;
+  });
   return blocked;
 }
 

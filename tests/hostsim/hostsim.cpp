@@ -18,6 +18,7 @@
 #include "../../soilmachine_amd/csrc/soil_spec.h"
 #include <type_traits>
 #include "../../soilmachine_amd/csrc/soil_coop.h"
+#include <pthread.h>
 #include <thread>
 #include <algorithm>
 #include <random>
@@ -240,6 +241,8 @@ template <class F> static void parallel_for(uint32_t n, int nthreads, F f, unsig
     th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nthreads) f(order[i]); });
   for (auto& t : th) t.join();
 }
+static int g_boundary_threads = 1;
+extern "C" void hs_set_boundary_threads(int n) { g_boundary_threads = n < 1 ? 1 : n; }
 template <bool WIND>
 static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) {
   if (n == 0) return 0;
@@ -258,7 +261,19 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
     if (sh.mode & 1u) parallel_for(np, nthreads, [&](uint32_t i) { const uint32_t pid = sh.pending[i]; sh.part[pid].blocked = spec_blocked(sh, pid, 0u, 1u) ? 1u : 0u; }, 0);
     const bool coop = (sh.mode & 4u) != 0;                   // mode bit 2 (host only): the wave-loop structure of soil_coop.h
     parallel_for(np, nthreads, [&](uint32_t i) { if (coop) spec_exec_one_coop<WIND>(s, s.soils, sh, sh.pending[i]); else spec_exec_one<WIND>(s, s.soils, sh, sh.pending[i]); }, shuffle ? shuffle + 2 + sh.ctrl[SC_ROUNDS] : 0);
-    { static SpecWork* w = new SpecWork(); spec_boundary_team(s, sh, *w, 0u, 1u, []() {}); }
+    {
+      static SpecWork* w = new SpecWork();
+      const int bt = g_boundary_threads;                     // >1: the boundary runs as a TEAM (threads + barrier), as on the device
+      if (bt <= 1) spec_boundary_team(s, sh, *w, 0u, 1u, []() {});
+      else {
+        pthread_barrier_t bar; pthread_barrier_init(&bar, nullptr, (unsigned)bt);
+        std::vector<std::thread> th;
+        for (int t = 0; t < bt; t++)
+          th.emplace_back([&, t]() { spec_boundary_team(s, sh, *w, (uint32_t)t, (uint32_t)bt, [&]() { pthread_barrier_wait(&bar); }); });
+        for (auto& t : th) t.join();
+        pthread_barrier_destroy(&bar);
+      }
+    }
     if (sh.ctrl[SC_NPENDING] == 0 && sh.ctrl[SC_BASE] == n) break;
     if (sh.ctrl[SC_BASE] == last_base) stall++; else { stall = 0; last_base = sh.ctrl[SC_BASE]; }
     if (stall >= 8 || sh.ctrl[SC_NESTED_COMMITTED] > SPEC_MAXNEST - 64) { fell_back = 1; break; }

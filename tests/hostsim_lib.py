@@ -46,6 +46,7 @@ def lib():
         L.hs_spec_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, vp]
         L.hs_spec_water.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint, vp]
         L.hs_spec_wind.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint, vp]
+        L.hs_set_boundary_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -97,6 +98,11 @@ class HostSim:
 
     def tick(self, nwater, nwind, dowater=True, dowind=True):
         self.L.hs_tick(self.h, nwater, nwind, int(dowater), int(dowind))
+
+    @staticmethod
+    def set_boundary_threads(n: int):
+        """Team size of the round boundary (1 = scalar; >1 = threads + barrier, the shape the device kernel runs)."""
+        lib().hs_set_boundary_threads(int(n))
 
     def spec_tick(self, nwater, nwind, dowater=True, dowind=True, nthreads=8, scout=1 | (3 << 4), shuffle=0):
         """One tick with the speculative engine emulated by `nthreads` host threads.

@@ -55,9 +55,17 @@ def test_device_sources_reproduce_reference_digests(case):
 
 
 # ---------------------------------------------------------------- speculative engine (threads emulate the waves)
+@pytest.fixture(params=[1, 5], ids=["boundary-scalar", "boundary-team5"])
+def boundary_team(request):
+    """The round boundary as one thread, and as a team of 5 threads with a barrier (the device runs 1024)."""
+    HostSim.set_boundary_threads(request.param)
+    yield request.param
+    HostSim.set_boundary_threads(1)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 7])            # bit 2: the wave-loop structure of soil_coop.h
 @pytest.mark.parametrize("case", ["default64", "rgps64", "rocksand48x80"])
-def test_speculative_protocol_is_exact(case, mode):
+def test_speculative_protocol_is_exact(case, mode, boundary_team):
     """stamps / claims / forwarding / kill closure / rollback / suspend-resume: whatever interleaving the 8 threads
     produce and whichever engine mode is on, the state after every tick equals the reference's."""
     soil, seed, dowind, ticks = SNAP_CASES[case]
