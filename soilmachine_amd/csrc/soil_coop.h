@@ -273,7 +273,7 @@ SMX_D void spec_scout_one_coop(const DevState& s, const SoilP* soils, const Spec
   const bool l0 = coop_lane() == 0;
   ScoutPolicy pol(sh, pid);
   Sim<ScoutPolicy> sim(s, soils, pol);
-  const uint32_t k = 2u * pid + 2u * sh.part[pid].noff;
+  const uint32_t k = 2u * pid;                               // particle id = slot of the draw-pair sequence
   const int ry = (int)(sh.draws[k] >> 1) % s.dimy, rx = (int)(sh.draws[k + 1] >> 1) % s.dimx;
   if constexpr (WIND) {
     Wind p;

@@ -21,9 +21,14 @@
 //   * boundary     : between rounds one workgroup computes the kill closure (flags, dependencies, rand()
 //                    offsets), rolls killed particles back in DESCENDING id order, commits the finished
 //                    prefix and rebuilds the pending list.
-//   * rand()       : spawn draws are the phase's stream at offset 2*(id + nested particles of lower ids); the
-//                    nested count of unfinished lower particles is speculated to be 0 and validated at every
-//                    boundary.
+//   * rand() SLOTS : the phase's rand() stream is a sequence of draw pairs ("slots"). The reference hands slot m to
+//                    the next top-level particle, or -- while a particle floods -- to the nested particles it spawns
+//                    (water.h:251), which take the slots right after their parent's. Particle ids ARE slot numbers:
+//                    id m spawns from draws 2m, 2m+1 and its nested particles use slots m+1, m+2, ...  Every slot
+//                    is run speculatively as a top-level particle; when a lower particle turns out to spawn k
+//                    nested ones, only the k slots they consume are voided (their tentative runs are undone) -- the
+//                    trajectories of all later slots stay valid, and the phase simply ends k slots later. The
+//                    phase is over when n top-level particles are committed.
 //   * suspend      : a particle that cannot acquire the block of its next step (claimed by a lower pending
 //                    particle, or held by one that is still running) does not throw its work away: it keeps its
 //                    cells, checkpoints {particle, carried block, log cursor} and resumes at that very step in the
@@ -76,6 +81,11 @@ constexpr int MAX_CHUNKS = 1024;              // chunks per particle (524288 tou
 constexpr int MAX_DEPS = 28;
 constexpr int MAX_NODELOG = 2048;             // node allocations / frees per particle attempt
 constexpr int SPEC_NCTR = 9;
+constexpr uint32_t SPEC_SOLO_AFTER = 3;       // rounds without a commit after which the lowest particle runs alone
+constexpr uint32_t SPEC_STALL_LIMIT = 24;     // ... and after which the host gives the phase to the serial walker
+constexpr uint32_t SPEC_SCOUT_MARGIN = 64;    // slots past the n-th that are scouted too (they run when nested particles void lower slots)
+constexpr uint32_t SPEC_MAXNEST = 1024;        // nested particles one speculative phase can absorb (else: serial fallback);
+                                              // a phase of n particles owns n + SPEC_MAXNEST slots
 
 struct alignas(64) SpecLog {                  // undo record of one touched cell (or one modified pool node)
   uint32_t cell, prev;                        // cell index, stamp value it replaced
@@ -102,7 +112,8 @@ struct SpecCkpt {                             // checkpoint of a suspended parti
 };
 
 enum SpecCtrl { SC_NPENDING = 0, SC_BASE, SC_N, SC_NESTED_COMMITTED, SC_NODE_CURSOR, SC_NRECLAIM, SC_NFREE_START,
-                SC_ROUNDS, SC_ABORTS, SC_KILLS, SC_RECLAIM_LOST, SC_CHUNK_CURSOR, SC_SKIPPED, SC_EXECUTED, SC_SUSPENDS, SC_ROUND_MAXSTEPS, SC_SUM_MAXSTEPS, SC_COUNT = 20 };
+                SC_ROUNDS, SC_ABORTS, SC_KILLS, SC_RECLAIM_LOST, SC_CHUNK_CURSOR, SC_SKIPPED, SC_EXECUTED, SC_SUSPENDS, SC_ROUND_MAXSTEPS, SC_SUM_MAXSTEPS,
+                SC_NSLOTS, SC_TOP, SC_STALL, SC_SOLO, SC_COUNT = 24 };
 
 struct SpecShared {
   uint32_t* stamp;
@@ -364,13 +375,13 @@ struct SpecPolicy {
     sh.free_log[(size_t)pid * MAX_NODELOG + nfree++] = e;
   }
   SMX_D void rand2(const DevState&, int& first, int& second) {   // draws of a NESTED particle (water.h:251)
-    const uint32_t k = 2u * pid + 2u * part->noff + 2u + 2u * nested_drawn;
+    const uint32_t k = 2u * (pid + 1u + nested_drawn);     // the slots right after this particle's own
     nested_drawn++;
     if (k + 1 >= sh.ndraws) { overflow = 1; first = second = 0; return; }
     first = (int)(sh.draws[k] >> 1); second = (int)(sh.draws[k + 1] >> 1);
   }
   SMX_D void spawn_draws(int& first, int& second) const {
-    const uint32_t k = 2u * pid + 2u * part->noff;
+    const uint32_t k = 2u * pid;                           // particle id = slot of the phase's draw-pair sequence
     first = (int)(sh.draws[k] >> 1); second = (int)(sh.draws[k + 1] >> 1);
   }
   SMX_D void add_counter(const DevState&, int which, unsigned long long v) { if (which < SPEC_NCTR) ctr[which] += v; }
@@ -418,25 +429,27 @@ constexpr uint32_t SPEC_WINDOW = 4096;        // particles one boundary pass loo
 struct SpecWork {                             // staged per-particle state, index = pid - base
   uint8_t st[SPEC_WINDOW], kl[SPEC_WINDOW], ab[SPEC_WINDOW], dov[SPEC_WINDOW];
   uint16_t nested[SPEC_WINDOW];               // <= SPEC_MAXNEST
-  uint32_t noff[SPEC_WINDOW];
+  uint8_t mask[SPEC_WINDOW];                  // slot is not a top-level particle (now): consumed by a lower particle's
+                                              // nested draws, or beyond the phase's n-th particle
   uint16_t list[SPEC_WINDOW];                 // particles that need a rollback / stamp release (descending);
                                               // reused by the commit step: nfree of the committed prefix
   uint32_t nlist, changed, base, end;
-  uint32_t ncommit, rbase;                    // particles committed now; running (uncapped) reclaim cursor
+  uint32_t ncommit, rbase;                    // slots leaving the window now; running (uncapped) reclaim cursor
+  uint32_t next_end, rank_end, top;           // slot chain / particle rank at the window's end; committed particles
   unsigned long long acc[SPEC_NCTR + 3];      // commit sums: ctr[0..NCTR), live_delta, nested, freed nodes
 };
 
 template <class SyncF>
 SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork& w, uint32_t tid, uint32_t nt, SyncF sync) {
   uint32_t* ctrl = sh.ctrl;
-  const uint32_t n = ctrl[SC_N];
-  if (tid == 0) { w.base = ctrl[SC_BASE]; w.end = (n - w.base > SPEC_WINDOW) ? w.base + SPEC_WINDOW : n; }
+  const uint32_t n = ctrl[SC_N], nslots = ctrl[SC_NSLOTS];
+  if (tid == 0) { w.base = ctrl[SC_BASE]; w.end = (nslots - w.base > SPEC_WINDOW) ? w.base + SPEC_WINDOW : nslots; }
   sync();
   const uint32_t base = w.base, end = w.end, cnt = end - base;
   for (uint32_t i = tid; i < cnt; i += nt) {
     const SpecPart& q = sh.part[base + i];
     w.st[i] = (uint8_t)q.status; w.kl[i] = (uint8_t)((q.kill != 0) || (q.overflow != 0 && q.status != ST_PENDING));
-    w.ab[i] = (uint8_t)q.aborted; w.dov[i] = (uint8_t)q.dep_overflow; w.nested[i] = (uint16_t)q.nested; w.noff[i] = q.noff;
+    w.ab[i] = (uint8_t)q.aborted; w.dov[i] = (uint8_t)q.dep_overflow; w.nested[i] = (uint16_t)q.nested;
   }
   sync();
   // ---- 1. kill closure
@@ -452,15 +465,28 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
       }
     }
     sync();
-    if (tid == 0) {                                        // rand() offsets + dependency-list overflows, in id order
-      uint32_t nest = ctrl[SC_NESTED_COMMITTED];
+    if (tid == 0) {                                        // slot chain + dependency-list overflows, in id order
+      // `next` = the slot the reference hands to its next top-level particle: a finished particle's nested
+      // particles consumed the slots right after its own (an unfinished one is speculated to spawn none).
+      // A tentative run on a slot in between -- or past the phase's n-th particle -- is void.
+      uint32_t next = base, rank = ctrl[SC_TOP];
       bool any = false;
       for (uint32_t i = 0; i < cnt; i++) {
-        if (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED) {
-          if (!w.kl[i] && ((w.dov[i] && any) || w.noff[i] != nest)) { w.kl[i] = 1; w.changed = 1; }
-          if (w.kl[i]) any = true; else nest += w.nested[i];   // (a suspended particle has spawned nothing yet)
+        const bool holds = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED);
+        if (base + i < next || rank >= n) {
+          w.mask[i] = 1;
+          if (holds) { if (!w.kl[i]) { w.kl[i] = 1; w.changed = 1; } any = true; }
+          continue;
         }
+        w.mask[i] = 0;
+        if (holds) {
+          if (!w.kl[i] && w.dov[i] && any) { w.kl[i] = 1; w.changed = 1; }
+          if (w.kl[i]) any = true;
+        }
+        next = base + i + 1u + ((holds && !w.kl[i]) ? (uint32_t)w.nested[i] : 0u);   // (a suspended particle has spawned nothing yet)
+        rank++;
       }
+      w.next_end = next; w.rank_end = rank;
     }
     sync();
     const bool again = w.changed != 0;                     // everybody reads the verdict before thread 0 resets it
@@ -521,22 +547,28 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
   }
   // ---- 3. promote, commit the finished prefix (team-parallel: counters by LDS sums, freed nodes by ranges)
   if (tid == 0) {
-    uint32_t b = 0;                                        // number of particles committed now
+    uint32_t b = 0, top = ctrl[SC_TOP];                    // slots leaving the window; committed top-level particles
     for (uint32_t i = 0; i < cnt; i++) if (w.st[i] == ST_DONE_NEW) w.st[i] = ST_DONE_OLD;
-    while (b < cnt && w.st[b] == ST_DONE_OLD) w.st[b++] = ST_COMMITTED;
-    w.ncommit = b;
+    while (b < cnt && top < n && !w.mask[b] && w.st[b] == ST_DONE_OLD) {
+      const uint32_t k = w.nested[b];                      // its nested particles consumed slots b+1 .. b+k: void for good
+      w.st[b] = ST_COMMITTED; top++;
+      for (uint32_t j = 1; j <= k && b + j < cnt; j++) w.st[b + j] = ST_COMMITTED;   // (masked; rolled back above if they ran)
+      b += 1u + k;
+    }
+    w.ncommit = b; w.top = top;
     for (int k = 0; k < SPEC_NCTR + 3; k++) w.acc[k] = 0;
   }
   sync();
-  const uint32_t b = w.ncommit;
-  for (uint32_t i = tid; i < b; i += nt) w.list[i] = (uint16_t)sh.part[base + i].nfree;   // <= MAX_NODELOG
+  const uint32_t b = w.ncommit, bc = b < cnt ? b : cnt;    // (the last particle's void slots may reach past the window)
+  for (uint32_t i = tid; i < bc; i += nt) w.list[i] = w.mask[i] ? (uint16_t)0 : (uint16_t)sh.part[base + i].nfree;   // <= MAX_NODELOG
   sync();
   {
     unsigned long long a[SPEC_NCTR + 2];
     for (int k = 0; k < SPEC_NCTR + 2; k++) a[k] = 0;
     bool any = false;
     const uint32_t rb = w.rbase;
-    for (uint32_t i = tid; i < b; i += nt) {
+    for (uint32_t i = tid; i < bc; i += nt) {
+      if (w.mask[i]) continue;                             // a void slot: nothing to commit
       const SpecPart& q = sh.part[base + i];
       for (int k = 0; k < SPEC_NCTR; k++) a[k] += q.ctr[k];
       a[SPEC_NCTR] += (unsigned long long)q.live_delta; a[SPEC_NCTR + 1] += q.nested;
@@ -555,21 +587,34 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
     if (w.acc[SPEC_NCTR]) s.ctr[C_LIVE_SECTIONS] += w.acc[SPEC_NCTR];
     ctrl[SC_NESTED_COMMITTED] += (uint32_t)w.acc[SPEC_NCTR + 1];
     uint32_t rb = w.rbase, nfreed = 0;
-    for (uint32_t i = 0; i < b; i++) nfreed += w.list[i];
+    for (uint32_t i = 0; i < bc; i++) nfreed += w.list[i];
     const uint32_t cap = sh.reclaim_cap, hi = rb + nfreed;
     if (hi > cap) ctrl[SC_RECLAIM_LOST] += hi - (rb > cap ? rb : cap);
     ctrl[SC_NRECLAIM] = hi;
-    uint32_t np = 0, nest = ctrl[SC_NESTED_COMMITTED];
-    for (uint32_t i = b; i < cnt; i++) {
-      if (w.st[i] == ST_PENDING) { w.noff[i] = nest; sh.pending[np++] = base + i; }
-      else if (w.st[i] == ST_SUSPENDED) sh.pending[np++] = base + i;   // resumes with the offset it started with
-      else nest += w.nested[i];
+    // pending list: the top-level slots of the window that still have to run (ranks below n only)
+    uint32_t np = 0;
+    const uint32_t stall = b ? 0u : ctrl[SC_STALL] + 1u;   // consecutive rounds without a commit
+    ctrl[SC_STALL] = stall;
+    if (w.top < n && stall >= SPEC_SOLO_AFTER && bc < cnt && !w.mask[bc] && (w.st[bc] == ST_PENDING || w.st[bc] == ST_SUSPENDED)) {
+      // The lowest particle keeps failing (typically a flooding particle whose nested particles run into cells that
+      // higher particles re-take every round): it runs ALONE until it commits. Nobody else moves, so each failure
+      // flags -- and the next boundary unwinds -- one more tentative holder in its way; the others keep their work.
+      sh.pending[np++] = base + bc;
+      ctrl[SC_SOLO]++;
+    } else if (w.top < n) {
+      for (uint32_t i = bc; i < cnt; i++)
+        if (!w.mask[i] && (w.st[i] == ST_PENDING || w.st[i] == ST_SUSPENDED)) sh.pending[np++] = base + i;
+      // slots beyond the window become eligible as it slides; the slot chain continues from the window's end
+      const uint32_t newbase = base + b;
+      const uint32_t newend = (nslots - newbase > SPEC_WINDOW) ? newbase + SPEC_WINDOW : nslots;
+      uint32_t next = w.next_end > newbase ? w.next_end : newbase, rank = w.rank_end;
+      for (uint32_t p = end > newbase ? end : newbase; p < newend; p++) {
+        if (p < next || rank >= n) continue;
+        sh.pending[np++] = p; rank++;
+      }
     }
-    // particles beyond the window become eligible as the window slides: they keep noff from the last in-window state
-    const uint32_t newbase = base + b;
-    const uint32_t newend = (n - newbase > SPEC_WINDOW) ? newbase + SPEC_WINDOW : n;
-    for (uint32_t p = end; p < newend; p++) { sh.part[p].noff = nest; sh.pending[np++] = p; }
-    ctrl[SC_BASE] = newbase;
+    ctrl[SC_BASE] = base + b;
+    ctrl[SC_TOP] = w.top;
     ctrl[SC_NPENDING] = np;
     ctrl[SC_ROUNDS]++;
     ctrl[SC_SUM_MAXSTEPS] += ctrl[SC_ROUND_MAXSTEPS]; ctrl[SC_ROUND_MAXSTEPS] = 0;
@@ -577,7 +622,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
   sync();
   for (uint32_t i = tid; i < cnt; i += nt) {
     SpecPart& q = sh.part[base + i];
-    q.status = w.st[i]; q.kill = 0; q.aborted = 0; q.noff = w.noff[i];
+    q.status = w.st[i]; q.kill = 0; q.aborted = 0;
   }
   sync();
 }
@@ -585,7 +630,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
 // give up speculation: undo every tentative particle so that the state equals "particles [0, base) executed"
 SMX_D void spec_abandon(const DevState& s, const SpecShared& sh) {
   uint32_t* ctrl = sh.ctrl;
-  const uint32_t n = ctrl[SC_N], base = ctrl[SC_BASE];
+  const uint32_t n = ctrl[SC_NSLOTS], base = ctrl[SC_BASE];
   for (uint32_t p = base; p < n; p++) if (sh.part[p].status == ST_DONE_OLD || sh.part[p].status == ST_DONE_NEW || sh.part[p].status == ST_SUSPENDED) sh.part[p].kill = 1;
   for (uint32_t p = n; p-- > base;) {
     SpecPart& q = sh.part[p];
@@ -625,27 +670,34 @@ SMX_D void spec_finish_pool(const DevState& s, const SpecShared& sh) {
 // ------------------------------------------------------------------------------------------------
 namespace smx {
 
-constexpr uint32_t SPEC_MAXNEST = 512;        // nested particles one speculative phase can absorb (else: serial fallback)
 
 // phase start (team of nt threads): thread 0 peeks the rand() stream ahead and resets the control block,
 // everybody resets the per-particle records. The speculative engine needs pool headroom (SpecPolicy::can_get
 // never refuses): without it the phase is flagged (SC_N = 0) and the host runs the serial walker instead.
 SMX_D void spec_begin_team(const DevState& s, const SpecShared& sh, uint32_t n, uint32_t tid, uint32_t nt) {
   if (tid == 0) {
-    RandState r = *s.rnd;                     // copy: the global stream is only advanced when the phase ends
-    for (uint32_t k = 0; k < sh.ndraws; k++) {
-      const uint32_t i = r.idx;
-      const uint32_t v = r.ring[i % 31] + r.ring[(i - 3) % 31];
-      r.ring[i % 31] = v; r.idx = i + 1;
-      sh.draws[k] = v;
+    // Peek the stream ahead without advancing it (that happens when the phase ends). The ring is rotated once so
+    // that a[j] is the word draw j overwrites; a revolution of 31 draws then has static indices only (registers,
+    // not scratch): a[j] += a[j-3 mod 31].
+    const RandState& r = *s.rnd;
+    const uint32_t i0 = r.idx;
+    uint32_t a[31];
+    for (int j = 0; j < 31; j++) a[j] = r.ring[(i0 + (uint32_t)j) % 31];
+    for (uint32_t k = 0; k < sh.ndraws; k += 31) {
+#pragma unroll
+      for (int j = 0; j < 31; j++) {
+        a[j] += a[(j + 28) % 31];
+        if (k + (uint32_t)j < sh.ndraws) sh.draws[k + j] = a[j];
+      }
     }
     for (int i = 0; i < SC_COUNT; i++) sh.ctrl[i] = 0;
     const unsigned long long live = s.ctr[C_LIVE_SECTIONS];
     const bool room = live + 65536ull + 64ull * n < s.pool_capacity && *s.free_count > 65536u + 64u * n;
     sh.ctrl[SC_N] = room ? n : 0; sh.ctrl[SC_NPENDING] = room ? ((n > SPEC_WINDOW) ? SPEC_WINDOW : n) : 0;
+    sh.ctrl[SC_NSLOTS] = n + SPEC_MAXNEST;
     sh.ctrl[SC_NFREE_START] = *s.free_count;
   }
-  for (uint32_t p = tid; p < n; p += nt) {
+  for (uint32_t p = tid; p < n + SPEC_MAXNEST; p += nt) {  // one record per SLOT (n particles + the nested ones' slots)
     SpecPart& q = sh.part[p];
     q.status = ST_PENDING; q.kill = 0; q.aborted = 0; q.fail_cell = NOCLAIM; q.noff = 0; q.nested = 0; q.nlog = 0;
     q.nchunks = 0; q.ndeps = 0; q.dep_overflow = 0; q.nalloc = 0; q.nfree = 0; q.overflow = 0; q.attempts = 0; q.nnode = 0;
@@ -739,7 +791,7 @@ template <bool WIND>
 SMX_D void spec_scout_one(const DevState& s, const SoilP* soils, const SpecShared& sh, uint32_t pid) {
   ScoutPolicy pol(sh, pid);
   Sim<ScoutPolicy> sim(s, soils, pol);
-  const uint32_t k = 2u * pid + 2u * sh.part[pid].noff;
+  const uint32_t k = 2u * pid;
   const int ry = (int)(sh.draws[k] >> 1) % s.dimy, rx = (int)(sh.draws[k + 1] >> 1) % s.dimx;
   if constexpr (WIND) {
     Wind p; sim.wind_init(p, rx, ry); sim.wind_run(p);

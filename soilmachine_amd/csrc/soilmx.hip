@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_spec_begin(DevState s, SpecShared sh, u
 template <bool WIND>
 __global__ void __launch_bounds__(64) k_spec_scout(DevState s, SpecShared sh, uint32_t lanes) {
   SMX_LOAD_SOILS(soils_sh)
-  const uint32_t n = sh.ctrl[SC_N];
+  const uint32_t n = sh.ctrl[SC_N] ? sh.ctrl[SC_N] + SPEC_SCOUT_MARGIN : 0u;
   const uint32_t pid = blockIdx.x * lanes + threadIdx.x;
   if (threadIdx.x >= lanes || pid >= n) return;
   spec_scout_one<WIND>(s, soils_sh, sh, pid);
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) k_spec_scout(DevState s, SpecShared sh, ui
 template <bool WIND>
 __global__ void __launch_bounds__(64) k_spec_scout_coop(DevState s, SpecShared sh) {
   SMX_LOAD_SOILS(soils_sh)
-  if (blockIdx.x >= sh.ctrl[SC_N]) return;
+  if (sh.ctrl[SC_N] == 0 || blockIdx.x >= sh.ctrl[SC_N] + SPEC_SCOUT_MARGIN) return;
   spec_scout_one_coop<WIND>(s, soils_sh, sh, blockIdx.x);
 }
 // one wave per pending particle walks its predicted footprint: publish claims, then (next kernel) test them
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64) k_spec_abandon(DevState s, SpecShared sh) 
   if (threadIdx.x == 0) spec_abandon(s, sh);
 }
 __global__ void __launch_bounds__(256) k_spec_end(DevState s, SpecShared sh, uint32_t whole_phase) {
-  const uint32_t done = whole_phase ? sh.ctrl[SC_N] : sh.ctrl[SC_BASE];
+  const uint32_t done = whole_phase ? sh.ctrl[SC_N] : sh.ctrl[SC_TOP];   // top-level particles executed
   spec_end_team(s, sh, done, sh.ctrl[SC_NESTED_COMMITTED], threadIdx.x, blockDim.x);
 }
 
@@ -667,7 +667,7 @@ int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out
 }
 
 // ---------------- speculative engine: host driver ----------------
-static int spec_alloc(smx_ctx* ctx, uint32_t n) {
+static int spec_alloc(smx_ctx* ctx, uint32_t n) {          // n = particles of the phase; it owns n + SPEC_MAXNEST slots
   if (ctx->spec_cap >= n) return 0;
   SpecShared& sh = ctx->sh;
   if (ctx->spec_cap) {
@@ -679,18 +679,19 @@ static int spec_alloc(smx_ctx* ctx, uint32_t n) {
     sh.reclaim_cap = 1u << 22; HIPCHK(hipMalloc(&sh.reclaim, (size_t)sh.reclaim_cap * 4));
     HIPCHK(hipHostMalloc(&ctx->h_ctrl, SC_COUNT * 4));
   }
-  const uint32_t cap = n < 1024 ? 1024 : n;
-  HIPCHK(hipMalloc(&sh.part, (size_t)cap * sizeof(SpecPart)));
-  HIPCHK(hipMalloc(&sh.chunk_tab, (size_t)cap * MAX_CHUNKS * 4));
+  const uint32_t cap = n < 1024 ? 1024 : n;                 // particles
+  const uint32_t slots = cap + SPEC_MAXNEST;                // per-slot records (soil_spec.h "rand() SLOTS")
+  HIPCHK(hipMalloc(&sh.part, (size_t)slots * sizeof(SpecPart)));
+  HIPCHK(hipMalloc(&sh.chunk_tab, (size_t)slots * MAX_CHUNKS * 4));
   sh.arena_chunks = cap * 32u < 16384u ? 16384u : cap * 32u;
   HIPCHK(hipMalloc(&sh.arena, (size_t)sh.arena_chunks * LOG_CHUNK * sizeof(SpecLog)));
-  HIPCHK(hipMalloc(&sh.alloc_log, (size_t)cap * MAX_NODELOG * 4)); HIPCHK(hipMalloc(&sh.free_log, (size_t)cap * MAX_NODELOG * 4));
-  HIPCHK(hipMalloc(&sh.pending, (size_t)cap * 4));
-  sh.ndraws = 2 * cap + 2 * SPEC_MAXNEST; HIPCHK(hipMalloc(&sh.draws, (size_t)sh.ndraws * 4));
-  // scouted footprints: water paths are a few thousand cells, wind paths up to ~10^5
+  HIPCHK(hipMalloc(&sh.alloc_log, (size_t)slots * MAX_NODELOG * 4)); HIPCHK(hipMalloc(&sh.free_log, (size_t)slots * MAX_NODELOG * 4));
+  HIPCHK(hipMalloc(&sh.pending, (size_t)slots * 4));
+  sh.ndraws = 2 * slots; HIPCHK(hipMalloc(&sh.draws, (size_t)sh.ndraws * 4));
+  // scouted footprints (the first n + SPEC_SCOUT_MARGIN slots only): water paths are a few thousand cells, wind paths up to ~10^5
   sh.scout_cap = cap <= 2048 ? 131072u : 16384u;
-  HIPCHK(hipMalloc(&sh.scout_cells, (size_t)cap * sh.scout_cap * 4)); HIPCHK(hipMalloc(&sh.scout_len, (size_t)cap * 4));
-  HIPCHK(hipMalloc(&sh.ckpt, (size_t)cap * sizeof(SpecCkpt)));
+  HIPCHK(hipMalloc(&sh.scout_cells, (size_t)(cap + SPEC_SCOUT_MARGIN) * sh.scout_cap * 4)); HIPCHK(hipMalloc(&sh.scout_len, (size_t)slots * 4));
+  HIPCHK(hipMalloc(&sh.ckpt, (size_t)slots * sizeof(SpecCkpt)));
   sh.mode = 3u;
   ctx->spec_cap = cap;
   return 0;
@@ -713,12 +714,13 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
   const uint32_t L = (uint32_t)spec_lanes();
   static const bool wind_scout = [] { const char* e = getenv("SMX_WIND_SCOUT"); return e ? atoi(e) != 0 : true; }();
   static const bool coop_scout = [] { const char* e = getenv("SMX_COOP"); return e ? atoi(e) != 0 : true; }();
+  const uint32_t ns = (uint32_t)n + SPEC_SCOUT_MARGIN;       // scouted slots
   if (coop_scout) {
-    if (!wind) hipLaunchKernelGGL(k_spec_scout_coop<false>, dim3(n), dim3(64), 0, st, ctx->d, sh);
-    else if (wind_scout) hipLaunchKernelGGL(k_spec_scout_coop<true>, dim3(n), dim3(64), 0, st, ctx->d, sh);
+    if (!wind) hipLaunchKernelGGL(k_spec_scout_coop<false>, dim3(ns), dim3(64), 0, st, ctx->d, sh);
+    else if (wind_scout) hipLaunchKernelGGL(k_spec_scout_coop<true>, dim3(ns), dim3(64), 0, st, ctx->d, sh);
   } else {
-    if (!wind) hipLaunchKernelGGL(k_spec_scout<false>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
-    else if (wind_scout) hipLaunchKernelGGL(k_spec_scout<true>, dim3((n + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+    if (!wind) hipLaunchKernelGGL(k_spec_scout<false>, dim3((ns + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
+    else if (wind_scout) hipLaunchKernelGGL(k_spec_scout<true>, dim3((ns + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
   }
   uint32_t np = (uint32_t)n > SPEC_WINDOW ? SPEC_WINDOW : (uint32_t)n, last_base = 0, stall = 0;
   bool fallback = false;
@@ -753,16 +755,16 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
       prev_exec = c[SC_EXECUTED]; prev_sum = c[SC_SUM_MAXSTEPS]; t_round = now;
     }
     if (c[SC_N] == 0) { fallback = true; break; }                       // no pool headroom: nothing was executed
-    if (c[SC_BASE] == (uint32_t)n) break;
+    if (c[SC_TOP] == (uint32_t)n) break;                                // n top-level particles committed
     np = c[SC_NPENDING];
     if (c[SC_BASE] == last_base) stall++; else { stall = 0; last_base = c[SC_BASE]; }
-    if (np == 0 || stall >= 8 || c[SC_NESTED_COMMITTED] + 64 > SPEC_MAXNEST || round > 100000) { fallback = true; break; }
+    if (np == 0 || stall >= SPEC_STALL_LIMIT || c[SC_NESTED_COMMITTED] + 64 > SPEC_MAXNEST || round > 100000) { fallback = true; break; }
   }
   const uint32_t* c = ctx->h_ctrl;
   ctx->spec_rounds += c[SC_ROUNDS]; ctx->spec_aborts += c[SC_ABORTS]; ctx->spec_kills += c[SC_KILLS]; ctx->spec_executed += c[SC_EXECUTED];
   if (fallback) {
     ctx->spec_fallbacks++;
-    const uint32_t base = (c[SC_N] == 0) ? 0u : c[SC_BASE];
+    const uint32_t base = (c[SC_N] == 0) ? 0u : c[SC_TOP];             // top-level particles the speculation committed
     if (c[SC_N] != 0) {
       hipLaunchKernelGGL(k_spec_abandon, dim3(1), dim3(64), 0, st, ctx->d, sh);
       hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(256), 0, st, ctx->d, sh, 0u);

@@ -209,26 +209,29 @@ double hs_remove(hs_ctx* c, int x, int y, double h) {
 struct SpecBuffers {
   std::vector<uint32_t> stamp, claim, chunk_tab, alloc_log, free_log, pending, ctrl, reclaim, scout_cells, scout_len;
   std::vector<SpecPart> part;
-  std::vector<SpecLog> arena;
+  SpecLog* arena = nullptr;                                 // big and sparse: malloc'd, never zero-filled
+  uint32_t* scout_cells_raw = nullptr;
+  ~SpecBuffers() { free(arena); free(scout_cells_raw); }
   std::vector<SpecCkpt> ckpt;
   std::vector<uint32_t> draws;
   SpecShared sh;
 };
-static void spec_setup(hs_ctx* c, SpecBuffers& b, uint32_t n) {
+static void spec_setup(hs_ctx* c, SpecBuffers& b, uint32_t nparticles) {
+  const uint32_t n = nparticles + SPEC_MAXNEST;             // one record per slot
   b.stamp.assign(c->n, 0); b.claim.assign(c->n, NOCLAIM);
   b.part.resize(n); b.chunk_tab.assign((size_t)n * MAX_CHUNKS, 0);
-  const uint32_t arena_chunks = std::max<uint32_t>(4096, n * 64);
-  b.arena.resize((size_t)arena_chunks * LOG_CHUNK);
+  const uint32_t arena_chunks = std::max<uint32_t>(4096, nparticles * 64);
+  b.arena = (SpecLog*)malloc((size_t)arena_chunks * LOG_CHUNK * sizeof(SpecLog));
   b.alloc_log.assign((size_t)n * MAX_NODELOG, 0); b.free_log.assign((size_t)n * MAX_NODELOG, 0);
   b.pending.assign(n, 0); b.ctrl.assign(SC_COUNT, 0); b.reclaim.assign(1 << 20, 0);
-  b.draws.assign(2 * n + 2 * SPEC_MAXNEST, 0);
-  b.sh.scout_cap = 65536; b.scout_cells.assign((size_t)n * b.sh.scout_cap, 0); b.scout_len.assign(n, 0);
+  b.draws.assign(2 * n, 0);
+  b.sh.scout_cap = 65536; b.scout_cells_raw = (uint32_t*)malloc((size_t)(nparticles + SPEC_SCOUT_MARGIN) * b.sh.scout_cap * 4); b.scout_len.assign(n, 0);   // only scouted slots own a list
   SpecShared& sh = b.sh;
   sh.stamp = b.stamp.data(); sh.claim = b.claim.data(); sh.part = b.part.data(); sh.chunk_tab = b.chunk_tab.data();
-  sh.arena = b.arena.data(); sh.arena_chunks = arena_chunks; sh.alloc_log = b.alloc_log.data(); sh.free_log = b.free_log.data();
+  sh.arena = b.arena; sh.arena_chunks = arena_chunks; sh.alloc_log = b.alloc_log.data(); sh.free_log = b.free_log.data();
   sh.pending = b.pending.data(); sh.ctrl = b.ctrl.data(); sh.draws = b.draws.data(); sh.ndraws = (uint32_t)b.draws.size();
   sh.reclaim = b.reclaim.data(); sh.reclaim_cap = (uint32_t)b.reclaim.size();
-  sh.scout_cells = b.scout_cells.data(); sh.scout_len = b.scout_len.data();
+  sh.scout_cells = b.scout_cells_raw; sh.scout_len = b.scout_len.data();
   b.ckpt.resize(n); sh.ckpt = b.ckpt.data(); sh.mode = 2u;
 }
 template <class F> static void parallel_for(uint32_t n, int nthreads, F f, unsigned shuffle_seed) {
@@ -253,7 +256,7 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
   uint32_t last_base = 0, stall = 0; int fell_back = 0;
   b.sh.mode = (uint32_t)(scout >> 4);                       // scout argument: bit0 = trajectory scout, bits 4.. = engine mode
   scout &= 1;
-  if (scout) parallel_for(n, nthreads, [&](uint32_t i) { if (b.sh.mode & 4u) spec_scout_one_coop<WIND>(s, s.soils, sh, i); else spec_scout_one<WIND>(s, s.soils, sh, i); }, shuffle ? shuffle + 1 : 0);
+  if (scout) parallel_for(n + SPEC_SCOUT_MARGIN, nthreads, [&](uint32_t i) { if (b.sh.mode & 4u) spec_scout_one_coop<WIND>(s, s.soils, sh, i); else spec_scout_one<WIND>(s, s.soils, sh, i); }, shuffle ? shuffle + 1 : 0);
   while (true) {
     std::fill(b.claim.begin(), b.claim.end(), NOCLAIM);
     const uint32_t np = sh.ctrl[SC_NPENDING];
@@ -274,14 +277,26 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
         pthread_barrier_destroy(&bar);
       }
     }
-    if (sh.ctrl[SC_NPENDING] == 0 && sh.ctrl[SC_BASE] == n) break;
+    if (sh.ctrl[SC_TOP] == n) break;
     if (sh.ctrl[SC_BASE] == last_base) stall++; else { stall = 0; last_base = sh.ctrl[SC_BASE]; }
-    if (stall >= 8 || sh.ctrl[SC_NESTED_COMMITTED] > SPEC_MAXNEST - 64) { fell_back = 1; break; }
+    if (sh.ctrl[SC_NPENDING] == 0 || stall >= SPEC_STALL_LIMIT || sh.ctrl[SC_NESTED_COMMITTED] > SPEC_MAXNEST - 64) {
+      if (getenv("HS_TRACE")) {
+        const SpecPart& q = sh.part[sh.ctrl[SC_BASE]];
+        if (q.fail_cell != NOCLAIM) {
+          const uint32_t fc = q.fail_cell, v = sh.stamp[fc];
+          fprintf(stderr, "[hostsim]   fail_cell %u stamp %u claim %u owner-status %d owner-kill %d\n", fc, v, sh.claim[fc],
+                  (v && v != POISON) ? (int)sh.part[v - 1].status : -1, (v && v != POISON) ? (int)sh.part[v - 1].kill : -1);
+        }
+        fprintf(stderr, "[hostsim] fallback: npending %u stall %u nested %u base %u top %u | base particle: status %u overflow %u attempts %u nlog %u nalloc %u nfree %u nested %u\n",
+                sh.ctrl[SC_NPENDING], stall, sh.ctrl[SC_NESTED_COMMITTED], sh.ctrl[SC_BASE], sh.ctrl[SC_TOP], q.status, q.overflow, q.attempts, q.nlog, q.nalloc, q.nfree, q.nested);
+      }
+      fell_back = 1; break;
+    }
   }
   if (stats) { stats[0] = sh.ctrl[SC_ROUNDS]; stats[1] = sh.ctrl[SC_ABORTS]; stats[2] = sh.ctrl[SC_KILLS]; stats[3] = (uint32_t)fell_back; stats[4] = sh.ctrl[SC_EXECUTED]; stats[5] = sh.ctrl[SC_SUM_MAXSTEPS]; }
   if (fell_back) {
     spec_abandon(s, sh);
-    const uint32_t base = sh.ctrl[SC_BASE];
+    const uint32_t base = sh.ctrl[SC_TOP];                   // top-level particles committed so far
     spec_end(s, sh, base, sh.ctrl[SC_NESTED_COMMITTED]);
     if (WIND) hs_wind(c, (int)(n - base)); else hs_water(c, (int)(n - base));
     return 1;
