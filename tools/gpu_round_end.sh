@@ -23,7 +23,7 @@ step() {  # step <name> <need-seconds> <timeout> <cmd...>
   return $rc
 }
 python -c "import torch" > /dev/null 2>&1 &          # page the image in while the torch-free steps run
-step smoke 20 120 python __graft_entry__.py --smoke
+step smoke 20 120 python -c "import __graft_entry__ as g; g.smoke()"
 tail -2 $out/smoke.log
 step quick 40 200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "snapshots or phase_by_phase or import_resume"
 tail -3 $out/quick.log
@@ -32,6 +32,12 @@ step bench 60 240 python bench.py
 cp $out/bench.log $out/bench.json 2>/dev/null
 tail -c 400 $out/bench.log; echo
 step trace 60 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline
+if [ -f soilmachine_amd/libsoilmx_prev.so ]; then      # A/B: the previous build of the library on the same box
+  cp soilmachine_amd/libsoilmx.so /tmp/libsoilmx_new.so && cp soilmachine_amd/libsoilmx_prev.so soilmachine_amd/libsoilmx.so
+  step bench_prev 45 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline
+  cp /tmp/libsoilmx_new.so soilmachine_amd/libsoilmx.so
+  tail -c 300 $out/bench_prev.log; echo
+fi
 step fulltests 120 900 python -m pytest tests -x -q -m gpu
 tail -5 $out/fulltests.log
 P="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
