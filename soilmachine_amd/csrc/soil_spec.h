@@ -113,7 +113,7 @@ struct SpecCkpt {                             // checkpoint of a suspended parti
 
 enum SpecCtrl { SC_NPENDING = 0, SC_BASE, SC_N, SC_NESTED_COMMITTED, SC_NODE_CURSOR, SC_NRECLAIM, SC_NFREE_START,
                 SC_ROUNDS, SC_ABORTS, SC_KILLS, SC_RECLAIM_LOST, SC_CHUNK_CURSOR, SC_SKIPPED, SC_EXECUTED, SC_SUSPENDS, SC_ROUND_MAXSTEPS, SC_SUM_MAXSTEPS,
-                SC_NSLOTS, SC_TOP, SC_STALL, SC_SOLO, SC_COUNT = 24 };
+                SC_NSLOTS, SC_TOP, SC_STALL, SC_SOLO, SC_HIGH, SC_COUNT = 24 };
 
 struct SpecShared {
   uint32_t* stamp;
@@ -426,8 +426,12 @@ struct SpecPolicy {
 // Written for a TEAM of `nt` threads (thread `tid`); `sync` is the team barrier. The scalar passes run on
 // thread 0 over the staged arrays in `w` (LDS on the device).
 constexpr uint32_t SPEC_WINDOW = 4096;        // particles one boundary pass looks at (ids base .. base+window)
-struct SpecWork {                             // staged per-particle state, index = pid - base
-  uint8_t st[SPEC_WINDOW], kl[SPEC_WINDOW], ab[SPEC_WINDOW], dov[SPEC_WINDOW];
+// (thread 0's scans read the byte arrays FOUR SLOTS PER LOAD: one scan is a chain of LDS round trips, and the five
+//  of them were most of the boundary's time -- profiles/r01_kernel_stats.csv, k_spec_boundary)
+SMX_D uint32_t spec_w4(const uint8_t* a, uint32_t i0) { uint32_t v; __builtin_memcpy(&v, a + i0, 4); return v; }
+SMX_D void spec_w4_put(uint8_t* a, uint32_t i0, uint32_t v) { __builtin_memcpy(a + i0, &v, 4); }
+struct alignas(8) SpecWork {                  // staged per-particle state, index = pid - base
+  alignas(8) uint8_t st[SPEC_WINDOW], kl[SPEC_WINDOW], ab[SPEC_WINDOW], dov[SPEC_WINDOW];
   uint16_t nested[SPEC_WINDOW];               // <= SPEC_MAXNEST
   uint8_t mask[SPEC_WINDOW];                  // slot is not a top-level particle (now): consumed by a lower particle's
                                               // nested draws, or beyond the phase's n-th particle
@@ -443,7 +447,12 @@ template <class SyncF>
 SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork& w, uint32_t tid, uint32_t nt, SyncF sync) {
   uint32_t* ctrl = sh.ctrl;
   const uint32_t n = ctrl[SC_N], nslots = ctrl[SC_NSLOTS];
-  if (tid == 0) { w.base = ctrl[SC_BASE]; w.end = (nslots - w.base > SPEC_WINDOW) ? w.base + SPEC_WINDOW : nslots; }
+  if (tid == 0) {                                          // the window stops at the highest slot that ever became pending:
+    w.base = ctrl[SC_BASE];                                // the slots above never ran and hold nothing
+    uint32_t e = (nslots - w.base > SPEC_WINDOW) ? w.base + SPEC_WINDOW : nslots;
+    const uint32_t high = ctrl[SC_HIGH] > w.base ? ctrl[SC_HIGH] : w.base + 1u;
+    w.end = e < high ? e : high;
+  }
   sync();
   const uint32_t base = w.base, end = w.end, cnt = end - base;
   for (uint32_t i = tid; i < cnt; i += nt) {
@@ -452,6 +461,7 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
     w.ab[i] = (uint8_t)q.aborted; w.dov[i] = (uint8_t)q.dep_overflow; w.nested[i] = (uint16_t)q.nested;
   }
   sync();
+  while (true) {                                           // (repeated while the lowest particle's way is being cleared, see 2b)
   // ---- 1. kill closure
   while (true) {
     if (tid == 0) w.changed = 0;
@@ -470,22 +480,34 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
       // particles consumed the slots right after its own (an unfinished one is speculated to spawn none).
       // A tentative run on a slot in between -- or past the phase's n-th particle -- is void.
       uint32_t next = base, rank = ctrl[SC_TOP];
-      bool any = false;
-      for (uint32_t i = 0; i < cnt; i++) {
-        const bool holds = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED);
-        if (base + i < next || rank >= n) {
-          w.mask[i] = 1;
-          if (holds) { if (!w.kl[i]) { w.kl[i] = 1; w.changed = 1; } any = true; }
-          continue;
+      bool any = false, chg = false;
+      for (uint32_t i0 = 0; i0 < cnt; i0 += 4u) {
+        const uint32_t st4 = spec_w4(w.st, i0), kl4 = spec_w4(w.kl, i0), dov4 = spec_w4(w.dov, i0);
+        const uint32_t ne01 = spec_w4((const uint8_t*)w.nested, 2u * i0), ne23 = spec_w4((const uint8_t*)w.nested, 2u * i0 + 4u);
+        uint32_t kln = kl4, mk4 = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+          if (i0 + u >= cnt) break;
+          const uint32_t sh8 = 8u * u, st = (st4 >> sh8) & 0xffu;
+          const bool holds = (st == ST_DONE_NEW || st == ST_DONE_OLD || st == ST_SUSPENDED);
+          bool kl = ((kln >> sh8) & 0xffu) != 0;
+          if (base + i0 + u < next || rank >= n) {
+            mk4 |= 1u << sh8;
+            if (holds) { if (!kl) { kln |= 1u << sh8; chg = true; } any = true; }
+            continue;
+          }
+          if (holds) {
+            if (!kl && ((dov4 >> sh8) & 0xffu) && any) { kln |= 1u << sh8; chg = true; kl = true; }
+            if (kl) any = true;
+          }
+          const uint32_t ne = ((u < 2u ? ne01 : ne23) >> (16u * (u & 1u))) & 0xffffu;
+          next = base + i0 + u + 1u + ((holds && !kl) ? ne : 0u);   // (a suspended particle has spawned nothing yet)
+          rank++;
         }
-        w.mask[i] = 0;
-        if (holds) {
-          if (!w.kl[i] && w.dov[i] && any) { w.kl[i] = 1; w.changed = 1; }
-          if (w.kl[i]) any = true;
-        }
-        next = base + i + 1u + ((holds && !w.kl[i]) ? (uint32_t)w.nested[i] : 0u);   // (a suspended particle has spawned nothing yet)
-        rank++;
+        if (kln != kl4) spec_w4_put(w.kl, i0, kln);
+        spec_w4_put(w.mask, i0, mk4);
       }
+      if (chg) w.changed = 1;
       w.next_end = next; w.rank_end = rank;
     }
     sync();
@@ -496,9 +518,16 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
   // ---- 2. rollback list, highest id first
   if (tid == 0) {
     uint32_t m = 0;
-    for (uint32_t i = cnt; i-- > 0;) {
-      const bool done = (w.st[i] == ST_DONE_NEW || w.st[i] == ST_DONE_OLD || w.st[i] == ST_SUSPENDED);   // holds cells + log
-      if ((done && w.kl[i]) || (!done && w.ab[i])) w.list[m++] = (uint16_t)i;
+    for (uint32_t i0 = (cnt + 3u) & ~3u; i0 >= 4u;) {
+      i0 -= 4u;
+      const uint32_t st4 = spec_w4(w.st, i0), kl4 = spec_w4(w.kl, i0), ab4 = spec_w4(w.ab, i0);
+#pragma unroll
+      for (uint32_t u = 4u; u-- > 0u;) {
+        if (i0 + u >= cnt) continue;
+        const uint32_t sh8 = 8u * u, st = (st4 >> sh8) & 0xffu;
+        const bool done = (st == ST_DONE_NEW || st == ST_DONE_OLD || st == ST_SUSPENDED);   // holds cells + log
+        if ((done && ((kl4 >> sh8) & 0xffu)) || (!done && ((ab4 >> sh8) & 0xffu))) w.list[m++] = (uint16_t)(i0 + u);
+      }
     }
     w.nlist = m;
     w.rbase = ctrl[SC_NRECLAIM];                           // reclaim cursor of this pass (written back once, at the end)
@@ -542,13 +571,34 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
         if (e->cell & NODE_ENTRY) continue;
         sh.stamp[e->cell] = e->prev;
       }
+      if (tid == 0) w.ab[i] = 0;                           // (released: a repeated pass must not do it again)
     }
     sync();
   }
+  // ---- 2b. The lowest particle decides the phase's progress. If it gave up at a cell that tentative holders had
+  // handed on to each other (h1 took it over from h2, h2 from h3, ...), undoing the one it met only exposes the
+  // next: unwind the whole chain now instead of one holder per round (a lake cell can have dozens).
+  if (tid == 0) {
+    w.changed = 0;
+    const uint32_t st0 = w.st[0], fc = sh.part[base].fail_cell;
+    if ((st0 == ST_PENDING || st0 == ST_SUSPENDED) && !w.mask[0] && fc != NOCLAIM) {
+      const uint32_t v = sh.stamp[fc];
+      if (v != POISON && v > base + 1u && v - 1u - base < cnt) {
+        const uint32_t h = v - 1u - base, sth = w.st[h];
+        if ((sth == ST_DONE_NEW || sth == ST_DONE_OLD || sth == ST_SUSPENDED) && !w.kl[h]) { w.kl[h] = 1; w.changed = 1; }
+      }
+    }
+  }
+  sync();
+  const bool more = w.changed != 0;
+  sync();
+  if (!more) break;
+  }
   // ---- 3. promote, commit the finished prefix (team-parallel: counters by LDS sums, freed nodes by ranges)
+  for (uint32_t i = tid; i < cnt; i += nt) if (w.st[i] == ST_DONE_NEW) w.st[i] = ST_DONE_OLD;
+  sync();
   if (tid == 0) {
     uint32_t b = 0, top = ctrl[SC_TOP];                    // slots leaving the window; committed top-level particles
-    for (uint32_t i = 0; i < cnt; i++) if (w.st[i] == ST_DONE_NEW) w.st[i] = ST_DONE_OLD;
     while (b < cnt && top < n && !w.mask[b] && w.st[b] == ST_DONE_OLD) {
       const uint32_t k = w.nested[b];                      // its nested particles consumed slots b+1 .. b+k: void for good
       w.st[b] = ST_COMMITTED; top++;
@@ -602,16 +652,24 @@ SMX_D void spec_boundary_team(const DevState& s, const SpecShared& sh, SpecWork&
       sh.pending[np++] = base + bc;
       ctrl[SC_SOLO]++;
     } else if (w.top < n) {
-      for (uint32_t i = bc; i < cnt; i++)
-        if (!w.mask[i] && (w.st[i] == ST_PENDING || w.st[i] == ST_SUSPENDED)) sh.pending[np++] = base + i;
+      for (uint32_t i0 = bc & ~3u; i0 < cnt; i0 += 4u) {
+        const uint32_t st4 = spec_w4(w.st, i0), mk4 = spec_w4(w.mask, i0);
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+          const uint32_t i = i0 + u, st = (st4 >> (8u * u)) & 0xffu;
+          if (i < bc || i >= cnt || ((mk4 >> (8u * u)) & 0xffu)) continue;
+          if (st == ST_PENDING || st == ST_SUSPENDED) sh.pending[np++] = base + i;
+        }
+      }
       // slots beyond the window become eligible as it slides; the slot chain continues from the window's end
       const uint32_t newbase = base + b;
       const uint32_t newend = (nslots - newbase > SPEC_WINDOW) ? newbase + SPEC_WINDOW : nslots;
       uint32_t next = w.next_end > newbase ? w.next_end : newbase, rank = w.rank_end;
-      for (uint32_t p = end > newbase ? end : newbase; p < newend; p++) {
-        if (p < next || rank >= n) continue;
+      for (uint32_t p = end > newbase ? end : newbase; p < newend && rank < n; p++) {
+        if (p < next) continue;
         sh.pending[np++] = p; rank++;
       }
+      if (np && sh.pending[np - 1] + 1u > ctrl[SC_HIGH]) ctrl[SC_HIGH] = sh.pending[np - 1] + 1u;   // (ascending list)
     }
     ctrl[SC_BASE] = base + b;
     ctrl[SC_TOP] = w.top;
@@ -695,6 +753,7 @@ SMX_D void spec_begin_team(const DevState& s, const SpecShared& sh, uint32_t n, 
     const bool room = live + 65536ull + 64ull * n < s.pool_capacity && *s.free_count > 65536u + 64u * n;
     sh.ctrl[SC_N] = room ? n : 0; sh.ctrl[SC_NPENDING] = room ? ((n > SPEC_WINDOW) ? SPEC_WINDOW : n) : 0;
     sh.ctrl[SC_NSLOTS] = n + SPEC_MAXNEST;
+    sh.ctrl[SC_HIGH] = (n > SPEC_WINDOW) ? SPEC_WINDOW : n;
     sh.ctrl[SC_NFREE_START] = *s.free_count;
   }
   for (uint32_t p = tid; p < n + SPEC_MAXNEST; p += nt) {  // one record per SLOT (n particles + the nested ones' slots)

@@ -264,6 +264,11 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
     if (sh.mode & 1u) parallel_for(np, nthreads, [&](uint32_t i) { const uint32_t pid = sh.pending[i]; sh.part[pid].blocked = spec_blocked(sh, pid, 0u, 1u) ? 1u : 0u; }, 0);
     const bool coop = (sh.mode & 4u) != 0;                   // mode bit 2 (host only): the wave-loop structure of soil_coop.h
     parallel_for(np, nthreads, [&](uint32_t i) { if (coop) spec_exec_one_coop<WIND>(s, s.soils, sh, sh.pending[i]); else spec_exec_one<WIND>(s, s.soils, sh, sh.pending[i]); }, shuffle ? shuffle + 2 + sh.ctrl[SC_ROUNDS] : 0);
+    if (getenv("HS_TRACE") && np == 1) {
+      const SpecPart& q = sh.part[sh.pending[0]];
+      if (q.fail_cell != NOCLAIM) fprintf(stderr, "[hostsim]   solo %u failed at cell %u stamp %u (status of that holder %d)\n", sh.pending[0], q.fail_cell, sh.stamp[q.fail_cell],
+                                          sh.stamp[q.fail_cell] && sh.stamp[q.fail_cell] != POISON ? (int)sh.part[sh.stamp[q.fail_cell] - 1].status : -1);
+    }
     {
       static SpecWork* w = new SpecWork();
       const int bt = g_boundary_threads;                     // >1: the boundary runs as a TEAM (threads + barrier), as on the device
