@@ -102,3 +102,29 @@ def test_speculative_protocol_larger_map_has_parallelism():
     oc, hc = o.counters(), hs.counters()
     for k in ("steps_water_all", "steps_wind", "nested_particles", "cascade_transfers", "rand_calls"):
         assert oc[k] == hc[k], k
+
+
+def test_nested_particles_void_only_their_slots_and_lakes_do_not_fall_back(boundary_team):
+    """rand() slots + solo rounds + take-over-chain clearing (soil_spec.h): 1000 water particles on a 256^2 map is far
+    denser than any BASELINE config -- lakes form after three ticks, every tick spawns hundreds of nested particles and
+    lake cells are handed on through dozens of tentative holders. The engine must stay exact, must not give the phase
+    to the serial walker, and a nested particle must no longer cost a re-run of every later particle."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 256
+    o = Oracle(cfg, n, n, seed=0)
+    o.initialize()
+    hs = HostSim(cfg, n, n, seed=0)
+    hs.load(o.snapshot())
+    nested_before = 0
+    for t in range(7):
+        st = hs.spec_tick(cfg.NWATER, cfg.NWIND, True, True, nthreads=8, shuffle=5 + t)
+        o.tick(cfg.NWATER, cfg.NWIND, True, True)
+        assert not compare(hs.snapshot(), o.snapshot()), f"tick {t}"
+        oc, hc = o.counters(), hs.counters()
+        for k in ("steps_water_all", "steps_wind", "nested_particles", "rand_calls", "pool_free"):
+            assert oc[k] == hc[k], (t, k)
+        assert int(st[3]) == 0 and int(st[9]) == 0, f"tick {t}: fell back to the serial walker"
+        executed_w = int(st[4])
+        assert executed_w < 6 * cfg.NWATER, f"tick {t}: {executed_w} executions for {cfg.NWATER} particles"
+        nested_before = hc["nested_particles"]
+    assert nested_before > 1000                                # the regime this test is about was reached
