@@ -18,8 +18,8 @@
 //                    run and from the footprint of its previous attempts). A particle yields at cells claimed
 //                    by a lower pending particle, so the lower id always wins a conflict (deterministic
 //                    reservations) and every round completes one full level of the conflict DAG.
-//   * boundary     : between rounds one workgroup computes the kill closure (flags, dependencies, rand()
-//                    offsets), rolls killed particles back in DESCENDING id order, commits the finished
+//   * boundary     : between rounds one workgroup computes the kill closure (flags, dependencies, the slot
+//                    chain below), rolls killed particles back in DESCENDING id order, commits the finished
 //                    prefix and rebuilds the pending list.
 //   * rand() SLOTS : the phase's rand() stream is a sequence of draw pairs ("slots"). The reference hands slot m to
 //                    the next top-level particle, or -- while a particle floods -- to the nested particles it spawns
@@ -96,7 +96,7 @@ struct alignas(64) SpecLog {                  // undo record of one touched cell
 
 struct SpecPart {                             // one particle of the phase
   uint32_t status, kill, aborted, fail_cell;
-  uint32_t noff, nested, nlog, nchunks;
+  uint32_t noff, nested, nlog, nchunks;            // (noff: unused since particle ids are rand() slots; keeps the layout)
   uint32_t ndeps, dep_overflow, nalloc, nfree;
   uint32_t overflow, attempts, nnode, blocked;     // nnode: NODE_ENTRY records in the log
   long long live_delta;
@@ -419,10 +419,12 @@ struct SpecPolicy {
 
 // ---------------- round boundary (ONE workgroup; everything it reads was written by earlier kernels) --------
 // 1. kill closure over the window [base, end): kill flags set by lower particles, log/node overflows, dependencies
-//    on killed particles, wrong rand() offsets (nested particles of lower ids).
+//    on killed particles, tentative runs on slots that a lower particle's nested particles consumed (slot chain).
 // 2. roll killed particles back (data + stamps) and release the stamps of particles that aborted by themselves,
-//    in DESCENDING id order (a cell taken over from a lower tentative particle must be unwound top-down).
-// 3. DONE_NEW -> DONE_OLD, commit the finished prefix, rebuild the pending list with fresh rand offsets.
+//    in DESCENDING id order (a cell taken over from a lower tentative particle must be unwound top-down);
+//    2b. clear the whole take-over chain on the cell the lowest particle gave up at.
+// 3. DONE_NEW -> DONE_OLD, commit the finished prefix (and void the slots its nested particles used), rebuild the
+//    pending list (or, after SPEC_SOLO_AFTER rounds without a commit, just the lowest particle).
 // Written for a TEAM of `nt` threads (thread `tid`); `sync` is the team barrier. The scalar passes run on
 // thread 0 over the staged arrays in `w` (LDS on the device).
 constexpr uint32_t SPEC_WINDOW = 4096;        // particles one boundary pass looks at (ids base .. base+window)
