@@ -123,6 +123,12 @@ int smx_seep(smx_ctx* ctx, int32_t x, int32_t y);                               
 int smx_top(smx_ctx* ctx, int32_t x, int32_t y, uint32_t* type, double* size, double* floor, double* sat,
             int32_t* empty);                                                            /* Layermap::top layermap.h:150 (a copy) */
 int smx_normals(smx_ctx* ctx, float* out3);             /* Layermap::normal(ivec2) for every cell, xyz interleaved (layermap.h:341) */
+/* Layermap::update(Vertexpool&) (layermap.h:551-555 -> :475-549, no SLICE cut): the visible vertex of every column in
+ * one pass -- 44-byte records {position[3], normal[3], color[4], index} (source/include/vertexpool.h:9-28) in cell
+ * order x*dimy+y: position = (x, SCALE*height, y), normal = Layermap::normal(ivec2), color = colors4[type], index =
+ * type; an empty column is (x, 0, y), (0,1,0), colors4[0], 0. colors4 = ncolors x RGBA (SurfParam::color,
+ * surface.h:17); out = dimx*dimy*44 bytes, caller-allocated. */
+int smx_fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44);
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out);      /* Layermap::height(vec2) (layermap.h:427) */
 
 /* ---- observability ---- */

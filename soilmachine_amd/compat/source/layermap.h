@@ -215,6 +215,13 @@ class Layermap {
   void update(Vertexpool<Vertex>& vertexpool) {                                                     // layermap.h:551-555
     if (section == NULL) return;
     refresh();
+    static_assert(sizeof(Vertex) == 44, "Vertex is the 44-byte record smx_fill_vertices writes");
+    if (vertexpool.store.size() >= (size_t)*section + (size_t)dim.x * dim.y) {   // contiguous section: one device pass
+      std::vector<float> col(4 * soils.size());
+      for (size_t k = 0; k < soils.size(); k++) { col[4 * k] = soils[k].color.x; col[4 * k + 1] = soils[k].color.y; col[4 * k + 2] = soils[k].color.z; col[4 * k + 3] = soils[k].color.w; }
+      check(smx_fill_vertices(ctx, col.data(), (int32_t)soils.size(), vertexpool.get(section, 0)), "smx_fill_vertices");
+      return;
+    }
     std::vector<float> nrm((size_t)dim.x * dim.y * 3);
     check(smx_normals(ctx, nrm.data()), "smx_normals");
     for (int i = 0; i < dim.x; i++)

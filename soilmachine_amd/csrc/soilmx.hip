@@ -10,6 +10,7 @@
 //   k_map_frequency / k_reset_frequency   water.h:353-365, float4-vectorised streaming kernels
 //   k_init_terrain                   Layermap::initialize (layermap.h:163-216): FBm OpenSimplex2 per cell + column build
 //   k_heights / k_surface / k_normals / k_bilinear   whole-map read-side primitives (layermap.h:341-439)
+//   k_fill_vertices                  Layermap::update(Vertexpool&) (layermap.h:475-555): the 44-byte vertex stream
 //
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
@@ -289,6 +290,40 @@ __global__ void __launch_bounds__(256) k_normals(DevState s, float* __restrict__
   Sim<SerialPolicy> sim(s, s.soils, pol);
   f3 v = sim.normal((int)(c / s.dimy), (int)(c % s.dimy));
   out[3 * c] = v.x; out[3 * c + 1] = v.y; out[3 * c + 2] = v.z;
+}
+// Layermap::update(Vertexpool&) for the whole map (layermap.h:475-555): one 44-byte vertex per column. A thread
+// builds its vertex in LDS, the block then streams its 256 x 11 floats out as one contiguous run (a 44-byte
+// stride per thread would scatter every store over two lines).
+__global__ void __launch_bounds__(256) k_fill_vertices(DevState s, const float* __restrict__ colors4, uint32_t ncolors,
+                                                       float* __restrict__ out) {
+  __shared__ float stage[256 * 11];
+  const size_t n = (size_t)s.dimx * s.dimy;
+  const size_t c0 = (size_t)blockIdx.x * 256, c = c0 + threadIdx.x;
+  if (c < n) {
+    const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
+    const Sec r = s.cells[c];
+    const uint32_t ty = (r.type == EMPTY) ? 0u : r.type;
+    const double h = (r.type == EMPTY) ? 0.0 : r.floor + r.size;
+    float* v = stage + threadIdx.x * 11;
+    f3 nrm = {0.f, 1.f, 0.f};
+    float py = 0.f;
+    uint32_t ci = 0;
+    if (!(h == 0.0 && ty == 0u)) {
+      SerialPolicy pol(s);
+      Sim<SerialPolicy> sim(s, s.soils, pol);
+      nrm = sim.normal(x, y);
+      py = (float)(s.scale * h);
+      ci = ty;
+    }
+    const uint32_t cc = ci < ncolors ? ci : 0u;
+    v[0] = (float)x; v[1] = py; v[2] = (float)y;
+    v[3] = nrm.x; v[4] = nrm.y; v[5] = nrm.z;
+    v[6] = colors4[4 * cc]; v[7] = colors4[4 * cc + 1]; v[8] = colors4[4 * cc + 2]; v[9] = colors4[4 * cc + 3];
+    v[10] = (float)(int)ci;
+  }
+  __syncthreads();
+  const size_t left = n - c0, cells = left < 256 ? left : 256, nf = cells * 11;
+  for (size_t i = threadIdx.x; i < nf; i += 256) out[c0 * 11 + i] = stage[i];
 }
 __global__ void __launch_bounds__(256) k_bilinear(DevState s, const float* __restrict__ pos, int n, double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -653,6 +688,24 @@ static int read_plane(smx_ctx* ctx, void* host, size_t bytes, int which) {
 int smx_read_heights(smx_ctx* ctx, double* out) { return read_plane(ctx, out, ctx->ncells * 8, 0); }
 int smx_read_surface(smx_ctx* ctx, uint32_t* out) { return read_plane(ctx, out, ctx->ncells * 4, 1); }
 int smx_normals(smx_ctx* ctx, float* out3) { return read_plane(ctx, out3, ctx->ncells * 12, 2); }
+
+int smx_fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44) {
+  if (!colors4 || ncolors <= 0 || !out_vertices44) { ctx->err = "smx_fill_vertices: colors4/out must be given"; return -2; }
+  float* dcol = nullptr; float* dout = nullptr;
+  const size_t bytes = ctx->ncells * 44;
+  HIPCHK(hipMalloc(&dcol, (size_t)ncolors * 16));
+  if (hipMalloc(&dout, bytes) != hipSuccess) { hipFree(dcol); ctx->err = "smx_fill_vertices: out of device memory"; return -1; }
+  hipError_t e = hipMemcpyAsync(dcol, colors4, (size_t)ncolors * 16, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_fill_vertices, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d, dcol,
+                       (uint32_t)ncolors, dout);
+    e = hipMemcpyAsync(out_vertices44, dout, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(dcol); hipFree(dout);
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
+  return 0;
+}
 
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out) {
   float* dpos = nullptr; double* dout = nullptr;

@@ -105,6 +105,14 @@ class Layermap:
         self._chk(self.L.smx_normals(self.h, capi.ptr(out)))
         return out
 
+    def vertices(self, colors: np.ndarray) -> np.ndarray:
+        """Layermap::update(Vertexpool&) (layermap.h:475-555) for the whole map in one device pass: (cells, 11) float32 =
+        position[3], normal[3], color[4], index (the reference's 44-byte Vertex); `colors` = (nsoils, 4) RGBA."""
+        colors = np.ascontiguousarray(colors, np.float32).reshape(-1, 4)
+        out = np.zeros((self.dimx * self.dimy, 11), np.float32)
+        self._chk(self.L.smx_fill_vertices(self.h, capi.ptr(colors), colors.shape[0], capi.ptr(out)))
+        return out
+
     def heights_bilinear(self, pos: np.ndarray) -> np.ndarray:
         pos = np.ascontiguousarray(pos, np.float32)
         out = np.zeros(pos.shape[0])

@@ -57,6 +57,42 @@ def test_heights_surface_normals_bilinear_bit_exact():
     assert np.array_equal(bits(m.heights_bilinear(pos)), bits(want))
 
 
+def test_vertex_stream_matches_reference_update_rule():
+    """smx_fill_vertices = Layermap::update(Vertexpool&) (layermap.h:475-555, no SLICE cut) for every column: the 44-byte
+    Vertex records rebuilt here from the ORACLE's heights / surface types / normals, bit for bit; non-square map with
+    carved-out empty columns so that the (x, 0, y), (0,1,0), soils[0] branch of layermap.h:545 is taken too."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    dimx, dimy = 70, 96                                            # not a multiple of the 256-cell block
+    m = Layermap(cfg, dimx, dimy, seed=4)
+    o = Oracle(cfg, dimx, dimy, seed=4)
+    o.initialize()
+    for (x, y) in [(0, 0), (5, 7), (69, 95), (33, 1)]:             # dig a few columns down to nothing
+        for _ in range(8):                                         # one section per call (layermap.h:310-339)
+            m.remove(x, y, 10.0)
+            o.L.so_remove(o.h, x, y, 10.0)
+    colors = np.linspace(0.05, 0.95, 4 * len(cfg.soils), dtype=np.float32).reshape(-1, 4)
+    got = m.vertices(colors)
+    h = o.heights()
+    want = np.zeros((dimx * dimy, 11), np.float32)
+    tmp = np.zeros(3, np.float32)
+    n_empty = 0
+    for x in range(dimx):
+        for y in range(dimy):
+            c = x * dimy + y
+            ty = int(o.L.so_surface(o.h, x, y))
+            if h[c] == 0.0 and ty == 0:
+                want[c] = [x, 0, y, 0, 1, 0, *colors[0], 0]
+                n_empty += 1
+            else:
+                o.L.so_normal(o.h, x, y, tmp.ctypes.data)
+                want[c, 0:3] = [x, np.float32(cfg.SCALE * h[c]), y]
+                want[c, 3:6] = tmp
+                want[c, 6:10] = colors[ty]
+                want[c, 10] = ty
+    assert n_empty >= 4
+    assert np.array_equal(bits(got), bits(want))
+
+
 # ---------------------------------------------------------------- column operations (layermap.h:230-339)
 def test_add_remove_sequences_bit_exact():
     cfg = load_cfg("rockgravelpebblessand.soil")
