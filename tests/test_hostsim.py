@@ -128,3 +128,21 @@ def test_nested_particles_void_only_their_slots_and_lakes_do_not_fall_back(bound
         assert executed_w < 6 * cfg.NWATER, f"tick {t}: {executed_w} executions for {cfg.NWATER} particles"
         nested_before = hc["nested_particles"]
     assert nested_before > 1000                                # the regime this test is about was reached
+
+
+def test_more_particles_than_the_boundary_window():
+    """A phase with more slots than SPEC_WINDOW (4096): the boundary's window slides with the committed prefix and
+    the slot chain continues across its end -- same state as the reference, no serial fallback."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n, nwater = 768, 4600
+    o = Oracle(cfg, n, n, seed=0)
+    o.initialize()
+    hs = HostSim(cfg, n, n, seed=0)
+    hs.load(o.snapshot())
+    st = hs.spec_tick(nwater, 0, True, False, nthreads=8, shuffle=3)
+    o.tick(nwater, 0, True, False)
+    assert not compare(hs.snapshot(), o.snapshot())
+    assert int(st[3]) == 0                                     # did not fall back
+    oc, hc = o.counters(), hs.counters()
+    for k in ("steps_water_all", "nested_particles", "rand_calls", "pool_free"):
+        assert oc[k] == hc[k], k
