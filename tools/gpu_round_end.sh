@@ -44,6 +44,8 @@ P="python bench.py --steps 3 --warmup 2 --no-cpu-baseline"
 step fetch 60 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o f -- $P
 step write 60 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w -- $P
 step sq 60 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $out/sq -o s -- $P
+# instruction-cache behaviour of the particle kernels (k_spec_exec_coop<wind> is 492 KB of code)
+step icache 60 200 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $out/icache -o i -- $P
 SMX_TRACE_ROUNDS=1 timeout 60 python bench.py --steps 1 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/rounds_trace.txt
 find $out -name "*.csv" | head -20
 cat $out/status.txt
