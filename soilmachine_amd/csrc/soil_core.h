@@ -126,6 +126,19 @@ struct Blk {
 struct Frame { int ix, iy, spill, num, i; uint32_t codes; };
 constexpr int MAX_FRAMES = 24;
 
+// The wind step's one level of cascade recursion (particle.h:96-97), OUT of line and BY VALUE for policies that ask
+// for it (P::OUTLINE_RECURSION): inlined four times into the wave kernel (two cascades x the A/B ping-pong of the
+// carried blocks) the map-based cascade made k_spec_exec_coop<wind> 492 KB of code with 514 spilled VGPRs.
+template <class P> struct RecRes { P pol; Blk b; bool ab, moved; };
+#ifdef SMX_HOSTSIM
+#define SMX_NOINLINE __attribute__((noinline))
+#else
+#define SMX_NOINLINE __device__ __attribute__((noinline))
+#endif
+template <class P> SMX_NOINLINE RecRes<P> wind_recurse(DevState s, const SoilP* soils, P pol, float cx, float cy, int ix, int iy);
+template <class P, class = void> struct outline_recursion { static constexpr bool value = false; };
+template <class P> struct outline_recursion<P, decltype((void)P::OUTLINE_RECURSION)> { static constexpr bool value = P::OUTLINE_RECURSION; };
+
 template <class P>
 struct Sim {
   const DevState& s;
@@ -758,10 +771,18 @@ struct Sim {
       if (r == 2 && budget > 0) {                            // cascade(npos, .., --transferloop)
         --budget;
         const f2 cp = {(float)(ix + nb_dx(bk)), (float)(iy + nb_dy(bk))};
-        moved |= particle_cascade<0>(cp);
-        if (ab) return false;
         const float fr = b.fr, tr = b.tr;
-        load_block<2>(ix, iy, b);                            // back in the parent: its block may have changed
+        if constexpr (outline_recursion<P>::value) {
+          RecRes<P> r = wind_recurse<P>(s, soils, pol, cp.x, cp.y, ix, iy);
+          pol.adopt(r.pol);
+          moved |= r.moved;
+          if (r.ab) { ab = true; return false; }
+          b = r.b;                                           // back in the parent: its block may have changed
+        } else {
+          moved |= particle_cascade<0>(cp);
+          if (ab) return false;
+          load_block<2>(ix, iy, b);                          // back in the parent: its block may have changed
+        }
         b.fr = fr; b.tr = tr;
         if (ab) return false;
         ctr = b.v8;
@@ -1120,5 +1141,16 @@ struct Sim {
   }
   SMX_D void wind_run(Wind& p, bool resume = false) { wind_loop(p, resume); }   // SoilMachine.cpp:305-306
 };
+
+template <class P>
+SMX_NOINLINE RecRes<P> wind_recurse(DevState s, const SoilP* soils, P pol, float cx, float cy, int ix, int iy) {
+  RecRes<P> r{pol, Blk{}, false, false};
+  Sim<P> sim(s, soils, r.pol);
+  r.moved = sim.template particle_cascade<0>(f2{cx, cy});
+  if (!sim.ab) sim.template load_block<2>(ix, iy, r.b);
+  r.ab = sim.ab;
+  sim.flush_counters();
+  return r;
+}
 
 }  // namespace smx

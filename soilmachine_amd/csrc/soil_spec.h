@@ -182,6 +182,14 @@ struct ScoutPolicy {
 // ---------------- in-place speculative execution ----------------
 struct SpecPolicy {
   static constexpr bool READ_ONLY = false;
+  static constexpr bool OUTLINE_RECURSION = true;           // soil_core.h wind_recurse
+  // take over the cursors of a copy that ran a piece of this particle out of line (same particle, same log)
+  SMX_D void adopt(const SpecPolicy& o) {
+    nlog = o.nlog; nchunks = o.nchunks; ndeps = o.ndeps; dep_overflow = o.dep_overflow; nalloc = o.nalloc; nfree = o.nfree;
+    nested_drawn = o.nested_drawn; overflow = o.overflow; nnode = o.nnode; fail_cell = o.fail_cell; live_delta = o.live_delta;
+    for (int i = 0; i < SPEC_NCTR; i++) ctr[i] = o.ctr[i];
+    last = o.last; chunk = o.chunk;
+  }
   const SpecShared& sh;
   uint32_t pid, me;
   SpecPart* part;
