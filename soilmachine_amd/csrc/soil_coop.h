@@ -241,7 +241,8 @@ SMX_D void wind_loop_coop(Sim<P>& sim, Wind& p, bool resume) {
       if (r <= 0) { if (l0 && r < 0 && sim.susp_ok) { sim.susp = 2; sim.pol.save_blk(CUR); } return; }        \
     }
     SMX_COOP_WIND_STEP(A, B)
-    SMX_COOP_WIND_STEP(B, A)
+    A = B;                                                   // the new block becomes the carried one (B is dead until the next load):
+                                                             // one body instead of an A/B ping-pong halves the kernel's code
 #undef SMX_COOP_WIND_STEP
   }
 }
