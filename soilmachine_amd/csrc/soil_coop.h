@@ -202,7 +202,7 @@ SMX_D void water_loop_coop(Sim<P>& sim, Water& p, bool toplevel, bool resume) {
       if (r <= 0) { if (l0 && r < 0 && sim.susp_ok) { sim.susp = 2; sim.pol.save_blk(CUR); } return; }        \
     }
     SMX_COOP_WATER_STEP(A, B)
-    SMX_COOP_WATER_STEP(B, A)
+    A = B;                                                   // (one body, as in wind_loop_coop)
 #undef SMX_COOP_WATER_STEP
   }
 }
