@@ -132,6 +132,10 @@ int smx_fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void*
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out);      /* Layermap::height(vec2) (layermap.h:427) */
 
 /* ---- observability ---- */
+/* The state digest of SURVEY.md Appendix E, computed from a device->host copy: sum of Layermap::height(ivec2) over the
+ * cells in x-outer / y-inner order (sequential double accumulation), number of sections, and the 64-bit hash
+ * h = (h ^ type) * 1099511628211 (start 1469598103934665603) over every column walked top -> bottom, same cell order. */
+int smx_digest(smx_ctx* ctx, double* sumh, uint64_t* nsec, uint64_t* typehash);
 int smx_get_counters(smx_ctx* ctx, smx_counters* out);
 int smx_get_timing(smx_ctx* ctx, smx_timing* out);
 int smx_timing_reset(smx_ctx* ctx);

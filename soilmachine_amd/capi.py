@@ -51,7 +51,7 @@ SYMBOLS = [
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
     "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices",
-    "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream",
+    "smx_digest", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream",
 ]
 
 _lib = None
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
     L.smx_normals.argtypes = [vp, vp]
     L.smx_fill_vertices.argtypes = [vp, vp, C.c_int32, vp]
     L.smx_heights_bilinear.argtypes = [vp, vp, i32, vp]
+    L.smx_digest.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
     L.smx_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.smx_get_timing.argtypes = [vp, C.POINTER(Timing)]
     L.smx_timing_reset.argtypes = [vp]

@@ -113,7 +113,7 @@ struct SpecCkpt {                             // checkpoint of a suspended parti
 
 enum SpecCtrl { SC_NPENDING = 0, SC_BASE, SC_N, SC_NESTED_COMMITTED, SC_NODE_CURSOR, SC_NRECLAIM, SC_NFREE_START,
                 SC_ROUNDS, SC_ABORTS, SC_KILLS, SC_RECLAIM_LOST, SC_CHUNK_CURSOR, SC_SKIPPED, SC_EXECUTED, SC_SUSPENDS, SC_ROUND_MAXSTEPS, SC_SUM_MAXSTEPS,
-                SC_NSLOTS, SC_TOP, SC_STALL, SC_SOLO, SC_HIGH, SC_COUNT = 24 };
+                SC_NSLOTS, SC_TOP, SC_STALL, SC_SOLO, SC_HIGH, SC_POOL_CROSSED, SC_COUNT = 24 };
 
 struct SpecShared {
   uint32_t* stamp;
@@ -760,7 +760,11 @@ SMX_D void spec_begin_team(const DevState& s, const SpecShared& sh, uint32_t n, 
     }
     for (int i = 0; i < SC_COUNT; i++) sh.ctrl[i] = 0;
     const unsigned long long live = s.ctr[C_LIVE_SECTIONS];
-    const bool room = live + 65536ull + 64ull * n < s.pool_capacity && *s.free_count > 65536u + 64u * n;
+    // headroom: SpecPolicy::can_get() never refuses, so a phase only runs speculatively when the pool cannot run out
+    // inside it (measured growth: ~80 sections per particle on rgps 64^2; 512 per particle + 64 Ki is the margin). Without
+    // room the phase runs on the serial walker, whose get() fails exactly where the reference's does (layermap.h:92-95);
+    // spec_end_team re-checks the live count afterwards (SC_POOL_CROSSED -> the host reports an error).
+    const bool room = live + 65536ull + 512ull * n < s.pool_capacity && (unsigned long long)*s.free_count > 65536ull + 512ull * n;
     sh.ctrl[SC_N] = room ? n : 0; sh.ctrl[SC_NPENDING] = room ? ((n > SPEC_WINDOW) ? SPEC_WINDOW : n) : 0;
     sh.ctrl[SC_NSLOTS] = n + SPEC_MAXNEST;
     sh.ctrl[SC_HIGH] = (n > SPEC_WINDOW) ? SPEC_WINDOW : n;
@@ -796,7 +800,10 @@ SMX_D void spec_end_team(const DevState& s, const SpecShared& sh, uint32_t npart
   uint32_t nr = ctrl[SC_NRECLAIM];
   if (nr > sh.reclaim_cap) nr = sh.reclaim_cap;
   for (uint32_t i = tid; i < nr; i += nt) s.freelist[nf + i] = sh.reclaim[i];
-  if (tid == 0) *s.free_count = nf + nr;
+  if (tid == 0) {
+    *s.free_count = nf + nr;
+    if (s.ctr[C_LIVE_SECTIONS] > s.pool_capacity) ctrl[SC_POOL_CROSSED] = 1;   // can_get() would have refused somewhere inside
+  }
 }
 SMX_D void spec_end(const DevState& s, const SpecShared& sh, uint32_t nparticles_done, uint32_t nested_done) {
   spec_end_team(s, sh, nparticles_done, nested_done, 0u, 1u);

@@ -256,7 +256,13 @@ __global__ void __launch_bounds__(256) k_init_terrain(DevState s, LayersDev L) {
   uint8_t flag = 0;
   if (ns > 0) {
     uint32_t base = 0;
-    if (ns > 1) base = atomicSub(s.free_count, (uint32_t)(ns - 1));   // old count: our nodes are freelist[base-ns+1 .. base-1]
+    if (ns > 1) {
+      base = atomicSub(s.free_count, (uint32_t)(ns - 1));             // old count: our nodes are freelist[base-ns+1 .. base-1]
+      if (base < (uint32_t)(ns - 1) || base > (uint32_t)s.pool_capacity) {   // out of nodes (smx_initialize rules this out: guard only)
+        atomicAdd(&s.ctr[C_POOL_OVERFLOW], 1ull);
+        ns = 1;                                                       // keep the bottom section only, touch nothing out of bounds
+      }
+    }
     double fl = 0.0;
     uint32_t pv = NIL;
     for (int k = 0; k < ns; k++) {
@@ -488,10 +494,9 @@ void smx_destroy(smx_ctx* ctx) {
   if (ctx->sh.stamp) {
     SpecShared& sh = ctx->sh;
     hipFree(sh.stamp); hipFree(sh.claim); hipFree(sh.ctrl); hipFree(sh.reclaim); hipHostFree(ctx->h_ctrl);
-    if (ctx->spec_cap) {
-      hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
-      hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len); hipFree(sh.ckpt);
-    }
+    // (hipFree(nullptr) is a no-op: after a failed spec_alloc some of these are null)
+    hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
+    hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len); hipFree(sh.ckpt);
   }
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -553,6 +558,13 @@ int smx_rand_advance(smx_ctx* ctx, uint64_t ndraws) {
 
 int smx_initialize(smx_ctx* ctx, int32_t seed, const smx_layer* layers, int32_t nlayers) {
   if (nlayers < 0 || nlayers > MAX_LAYERS) { ctx->err = "smx_initialize: too many layers"; return -2; }
+  // Every (cell, layer) pair can become a section. The reference prints "Memory Pool Out-Of-Elements" and silently
+  // drops the rest of the terrain (layermap.h:92-95,233); a device-parallel build cannot reproduce WHICH sections it
+  // drops, so a pool that cannot hold the worst case is refused up front instead of producing a different map.
+  if ((uint64_t)ctx->ncells * (uint64_t)(nlayers > 0 ? nlayers : 1) > ctx->cfg.pool_capacity) {
+    ctx->err = "smx_initialize: pool_capacity < cells * layers (the reference's POOLSIZE would overflow during Layermap::initialize)";
+    return -4;
+  }
   if (reset_pool(ctx)) return -1;
   HIPCHK(hipMemsetAsync(ctx->d.ctr + C_LIVE_SECTIONS, 0, 8, ctx->stream));
   LayersDev L; L.n = nlayers;
@@ -726,6 +738,9 @@ static int spec_alloc(smx_ctx* ctx, uint32_t n) {          // n = particles of t
   if (ctx->spec_cap) {
     hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
     hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len); hipFree(sh.ckpt);
+    sh.part = nullptr; sh.chunk_tab = nullptr; sh.arena = nullptr; sh.alloc_log = nullptr; sh.free_log = nullptr;
+    sh.pending = nullptr; sh.draws = nullptr; sh.scout_cells = nullptr; sh.scout_len = nullptr; sh.ckpt = nullptr;
+    ctx->spec_cap = 0;                                        // a failed hipMalloc below must not leave dangling pointers
   } else {
     HIPCHK(hipMalloc(&sh.stamp, ctx->ncells * 4)); HIPCHK(hipMalloc(&sh.claim, ctx->ncells * 4));
     HIPCHK(hipMalloc(&sh.ctrl, SC_COUNT * 4));
@@ -828,6 +843,13 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
     hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(256), 0, st, ctx->d, sh, 1u);
   }
   HIPCHK(hipGetLastError());
+  {
+    uint32_t crossed = 0;
+    HIPCHK(hipMemcpyAsync(&crossed, sh.ctrl + SC_POOL_CROSSED, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (crossed) { ctx->err = "speculative phase ran past pool_capacity (pool.get() would have failed inside it): raise pool_capacity"; return -6; }
+  }
+  if (c[SC_RECLAIM_LOST] != 0) { ctx->err = "speculative phase: reclaim list overflow (pool nodes leaked)"; return -6; }
   return 0;
 }
 
@@ -905,6 +927,7 @@ int smx_remove(smx_ctx* ctx, int32_t x, int32_t y, double h, double* remainder) 
   PointOp o{}; o.op = 1; o.x = x; o.y = y; o.a = h; double r = 0; int rc = point_op(ctx, o, &r); if (remainder) *remainder = r; return rc;
 }
 int smx_particle_cascade(smx_ctx* ctx, float px, float py, int32_t transferloop) {
+  if (!(px == px) || !(py == py) || !inb(ctx, (int)roundf(px), (int)roundf(py))) { ctx->err = "cell out of bounds"; return -2; }
   PointOp o{}; o.op = 2; o.px = px; o.py = py; o.k = transferloop; return point_op(ctx, o, nullptr);
 }
 int smx_water_cascade(smx_ctx* ctx, int32_t x, int32_t y, int32_t spill) {
@@ -931,6 +954,35 @@ int smx_top(smx_ctx* ctx, int32_t x, int32_t y, uint32_t* type, double* size, do
 }
 
 // ---------------- observability ----------------
+int smx_digest(smx_ctx* ctx, double* sumh, uint64_t* nsec, uint64_t* typehash) {
+  const size_t n = ctx->ncells;
+  const uint64_t cap = ctx->cfg.pool_capacity;
+  std::vector<Sec> cells(n);
+  std::vector<uint32_t> ptype(cap), pprev(cap);             // of a buried section only type and prev matter here
+  HIPCHK(hipMemcpyAsync(cells.data(), ctx->d.cells, n * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
+  // {type, prev} = the last 8 bytes of every 32-byte pool record: one strided 2D copy instead of the whole pool
+  std::vector<uint64_t> tp(cap);
+  HIPCHK(hipMemcpy2DAsync(tp.data(), 8, reinterpret_cast<const char*>(ctx->d.pool) + 24, sizeof(Sec), 8, cap, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double sh = 0.0; uint64_t ns = 0, h = 1469598103934665603ull;
+  for (size_t c = 0; c < n; c++) {
+    const Sec& t = cells[c];
+    if (t.type == EMPTY) { sh += 0.0; continue; }
+    sh += t.floor + t.size;
+    h = (h ^ (uint64_t)t.type) * 1099511628211ull; ns++;
+    uint32_t pv = t.prev; uint64_t guard = 0;
+    while (pv != NIL) {
+      if (pv >= cap || ++guard > cap) { ctx->err = "smx_digest: corrupt section chain"; return -5; }
+      const uint64_t w = tp[pv];
+      h = (h ^ (uint64_t)(uint32_t)w) * 1099511628211ull; ns++;
+      pv = (uint32_t)(w >> 32);
+    }
+  }
+  if (sumh) *sumh = sh;
+  if (nsec) *nsec = ns;
+  if (typehash) *typehash = h;
+  return 0;
+}
 int smx_get_counters(smx_ctx* ctx, smx_counters* out) {
   unsigned long long c[C_COUNT];
   RandState r;

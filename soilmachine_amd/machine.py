@@ -19,6 +19,16 @@ class SoilmxError(RuntimeError):
     pass
 
 
+POOLSIZE = 10_000_000      # SoilMachine.cpp:16
+
+
+def default_pool(dimx: int, dimy: int) -> int:
+    """The reference's POOLSIZE (10 M sections, SoilMachine.cpp:16). Deviation, stated: maps of 2048^2 cells and
+    more do not fit it (the reference silently drops terrain there), so large maps get
+    4 sections per cell instead."""
+    return max(POOLSIZE, 4 * int(dimx) * int(dimy))
+
+
 class Layermap:
     """Device-resident layermap (cells + section pool + frequency planes) behind the C-ABI."""
 
@@ -29,7 +39,7 @@ class Layermap:
         self.dimx = int(dimx if dimx is not None else cfg.SIZEX)
         self.dimy = int(dimy if dimy is not None else cfg.SIZEY)
         self.seed = seed
-        self.pool = int(pool if pool is not None else max(8 * self.dimx * self.dimy, 1 << 20))   # POOLSIZE (SoilMachine.cpp:16)
+        self.pool = int(pool if pool is not None else default_pool(self.dimx, self.dimy))
         c = capi.Config(self.dimx, self.dimy, cfg.SCALE, device, self.pool, engine, 0)
         h = C.c_void_p()
         rc = self.L.smx_create(C.byref(c), C.byref(h))
@@ -127,6 +137,13 @@ class Layermap:
         self._chk(self.L.smx_remove(self.h, x, y, h, C.byref(r)))
         return r.value
 
+    def digest(self) -> dict:
+        """The Appendix-E state digest (sum of heights, section count, type hash) + rand() draws consumed."""
+        sh, ns, th = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.smx_digest(self.h, C.byref(sh), C.byref(ns), C.byref(th)))
+        return {"sumh": sh.value, "nsec": int(ns.value), "typehash": f"{th.value:016x}",
+                "rand_calls": self.counters()["rand_calls"]}
+
     def counters(self) -> dict:
         c = capi.Counters()
         self._chk(self.L.smx_get_counters(self.h, C.byref(c)))
@@ -162,6 +179,17 @@ class SoilMachine:
             m._chk(m.L.smx_tick(m.h, self.nwater, self.nwind, int(self.dowater), int(self.dowind)))
         if sync:
             m.sync()
+            self._check_pool()
+
+    def _check_pool(self):
+        """The reference prints "Memory Pool Out-Of-Elements" and drops the section (layermap.h:92-95); here the
+        counter is surfaced as a warning whenever it has grown since the last synchronised tick."""
+        ov = self.map.counters()["pool_overflow"]
+        if ov > getattr(self, "_pool_overflow_seen", 0):
+            import warnings
+            warnings.warn(f"soilmx: section pool exhausted ({ov} pool.get() failures so far, capacity {self.map.pool}): "
+                          f"sections are being dropped exactly as the reference's POOLSIZE overflow does", RuntimeWarning)
+            self._pool_overflow_seen = ov
 
     # phase-by-phase access, as the reference's host loop spells it out
     def water(self, n=None): self.map._chk(self.map.L.smx_tick_water(self.map.h, self.nwater if n is None else n))

@@ -38,12 +38,25 @@ DIGEST_CASES = [
     ("sand256_t10", "sand.soil", dict(seed=0, ticks=10)),
     ("bigbutte2_128_t10", "bigbutte2.soil", dict(seed=5, size=128, ticks=10)),
     ("default1024_t5", "default.soil", dict(seed=0, size=1024, ticks=5, wind=False)),
+    # round 2: the remaining rows of SURVEY.md Appendix E and the BASELINE.json configs at depth
+    ("default256_t300", "default.soil", dict(seed=0, ticks=300, wind=False)),
+    ("default256_t1000", "default.soil", dict(seed=0, ticks=1000, wind=False)),
+    ("rgps1024_t3", "rockgravelpebblessand.soil", dict(seed=0, size=1024, ticks=3)),
+    ("rgpbig512_t10", "rockgravelpebbles_big.soil", dict(seed=0, ticks=10)),
+    ("default1024_t3_wind", "default.soil", dict(seed=0, size=1024, ticks=3)),          # BASELINE configs[2]
+    ("rgps4096_t5", "rockgravelpebblessand.soil", dict(seed=0, size=4096, ticks=5, pool=3 * 4096 * 4096)),   # configs[3]
+    ("rgpbig8192_t1", "rockgravelpebbles_big.soil", dict(seed=0, size=8192, ticks=1, pool=2 * 8192 * 8192)), # configs[4]
 ]
 
 
 def main():
-    digests = {}
-    for name, soil, kw, ticks in SNAP_CASES:
+    # `--only a,b,c`: (re)generate just these digest cases and merge them into the existing digests.json
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+    path = os.path.join(HERE, "digests.json")
+    digests = json.load(open(path)) if only is not None and os.path.exists(path) else {}
+    for name, soil, kw, ticks in ([] if only is not None else SNAP_CASES):
         with tempfile.TemporaryDirectory() as td:
             j = run_ref(os.path.join(REFSOIL, soil), ticks=max(ticks), dump_prefix=os.path.join(td, "r"), dump_at=ticks, **kw)
             for t in ticks:
@@ -56,13 +69,16 @@ def main():
                              steps_water_top=j["steps_water_top"], steps_wind=j["steps_wind"])
         print(name, digests[name]["nsec"], digests[name]["typehash"], flush=True)
     for name, soil, kw in DIGEST_CASES:
+        if only is not None and name not in only:
+            continue
         j = run_ref(os.path.join(REFSOIL, soil), **kw)
         kw2 = dict(kw); t = kw2.pop("ticks")
         digests[name] = dict(soil=soil, kw=kw2, ticks=t, nwater=j["nwater"], nwind=j["nwind"], dimx=j["dimx"], dimy=j["dimy"],
                              sumh=j["sumh"], nsec=j["nsec"], typehash=j["typehash"], rand_calls=j["rand_calls"],
                              steps_water_top=j["steps_water_top"], steps_wind=j["steps_wind"])
         print(name, j["nsec"], j["typehash"], flush=True)
-    json.dump(digests, open(os.path.join(HERE, "digests.json"), "w"), indent=1)
+        json.dump(digests, open(path, "w"), indent=1)
+    json.dump(digests, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":

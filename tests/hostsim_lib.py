@@ -8,6 +8,7 @@ import subprocess
 import numpy as np
 
 from soilmachine_amd.snapshot import Snapshot
+from soilmachine_amd.machine import default_pool
 from soilmachine_amd.soilfile import soils_array
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
@@ -63,7 +64,7 @@ class HostSim:
     def __init__(self, cfg, dimx, dimy, pool=None, seed=0):
         self.L = lib()
         self.cfg, self.dimx, self.dimy = cfg, dimx, dimy
-        self.pool = int(pool if pool is not None else max(8 * dimx * dimy, 1 << 20))
+        self.pool = int(pool if pool is not None else default_pool(dimx, dimy))
         self.h = self.L.hs_create(dimx, dimy, cfg.SCALE, self.pool)
         self._soils = soils_array(cfg)
         self.L.hs_set_soils(self.h, _p(self._soils), len(self._soils))

@@ -11,6 +11,7 @@ import subprocess
 import numpy as np
 
 from soilmachine_amd.snapshot import Snapshot
+from soilmachine_amd.machine import default_pool
 from soilmachine_amd.soilfile import SoilConfig, soils_array, layers_array
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,7 +94,7 @@ class Oracle:
     def __init__(self, cfg: SoilConfig, dimx: int, dimy: int, pool: int | None = None, seed: int = 0):
         self.L = lib()
         self.cfg, self.dimx, self.dimy = cfg, dimx, dimy
-        self.pool = int(pool if pool is not None else max(8 * dimx * dimy, 1 << 20))
+        self.pool = int(pool if pool is not None else default_pool(dimx, dimy))
         self.h = self.L.so_create(dimx, dimy, cfg.SCALE, self.pool)
         self._soils = soils_array(cfg)
         self.L.so_set_soils(self.h, _p(self._soils), len(self._soils))

@@ -1,0 +1,134 @@
+"""Parity at depth (round 2): the remaining rows of SURVEY.md Appendix E and the BASELINE.json configurations run for
+more than one tick on the device, against digests produced by the reference itself (tests/golden/make_golden.py).
+Bit-exact: section count, type hash, sequential sum of heights, number of rand() draws."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import digests, load_cfg, case_dims
+from oracle_lib import Oracle
+from soilmachine_amd import capi
+from soilmachine_amd.machine import Layermap, SoilMachine
+from soilmachine_amd.snapshot import compare
+from test_gpu_fullsize import column_invariants
+
+pytestmark = pytest.mark.gpu
+DIG = digests()
+
+
+def run_case(name, engine, pool=None):
+    d = DIG[name]
+    cfg = load_cfg(d["soil"])
+    dimx, dimy = case_dims(d, cfg)
+    kw = d["kw"]
+    sm = SoilMachine(cfg, dimx=dimx, dimy=dimy, seed=kw.get("seed", 0), nwater=d["nwater"], nwind=d["nwind"],
+                     dowind=kw.get("wind", True), engine=engine, pool=pool or kw.get("pool"))
+    sm.tick(d["ticks"], sync=True)
+    g = sm.map.digest()
+    assert (g["nsec"], g["typehash"], g["sumh"], g["rand_calls"]) == (d["nsec"], d["typehash"], d["sumh"], d["rand_calls"]), name
+    c = sm.map.counters()
+    assert c["steps_water_top"] == d["steps_water_top"] and c["steps_wind"] == d["steps_wind"]
+    assert c["pool_overflow"] == 0
+    return sm
+
+
+@pytest.mark.parametrize("case", ["rgps512_t20", "rgps1024_t3", "rgpbig512_t10", "default1024_t3_wind"])
+def test_appendix_e_and_config_digests(case):
+    """Appendix E: rgps 512^2 x 20, rgps 1024^2 x 3, rgp_big 512^2 x 10; BASELINE configs[2] (1024^2 default, wind on)."""
+    run_case(case, capi.ENGINE_SPECULATIVE)
+
+
+def test_device_digest_equals_snapshot_digest():
+    """smx_digest (C++ over a device->host copy) == the Python digest of the exported snapshot."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    sm = SoilMachine(cfg, 96, seed=3, nwater=80, nwind=40)
+    sm.tick(3, sync=True)
+    s = sm.map.snapshot()
+    g, w = sm.map.digest(), s.digest()
+    assert (g["nsec"], g["typehash"], g["sumh"]) == (w["nsec"], w["typehash"], w["sumh"])
+    assert g["rand_calls"] == s.rand_calls
+
+
+@pytest.mark.slow
+def test_4096_multilayer_five_ticks_reference_digest():
+    """BASELINE configs[3] at depth: 4096^2 rockgravelpebblessand, 5 ticks of 1000 water + 250 wind particles."""
+    sm = run_case("rgps4096_t5", capi.ENGINE_SPECULATIVE)
+    assert sm.map.counters()["spec_fallbacks"] == 0
+
+
+@pytest.mark.slow
+def test_8192_config4_init_one_tick_reference_digest_and_invariants():
+    """BASELINE configs[4]: 8192^2 rockgravelpebbles_big -- terrain + one tick bit-exact, structural invariants."""
+    sm = run_case("rgpbig8192_t1", capi.ENGINE_SPECULATIVE)
+    column_invariants(sm.map.snapshot())
+
+
+# ---------------------------------------------------------------- entry points that had no test in round 1
+def test_smx_top_matches_oracle_columns():
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 48
+    m = Layermap(cfg, n, n, seed=5)
+    o = Oracle(cfg, n, n, seed=5)
+    o.initialize()
+    for (x, y) in [(3, 4), (10, 10)]:                              # an emptied column and a water-topped one
+        for _ in range(8):
+            m.remove(x, y, 10.0); o.L.so_remove(o.h, x, y, 10.0)
+    m.add(7, 7, 0.02, 0); o.L.so_add(o.h, 7, 7, 0.02, 0)
+    s = o.snapshot()
+    end = np.cumsum(s.count.astype(np.int64))
+    for (x, y) in [(3, 4), (10, 10), (7, 7), (0, 0), (47, 47), (20, 31)]:
+        ty, sz, fl, sa, em = C.c_uint32(), C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        m._chk(m.L.smx_top(m.h, x, y, C.byref(ty), C.byref(sz), C.byref(fl), C.byref(sa), C.byref(em)))
+        c = x * n + y
+        if s.count[c] == 0:
+            assert em.value == 1 and ty.value == 0
+        else:
+            k = int(end[c]) - 1
+            assert em.value == 0
+            assert (ty.value, sz.value, fl.value, sa.value) == (int(s.type[k]), float(s.size[k]), float(s.floor[k]), float(s.sat[k]))
+    assert m.L.smx_top(m.h, n, 0, None, None, None, None, None) != 0      # out of bounds is an error, not a read
+
+
+def test_smx_rand_is_glibc_rand_and_shares_the_particle_stream():
+    cfg = load_cfg("default.soil")
+    m = Layermap(cfg, 32, 32, seed=42)
+    o = Oracle(cfg, 32, 32, seed=42)
+    o.initialize()
+    v = C.c_int32()
+    for _ in range(40):
+        m._chk(m.L.smx_rand(m.h, C.byref(v)))
+        assert v.value == o.L.so_rand(o.h)
+    # the particles draw from the same stream: run a phase on both sides, then compare the next draws again
+    m._chk(m.L.smx_tick_water(m.h, 25)); o.L.so_water_particles(o.h, 25)
+    for _ in range(5):
+        m._chk(m.L.smx_rand(m.h, C.byref(v)))
+        assert v.value == o.L.so_rand(o.h)
+    assert not compare(m.snapshot(), o.snapshot())
+
+
+def test_smx_set_scale_changes_the_dynamics_like_the_global():
+    """SCALE is a live global in the reference (SoilMachine.cpp:11, GUI slider :127): changing it mid-run must act on
+    normals, cascades and concentrations from the next tick on."""
+    cfg = load_cfg("rocksand.soil")
+    n = 64
+    sm = SoilMachine(cfg, n, seed=2, nwater=60, nwind=30)
+    o = Oracle(cfg, n, n, seed=2)
+    o.initialize()
+    sm.tick(2); o.tick(60, 30); o.tick(60, 30)
+    sm.map._chk(sm.map.L.smx_set_scale(sm.map.h, 45)); o.L.so_set_scale(o.h, 45)
+    sm.tick(2, sync=True); o.tick(60, 30); o.tick(60, 30)
+    got, want = sm.map.snapshot(), o.snapshot()
+    want.scale = got.scale                                         # (the snapshot header carries the creation-time SCALE)
+    assert not compare(got, want)
+
+
+def test_initialize_refuses_a_pool_that_cannot_hold_the_terrain():
+    """cells * layers > pool_capacity used to wrap the free-node counter on the device."""
+    cfg = load_cfg("rockgravelpebblessand.soil")                   # two LAYER blocks
+    with pytest.raises(Exception):
+        Layermap(cfg, 64, 64, seed=0, pool=64 * 64 + 100)
+    m = Layermap(cfg, 64, 64, seed=0, pool=2 * 64 * 64)            # exactly the worst case: accepted, and exact
+    o = Oracle(cfg, 64, 64, seed=0, pool=2 * 64 * 64)
+    o.initialize()
+    assert not compare(m.snapshot(), o.snapshot())
