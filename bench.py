@@ -101,7 +101,8 @@ def main():
     nwater = cfg.NWATER if args.nwater is None else args.nwater
     nwind = cfg.NWIND if args.nwind is None else args.nwind
     n = args.size
-    engine = {"auto": capi.ENGINE_SPECULATIVE, "serial": capi.ENGINE_SERIAL, "spec": capi.ENGINE_SPECULATIVE}[args.engine]
+    engine = {"auto": capi.ENGINE_SPECULATIVE, "serial": capi.ENGINE_SERIAL, "spec": capi.ENGINE_SPECULATIVE,
+              "batched": capi.ENGINE_BATCHED}[args.engine]
     pool = 3 * n * n
     seed = distrib.replica_seed(rank)   # replicas: independent worlds, SEED = rank (rank 0 == BASELINE's SEED 0)
     sm = SoilMachine(cfg, n, seed=seed, nwater=nwater, nwind=nwind, pool=pool, device=local_rank, engine=engine)
@@ -171,7 +172,7 @@ def main():
                                   "wind": tm["ms_wind"] / args.steps, "freq": tm["ms_freq"] / args.steps},
             "steps_per_tick": {"water": steps_w / args.steps, "wind": steps_d / args.steps,
                                "nested_particles": (c1["nested_particles"] - c0["nested_particles"]) / args.steps},
-            "engine_stats": {k: c1[k] - c0[k] for k in ("spec_rounds", "spec_aborts", "spec_fallbacks", "spec_executed")},
+            "engine_stats": dict({k: c1[k] - c0[k] for k in ("spec_rounds", "spec_aborts", "spec_fallbacks", "spec_executed")}, **m.batch_stats()),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

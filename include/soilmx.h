@@ -37,7 +37,10 @@ typedef struct smx_layer {
 } smx_layer;
 
 enum { SMX_ENGINE_SERIAL = 0,      /* one device walker, reference order (parity anchor)            */
-       SMX_ENGINE_SPECULATIVE = 1  /* optimistic parallel particles, ordered commit, same results    */ };
+       SMX_ENGINE_SPECULATIVE = 1, /* optimistic parallel particles, ordered commit, same results    */
+       SMX_ENGINE_BATCHED = 2      /* THROUGHPUT mode: all particles of a phase advance concurrently, one step
+                                      per epoch, each step atomic and isolated (claim tiles). Deterministic, but NOT
+                                      the reference's particle order: statistical parity only        */ };
 
 typedef struct smx_config {
   int32_t dimx, dimy;              /* SIZEX, SIZEY (SoilMachine.cpp:9-10)                            */
@@ -140,6 +143,11 @@ int smx_get_counters(smx_ctx* ctx, smx_counters* out);
 int smx_get_timing(smx_ctx* ctx, smx_timing* out);
 int smx_timing_reset(smx_ctx* ctx);
 int smx_set_engine(smx_ctx* ctx, int32_t engine);
+/* batched engine only: widen every reservation by `tiles` 4x4-cell tiles (0 = default; >= the map's tile count makes
+ * the engine run the particles strictly one after the other, i.e. in the reference's order) */
+int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles);
+/* batched engine: epochs (kernel rounds), generations and dropped child particles since the context was created */
+int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost);
 void* smx_stream(smx_ctx* ctx);                          /* the hipStream_t all work is queued on */
 
 #ifdef __cplusplus

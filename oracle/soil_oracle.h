@@ -69,6 +69,15 @@ double so_remove(so_ctx*, int x, int y, double h);
 void so_particle_cascade(so_ctx*, float px, float py, int transferloop);
 void so_water_cascade(so_ctx*, int x, int y, int spill);
 void so_seep(so_ctx*, int x, int y);
+// The BATCHED schedule (throughput engine, soilmachine_amd/csrc/soil_batch.h) restated on the CPU: same per-step
+// functions, the engine's own definition of who acts when. Checker for the batched HIP path (bit-exact); NOT a model of
+// the reference's particle order. stats: {epochs, generations, cells touched outside the acting particle's tiles (must be 0)}
+void so_batched_water(so_ctx*, int n);
+void so_batched_grid(so_ctx*);
+void so_batched_wind(so_ctx*, int n);
+void so_batched_tick(so_ctx*, int nwater, int nwind, int dowater, int dowind);
+void so_batched_set_dilate(so_ctx*, int tiles);
+void so_batched_stats(so_ctx*, uint64_t* out3);
 // dependency analysis between particles of one phase (evidence for DESIGN.md, not a simulation feature):
 // out7 = {tasks, DAG depth (in-place: RAW+WAW+WAR), DAG depth (multi-version: RAW+WAW), conflict-free tasks,
 //         step-granular critical path, total steps, sum of levels}; counters restart at every phase.

@@ -1,0 +1,393 @@
+// soil_batch.h -- the BATCHED (throughput) engine: every particle of a phase advances concurrently, one particle per
+// LANE, one step per epoch. This is the north-star's "one wavefront per particle-batch" path; it does NOT reproduce
+// the reference's particle-after-particle order (SoilMachine.cpp:287-307) and is never claimed bit-exact against the
+// reference (DESIGN.md "Batched engine", parity tier P2). It IS deterministic, and bit-exact against its own CPU
+// restatement (oracle/soil_oracle.cpp so_batched_*), because every step is executed ATOMICALLY AND IN ISOLATION:
+//
+//   * a step of the reference (move() + interact(), water.h:43-121 / wind.h:54-136; or flood(), water.h:123-145) is run
+//     by exactly the code of soil_core.h, unchanged, on the live map -- what changes is only the interleaving of the
+//     steps of different particles.
+//   * claim tiles: the map is cut into 4x4-cell tiles. Before a step a particle reserves every tile its step can touch
+//     (a bounding rectangle, see *_intent below) with an atomic max of {epoch, ~slot} on a claim plane; in the next
+//     kernel it acts only if it holds ALL of them -- the lowest slot wins a contested tile, the others simply try
+//     again in the following epoch. Winners of one epoch therefore have disjoint footprints: the epoch's result does
+//     not depend on the order in which the hardware runs them, plain loads and stores suffice, and no undo log exists.
+//   * two claim planes alternate (epoch parity): kernel e checks plane[e&1] (complete since kernel e-1 ended) and
+//     writes the reservations for epoch e+1 into the other one.
+//   * one kernel per epoch. A winner recomputes its move from the map (its tiles are exclusively its own), acts, then
+//     looks ahead (a side-effect-free move() on the block it already holds) to learn which tiles the NEXT step needs.
+//     A loser re-issues its reservation without reading anything.
+//   * nested particles (water.h:246-264) are not run inside their parent: the flood emits a child record; children
+//     are sorted by (parent, sequence) and run as the next GENERATION of the phase, consuming the rand() draws that
+//     follow the phase's own (2 per particle, 1st -> y, 2nd -> x as everywhere).
+//   * grid pass (water.h:335-343): a cell's seep + cascade(.., 3) reaches 4 cells = one tile around it, so tiles whose
+//     indices differ by >= 3 are independent: 9 colour passes (tx mod 3, ty mod 3), one thread per tile walking its
+//     16 cells in x-major order.
+#pragma once
+#include "soil_core.h"
+#include "soil_spec.h"   // SMX_A_* atomics (device / host-sim)
+
+namespace smx {
+
+constexpr int TILE_SHIFT = 2;                 // 4x4 cells per claim tile
+constexpr uint32_t B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3;   // B_NEW: top-level particle that has not acted yet
+constexpr int B_MAXCHILD = 24;                // nested particles one flood / one grid tile may emit per pass
+
+struct BRect { int tx0, tx1, ty0, ty1; };     // inclusive tile ranges; tx1 < tx0: empty
+
+// c_*: this slot's share of the step / cascade counters (summed into DevState::ctr when the generation ends: an atomic
+// per particle and epoch on five shared words would serialise the whole epoch)
+struct BWater { Water w; BRect rect; uint32_t state, toplevel; uint32_t c_steps, c_casc, c_tr, pad; };
+struct BWind { Wind d; BRect rect; uint32_t state, pad; uint32_t c_steps, c_casc, c_tr, pad2; };
+struct BChild {                               // a nested WaterParticle waiting for the next generation
+  unsigned long long key;                     // (parent << 8) | sequence: the deterministic order of the children
+  int tx, ty, bx, by, spill, pad;
+  double volume;
+};
+
+enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_COUNT = 16 };
+
+struct BatchShared {
+  unsigned long long* claim[2];               // [ntx * nty] each
+  int ntx, nty;
+  BWater* water; BWind* wind;                 // slots of the current generation
+  uint32_t* live;                             // indices of the slots that are not DONE (rebuilt by batch_compact)
+  BChild* children; uint32_t child_cap;
+  uint32_t* freed; uint32_t freed_cap;        // pool nodes released during a kernel (pushed back between kernels)
+  uint32_t* ctrl;                             // BCtrl
+  const uint32_t* draws;                      // rand() values (already >> 1) of this generation: 2 per slot
+  int dilate;                                 // reservations are widened by this many tiles on every side (see bdilate)
+  int maxsteps;                               // actions one particle may take in one epoch while it stays inside the tiles it holds
+};
+
+SMX_D unsigned long long btag(uint32_t epoch, uint32_t slot) { return ((unsigned long long)(epoch + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - slot); }
+SMX_D bool brect_empty(const BRect& r) { return r.tx1 < r.tx0; }
+SMX_D bool brect_contains(const BRect& a, const BRect& b) {   // b inside a
+  return !brect_empty(a) && b.tx0 >= a.tx0 && b.tx1 <= a.tx1 && b.ty0 >= a.ty0 && b.ty1 <= a.ty1;
+}
+// tiles of the cell rectangle [x0,x1] x [y0,y1], clipped to the map
+SMX_D BRect brect_cells(const DevState& s, int x0, int x1, int y0, int y1) {
+  x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
+  x1 = x1 > s.dimx - 1 ? s.dimx - 1 : x1; y1 = y1 > s.dimy - 1 ? s.dimy - 1 : y1;
+  BRect r; r.tx0 = x0 >> TILE_SHIFT; r.tx1 = x1 >> TILE_SHIFT; r.ty0 = y0 >> TILE_SHIFT; r.ty1 = y1 >> TILE_SHIFT;
+  return r;
+}
+// A reservation covers the tiles the action can touch PLUS a margin of `dilate` tiles: two particles act in the same
+// epoch only if they are more than 2*dilate tiles apart. Without the margin the engine is still deterministic and
+// race-free, but particles that drain into the same pit keep disturbing each other and no single one ever levels its
+// spot to the 1e-5 flatness that ends a move() (water.h:56) -- the event that seeds every lake in the reference, where
+// a particle has the map to itself. The margin gives the lowest particle of a neighbourhood that quiet.
+SMX_D BRect bdilate(const BatchShared& bs, const BRect& r) {
+  if (brect_empty(r) || bs.dilate <= 0) return r;
+  BRect o;
+  o.tx0 = r.tx0 - bs.dilate < 0 ? 0 : r.tx0 - bs.dilate; o.tx1 = r.tx1 + bs.dilate > bs.ntx - 1 ? bs.ntx - 1 : r.tx1 + bs.dilate;
+  o.ty0 = r.ty0 - bs.dilate < 0 ? 0 : r.ty0 - bs.dilate; o.ty1 = r.ty1 + bs.dilate > bs.nty - 1 ? bs.nty - 1 : r.ty1 + bs.dilate;
+  return o;
+}
+SMX_D void bclaim(const BatchShared& bs, int plane, const BRect& r, unsigned long long tag) {
+  for (int tx = r.tx0; tx <= r.tx1; tx++)
+    for (int ty = r.ty0; ty <= r.ty1; ty++) (void)SMX_A_MAX64(&bs.claim[plane][(size_t)tx * bs.nty + ty], tag);
+}
+SMX_D bool bholds(const BatchShared& bs, int plane, const BRect& r, unsigned long long tag) {
+  bool ok = true;
+  for (int tx = r.tx0; tx <= r.tx1; tx++)
+    for (int ty = r.ty0; ty <= r.ty1; ty++) ok &= (bs.claim[plane][(size_t)tx * bs.nty + ty] == tag);
+  return ok;
+}
+
+// ---------------- access policy: direct access (exclusive by construction), shared pool through atomics ----------------
+struct BatchPolicy {
+  static constexpr bool READ_ONLY = false;
+  static constexpr bool DEFER_NESTED = true;
+  const BatchShared& bs;
+  unsigned long long live0;                   // live sections when the kernel started (+ what this thread added)
+  long long live_delta = 0;
+  unsigned long long parent = 0;              // key prefix of the children this thread emits
+  uint32_t nchild = 0;
+  uint32_t a_steps = 0, a_casc = 0, a_tr = 0; // frequent counters: kept per slot, see BWater::c_*
+  SMX_D BatchPolicy(const DevState& s, const BatchShared& b) : bs(b), live0(s.ctr[C_LIVE_SECTIONS]) {}
+  template <int N> struct Pre {};
+  SMX_D void save_blk(const Blk&) {}
+  SMX_D void load_blk(Blk&) {}
+  SMX_D bool touch(const DevState&, size_t, size_t) { return true; }
+  template <int N> SMX_D void prefetch(const DevState&, const size_t (&)[N], const size_t (&)[N], Pre<N>&) {}
+  template <int N> SMX_D bool acquire_log(const DevState&, const size_t (&)[N], const Pre<N>&, const Sec (&)[N]) { return true; }
+  SMX_D void pre_write_node(const DevState&, uint32_t) {}
+  SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (!(v & f)) s.flags[c] = v | f; }
+  SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (v & f) s.flags[c] = v & (uint8_t)~f; }
+  // secpool::get (layermap.h:89-103) fails when live sections == capacity. Concurrent particles see the count as of
+  // the kernel's start plus their own additions: exact while the pool has headroom (the host checks), approximate
+  // in the last few sections before exhaustion -- stated in DESIGN.md.
+  SMX_D bool can_get(const DevState& s) const { return (long long)live0 + live_delta < (long long)s.pool_capacity; }
+  SMX_D void live_add(const DevState&, int d) { live_delta += d; }
+  SMX_D uint32_t node_alloc(const DevState& s) {            // pops only during a kernel (frees are deferred): lock-free
+    const uint32_t old = SMX_A_SUB(s.free_count, 1u);
+    if (old == 0u || old > (uint32_t)s.pool_capacity) { SMX_A_ADD(s.free_count, 1u); return NIL; }
+    return s.freelist[old - 1u];
+  }
+  SMX_D void node_free(const DevState&, uint32_t e) {
+    const uint32_t k = SMX_A_ADD(&bs.ctrl[BC_NFREED], 1u);
+    if (k < bs.freed_cap) bs.freed[k] = e; else SMX_A_ADD(&bs.ctrl[BC_FREED_LOST], 1u);
+  }
+  SMX_D void rand2(const DevState&, int& a, int& b) { a = 0; b = 0; }   // (nested particles draw when their generation starts)
+  SMX_D bool child_room() const { return nchild < (uint32_t)B_MAXCHILD; }
+  SMX_D void emit_child(int tx, int ty, int bx, int by, int spill, double volume) {
+    const uint32_t k = SMX_A_ADD(&bs.ctrl[BC_NCHILD], 1u);
+    if (k >= bs.child_cap) { SMX_A_ADD(&bs.ctrl[BC_CHILD_LOST], 1u); nchild++; return; }
+    BChild& c = bs.children[k];
+    c.key = (parent << 8) | (unsigned long long)nchild; nchild++;
+    c.tx = tx; c.ty = ty; c.bx = bx; c.by = by; c.spill = spill; c.pad = 0; c.volume = volume;
+  }
+  SMX_D void add_counter(const DevState& s, int which, unsigned long long v) {
+    if (!v) return;
+    if (which == C_STEPS_WATER_ALL || which == C_STEPS_WIND) a_steps += (uint32_t)v;      // (top-level steps: by the slot's flag)
+    else if (which == C_STEPS_WATER_TOP) {}
+    else if (which == C_CASCADE_CALLS) a_casc += (uint32_t)v;
+    else if (which == C_CASCADE_TRANSFERS) a_tr += (uint32_t)v;
+    else SMX_A_ADD64(&s.ctr[which], v);                                                   // floods, nested, overflow: rare
+  }
+  SMX_D void finish(const DevState& s) { if (live_delta) SMX_A_ADD64(&s.ctr[C_LIVE_SECTIONS], (unsigned long long)live_delta); live_delta = 0; }
+};
+
+// ---------------- intents: which tiles can the NEXT action of this particle touch? (pure functions of particle + block) ----
+// Water, running: a step = move() at ipos (plus-stencil, track word) + interact(): remove/add at ipos, bilinear height and
+// Particle::cascade(.., 0) in the 3x3 around npos = round(new pos)  ->  bbox(3x3(ipos) u 3x3(npos)).
+// A move() that returns false (stall, out of bounds) has still READ the plus-stencil of ipos to decide that (and
+// writes ipos's track word): the 3x3 around ipos stays reserved, or the decision itself would race with a neighbour.
+template <class P>
+SMX_D BRect water_intent_run(Sim<P>& sim, const Water& w, const Blk& blk) {
+  Water t = w;
+  const bool mv = sim.template water_move<true>(t, false, blk);
+  if (!mv) return brect_cells(sim.s, w.ix - 1, w.ix + 1, w.iy - 1, w.iy + 1);
+  const int nx = (int)roundf(t.pos.x), ny = (int)roundf(t.pos.y);
+  const int x0 = (w.ix < nx ? w.ix : nx) - 1, x1 = (w.ix > nx ? w.ix : nx) + 1;
+  const int y0 = (w.iy < ny ? w.iy : ny) - 1, y1 = (w.iy > ny ? w.iy : ny) + 1;
+  return brect_cells(sim.s, x0, x1, y0, y1);
+}
+// Water, move/interact loop over: flood() (water.h:123-145) or nothing. The flood acts around trunc(pos): sediment +
+// water added there, Particle::cascade in the 3x3 around round(pos), seep, and WaterParticle::cascade whose recursion
+// (one level per unit of spill, water.h:278-279) reaches `spill` cells + 1 ... = radius max(spill, 2) in all.
+SMX_D bool water_floods(const Water& w) { return !(w.volume < 0.01 || w.spill <= 0); }   // the gate of water.h:125
+SMX_D BRect water_intent_flood(const DevState& s, const Water& w) {
+  const int R = w.spill > 2 ? w.spill : 2;
+  const int fx = (int)w.pos.x, fy = (int)w.pos.y;
+  return brect_cells(s, fx - R, fx + R, fy - R, fy + R);
+}
+// Wind, running: move() at ipos (plus-stencil, frequency word) + interact(): remove at ipos / add at npos and ipos,
+// Particle::cascade(.., 1) around both with one level of recursion  ->  bbox(5x5(ipos) u 5x5(npos)).
+template <class P>
+SMX_D BRect wind_intent_run(Sim<P>& sim, const Wind& d, const Blk& blk) {
+  Wind t = d;
+  const bool mv = sim.template wind_move<true>(t, blk);
+  if (!mv) return brect_cells(sim.s, d.ix - 1, d.ix + 1, d.iy - 1, d.iy + 1);
+  const int nx = (int)roundf(t.pos.x), ny = (int)roundf(t.pos.y);
+  const int x0 = (d.ix < nx ? d.ix : nx) - 2, x1 = (d.ix > nx ? d.ix : nx) + 2;
+  const int y0 = (d.iy < ny ? d.iy : ny) - 2, y1 = (d.iy > ny ? d.iy : ny) + 2;
+  return brect_cells(sim.s, x0, x1, y0, y1);
+}
+
+// ---------------- generation start: construct the particles, publish their first reservations (plane 0, epoch 0) -------
+// top-level particle `slot` of a phase: WaterParticle(map) (water.h:11-19) from draws 2*slot (-> y), 2*slot+1 (-> x)
+template <class P>
+SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, const BChild* child) {
+  const DevState& s = sim.s;
+  BWater& q = bs.water[slot];
+  const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
+  Water w;
+  sim.water_init(w, rx, ry);
+  q.toplevel = child ? 0u : 1u;
+  if (child) {                                               // water.h:251-256: position, direction, volume, spill of a nested particle
+    const f2 d = {(float)child->bx - (float)child->tx, (float)child->by - (float)child->ty};
+    const f2 dn = normalize2(d);
+    const float s2 = sqrtf(2.0f);
+    w.speed = {s2 * dn.x, s2 * dn.y};
+    w.pos = {(float)child->tx, (float)child->ty};
+    w.spill = child->spill;
+    w.volume = child->volume;
+  }
+  w.ix = (int)roundf(w.pos.x); w.iy = (int)roundf(w.pos.y);
+  Blk A;
+  sim.template load_block<0>(w.ix, w.iy, A);
+  // A top-level particle reads what it `contains` from its spawn cell (water.h:15-17) when it first ACTS, not now: the
+  // reference constructs a particle right before it runs, so it sees what earlier particles did to that cell. (A nested
+  // particle takes it from a random cell somewhere on the map, water.h:251 -- that read happens here, where nothing writes.)
+  q.w = w; q.state = child ? B_RUN : B_NEW;
+  q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad = 0;
+  q.rect = bdilate(bs, water_intent_run(sim, w, A));
+  bclaim(bs, 0, q.rect, btag(0u, slot));
+}
+template <class P>
+SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
+  const DevState& s = sim.s;
+  BWind& q = bs.wind[slot];
+  const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
+  Wind d;
+  sim.wind_init(d, rx, ry);
+  q.d = d; q.pad = 0; q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad2 = 0;
+  Blk A;
+  sim.template load_block<1>(d.ix, d.iy, A);
+  q.state = B_NEW;                                           // `contains` (wind.h:19-21) is read when the particle first acts
+  q.rect = bdilate(bs, wind_intent_run(sim, d, A));
+  bclaim(bs, 0, q.rect, btag(0u, slot));
+}
+
+// ---------------- one epoch of one particle ----------------
+// A particle that holds its reservation acts; while the NEXT action still lies inside the tiles it holds (they are
+// exclusively its own until this kernel ends) it may go on, up to bs.maxsteps actions per epoch -- with a margin
+// (bs.dilate) a lone particle advances several steps per kernel, which is what keeps the long tail of a phase (a few
+// far-travelling wind particles, a queue of floods in one pit) from costing one kernel launch per step.
+template <class P>
+SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch, Frame* st) {
+  const DevState& s = sim.s;
+  BWater& q = bs.water[slot];
+  uint32_t state = q.state;
+  if (state == B_DONE) return;
+  BRect rect = q.rect;
+  const int cur = (int)(epoch & 1u), nxt = cur ^ 1;
+  if (bholds(bs, cur, rect, btag(epoch, slot))) {
+    const BRect held = rect;
+    Water w = q.w;
+    Blk A, B;
+    bool haveA = false;
+    int acted = 0;
+    while (true) {
+      BRect need;
+      if (state == B_RUN || state == B_NEW) {
+        if (!haveA) sim.template load_block<0>(w.ix, w.iy, A);
+        need = water_intent_run(sim, w, A);
+      } else {                                               // B_ENDED: flood() or nothing (water.h:125)
+        if (!water_floods(w)) { state = B_DONE; break; }
+        need = water_intent_flood(s, w);
+      }
+      if (acted >= bs.maxsteps || !brect_contains(held, need)) { rect = bdilate(bs, need); break; }   // reserve it for the next epoch
+      acted++;
+      if (state == B_NEW) {                                  // WaterParticle(map) water.h:15-17, on the map as it is NOW
+        w.surface = Sim<P>::vsurf(A.v8);
+        w.friction = sim.soils[w.surface].friction;
+        w.contains = sim.soils[w.surface].transports;
+        state = B_RUN;
+      }
+      if (state == B_RUN) {
+        if (sim.water_move(w, q.toplevel != 0u, A)) {        // water.h:43-73 (writes the track word)
+          const int r = sim.water_interact(w, A, B);         // water.h:75-121
+          if (r == 0) state = B_ENDED;
+          else { A = B; haveA = true; }                      // B = the exact block around the new ipos
+        } else state = B_ENDED;
+      } else {                                               // flood (water.h:123-145); nested particles -> children
+        sim.pol.parent = (unsigned long long)slot; sim.pol.nchild = 0;
+        int depth = 0;
+        if (sim.water_flood_prelude(w)) sim.push_frame(st, depth, w.ix, w.iy, w.spill);
+        sim.water_drive(w, false, false, st, depth);
+        state = B_DONE;
+        break;
+      }
+    }
+    q.w = w; q.state = state;
+    if (state == B_DONE) rect = BRect{0, -1, 0, -1};
+    q.rect = rect;
+    sim.flush_counters();
+    q.c_steps += sim.pol.a_steps; q.c_casc += sim.pol.a_casc; q.c_tr += sim.pol.a_tr;
+    sim.pol.a_steps = sim.pol.a_casc = sim.pol.a_tr = 0;
+  }
+  if (state != B_DONE) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
+}
+
+template <class P>
+SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
+  BWind& q = bs.wind[slot];
+  uint32_t state = q.state;
+  if (state == B_DONE) return;
+  BRect rect = q.rect;
+  const int cur = (int)(epoch & 1u), nxt = cur ^ 1;
+  if (bholds(bs, cur, rect, btag(epoch, slot))) {
+    const BRect held = rect;
+    Wind d = q.d;
+    Blk A, B;
+    bool haveA = false;
+    int acted = 0;
+    while (true) {
+      if (!haveA) sim.template load_block<1>(d.ix, d.iy, A);
+      const BRect need = wind_intent_run(sim, d, A);
+      if (acted >= bs.maxsteps || !brect_contains(held, need)) { rect = bdilate(bs, need); break; }
+      acted++;
+      if (state == B_NEW) {                                  // WindParticle(map) wind.h:19-21 + the gate of wind.h:56-57
+        d.surface = Sim<P>::vsurf(A.v8);
+        d.contains = sim.soils[d.surface].transports;
+        state = B_RUN;
+        if (sim.soils[d.contains].suspension == 0.0) { state = B_DONE; break; }
+      }
+      if (sim.wind_move(d, A)) {                             // wind.h:54-92 (writes the frequency word)
+        sim.wind_interact(d, A, B);                          // wind.h:94-136 (always true); B = exact block around the new ipos
+        A = B; haveA = true;
+      } else { state = B_DONE; break; }
+    }
+    q.d = d; q.state = state;
+    if (state == B_DONE) rect = BRect{0, -1, 0, -1};
+    q.rect = rect;
+    sim.flush_counters();
+    q.c_steps += sim.pol.a_steps; q.c_casc += sim.pol.a_casc; q.c_tr += sim.pol.a_tr;
+    sim.pol.a_steps = sim.pol.a_casc = sim.pol.a_tr = 0;
+  }
+  if (state != B_DONE) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
+}
+
+// The schedule of a generation (part of the engine's definition: the CPU restatement follows the same rule): margin
+// and steps per epoch as a function of how many particles are still running when a chunk of epochs starts.
+// Many particles: tight reservations, every step its own epoch (conflicts are what limits progress). Few particles:
+// wide margins, many steps per kernel (kernel launches are what limits progress).
+#ifdef SMX_HOSTSIM
+inline
+#else
+__host__ __device__ inline
+#endif
+void batch_schedule(uint32_t nlive, int base_dilate, int& dilate, int& maxsteps) {
+  int d = 0, k = 1;
+  if (nlive <= 32768u) { d = 1; k = 4; }
+  if (nlive <= 4096u) { d = 2; k = 8; }
+  if (nlive <= 512u) { d = 4; k = 16; }
+  dilate = base_dilate > d ? base_dilate : d;
+  maxsteps = k;
+}
+
+// ---------------- grid pass: one colour, one tile ----------------
+// WaterParticle::seep(map) (water.h:335-343) for the ACTIVE cells (classification bitmap, soilmx.hip k_grid_classify)
+// of tile (tx, ty), x-major inside the tile; nested particles become children keyed by (colour pass, tile, sequence).
+template <class P>
+SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned long long key, Frame* st) {
+  const DevState& s = sim.s;
+  sim.pol.parent = key; sim.pol.nchild = 0;
+  Water dummy;
+  dummy.pos = {0.f, 0.f}; dummy.speed = {0.f, 0.f}; dummy.volume = 0.0; dummy.sediment = 0.0; dummy.evaprate = 0.0;
+  dummy.spill = 0; dummy.ix = dummy.iy = 0; dummy.friction = 0.f; dummy.surface = dummy.contains = 0;
+  unsigned long long visited = 0;
+  const int x0 = tx << TILE_SHIFT, y0 = ty << TILE_SHIFT;
+  for (int x = x0; x < x0 + (1 << TILE_SHIFT) && x < s.dimx; x++)
+    for (int y = y0; y < y0 + (1 << TILE_SHIFT) && y < s.dimy; y++) {
+      const size_t c = (size_t)x * s.dimy + y;
+      if (!((s.active[c >> 6] >> (c & 63)) & 1ull)) continue;
+      int depth = 0;
+      sim.seep(x, y);                                        // water.h:339
+      sim.push_frame(st, depth, x, y, 3);                    // water.h:340
+      sim.water_drive(dummy, false, false, st, depth);
+      visited++;
+    }
+  sim.flush_counters();                                      // (cascade counters of the grid pass go straight to DevState::ctr)
+  if (sim.pol.a_casc) SMX_A_ADD64(&s.ctr[C_CASCADE_CALLS], (unsigned long long)sim.pol.a_casc);
+  if (sim.pol.a_tr) SMX_A_ADD64(&s.ctr[C_CASCADE_TRANSFERS], (unsigned long long)sim.pol.a_tr);
+  sim.pol.a_casc = sim.pol.a_tr = 0;
+  return visited;
+}
+
+// generation end: the per-slot counters of slot `i` (device: wave-reduced before the atomics)
+SMX_D void batch_slot_counters(const BatchShared& bs, bool wind, uint32_t i, unsigned long long (&acc)[4]) {
+  if (wind) { const BWind& q = bs.wind[i]; acc[0] += q.c_steps; acc[2] += q.c_casc; acc[3] += q.c_tr; }
+  else { const BWater& q = bs.water[i]; acc[0] += q.c_steps; if (q.toplevel) acc[1] += q.c_steps; acc[2] += q.c_casc; acc[3] += q.c_tr; }
+}
+SMX_D void batch_commit_counters(const DevState& s, bool wind, const unsigned long long (&acc)[4]) {
+  if (acc[0]) SMX_A_ADD64(&s.ctr[wind ? C_STEPS_WIND : C_STEPS_WATER_ALL], acc[0]);
+  if (!wind && acc[1]) SMX_A_ADD64(&s.ctr[C_STEPS_WATER_TOP], acc[1]);
+  if (acc[2]) SMX_A_ADD64(&s.ctr[C_CASCADE_CALLS], acc[2]);
+  if (acc[3]) SMX_A_ADD64(&s.ctr[C_CASCADE_TRANSFERS], acc[3]);
+}
+
+}  // namespace smx

@@ -854,6 +854,8 @@ struct Sim {
     f.ix = ix; f.iy = iy; f.spill = spill; f.num = sn.num; f.i = 0; f.codes = sn.codes;
   }
   // WaterParticle::move (water.h:43-73) on the carried block `cur` around ipos. false = move() returned false.
+  // PURE: the batched engine's look-ahead -- where would this move go? No track write, no counters.
+  template <bool PURE = false>
   SMX_D bool water_move(Water& p, bool toplevel, const Blk& cur) {
     const View cv = cur.v8;
     const f3 n = normal_blk(p.ix, p.iy, cur);
@@ -861,7 +863,7 @@ struct Sim {
     p.evaprate = 0.01;
     const size_t fi = fidx(p.ix, p.iy);
     const float fr = cur.fr;
-    if constexpr (!P::READ_ONLY)
+    if constexpr (!P::READ_ONLY && !PURE)
       s.wtrack[fi] = (float)((double)cur.tr + p.volume);                 // updatefrequency :348-351
     p.friction = soils[p.surface].friction * (1.0f - fr);
     p.evaprate = p.evaprate * (double)(1.0f - 0.2f * fr);
@@ -879,8 +881,10 @@ struct Sim {
       p.volume = 0.0;
       return false;
     }
-    n_steps_w_all++;
-    if (toplevel) n_steps_w_top++;
+    if constexpr (!PURE) {
+      n_steps_w_all++;
+      if (toplevel) n_steps_w_top++;
+    }
     return true;
   }
   // WaterParticle::interact (water.h:75-121): `cur` is the block around ipos, `nb` receives the block around the
@@ -944,6 +948,7 @@ struct Sim {
     }
   }
   // WindParticle::move (wind.h:54-92) on the carried block; false = move() returned false
+  template <bool PURE = false>
   SMX_D bool wind_move(Wind& p, const Blk& cur) {
     const f3 pspeed = {-2.f, 0.f, 1.f};
     const double gravity = 0.25, winddominance = 0.2, windfriction = 0.8;
@@ -951,7 +956,7 @@ struct Sim {
     const f3 n = normal_blk(p.ix, p.iy, cur);
     p.surface = vsurf(cv);
     const size_t fi = fidx(p.ix, p.iy);
-    if constexpr (!P::READ_ONLY)
+    if constexpr (!P::READ_ONLY && !PURE)
       s.windfreq[fi] = (float)(0.5 * cur.tr + 0.5f);                     // wind.h:49-52
     p.sheight = vh(cv) * (float)s.scale / 80.0f;
     if (p.height < p.sheight) p.height = p.sheight;
@@ -967,7 +972,7 @@ struct Sim {
     p.height += p.speed.y;
     if (!(p.pos.x >= 0.0f && p.pos.y >= 0.0f) || !((int)p.pos.x < s.dimx - 1 && (int)p.pos.y < s.dimy - 1)) return false;
     if (sqrtf(dot3(p.speed, p.speed)) < 0.01) return false;
-    n_steps_wind++;
+    if constexpr (!PURE) n_steps_wind++;
     return true;
   }
   // WindParticle::interact (wind.h:94-136). 1 = go on (interact() always returns true), 0 = aborted somewhere
@@ -1096,6 +1101,14 @@ struct Sim {
       transfer = (wh < transfer) ? wh : transfer;
       if (transfer <= 0) continue;
       if (transfer == wh) {                                 // :246-264 the whole water section leaves: nested particle
+        if constexpr (P::DEFER_NESTED) {                    // batched engine: the nested particle joins the next generation
+          if (!pol.child_room()) continue;                  // spawn buffer full: the water stays where it is
+          remove(tx, ty, transfer);
+          n_nested++;
+          pol.emit_child(tx, ty, bx, by, f.spill, transfer / 0.015);
+          if (ab) return;
+          continue;                                         // (recascade is false on this branch: no recursion, :278)
+        }
         remove(tx, ty, transfer);
         n_nested++;
         int ry, rx;

@@ -61,6 +61,16 @@ inline uint32_t host_atomic_cas(uint32_t* p, uint32_t expected, uint32_t desired
 }
 }  // namespace smx
 #define SMX_A_CAS(p, e, d) smx::host_atomic_cas((p), (e), (d))
+#define SMX_A_SUB(p, v) __atomic_fetch_sub((p), (v), __ATOMIC_SEQ_CST)
+#define SMX_A_ADD64(p, v) __atomic_fetch_add((p), (unsigned long long)(v), __ATOMIC_SEQ_CST)
+#define SMX_A_MAX64(p, v) smx::host_atomic_max64((p), (v))
+namespace smx {
+inline unsigned long long host_atomic_max64(unsigned long long* p, unsigned long long v) {
+  unsigned long long o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return o;
+}
+}  // namespace smx
 #else
 #define SMX_A_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SMX_A_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -68,6 +78,9 @@ inline uint32_t host_atomic_cas(uint32_t* p, uint32_t expected, uint32_t desired
 #define SMX_A_MIN(p, v) atomicMin((p), (v))
 #define SMX_A_MAX(p, v) atomicMax((p), (v))
 #define SMX_A_CAS(p, e, d) atomicCAS((p), (e), (d))
+#define SMX_A_SUB(p, v) atomicSub((p), (v))
+#define SMX_A_ADD64(p, v) atomicAdd((p), (unsigned long long)(v))
+#define SMX_A_MAX64(p, v) atomicMax((p), (unsigned long long)(v))
 #endif
 
 namespace smx {
@@ -149,6 +162,7 @@ SMX_D size_t spec_fidx(const DevState& s, size_t c) {        // cell order -> fr
 // ---------------- read-only scout: records the predicted footprint of a particle ----------------
 struct ScoutPolicy {
   static constexpr bool READ_ONLY = true;
+  static constexpr bool DEFER_NESTED = false;
   const SpecShared& sh;
   uint32_t pid, len = 0;
   uint32_t* out;
@@ -182,6 +196,7 @@ struct ScoutPolicy {
 // ---------------- in-place speculative execution ----------------
 struct SpecPolicy {
   static constexpr bool READ_ONLY = false;
+  static constexpr bool DEFER_NESTED = false;
   static constexpr bool OUTLINE_RECURSION = true;           // soil_core.h wind_recurse
   // take over the cursors of a copy that ran a piece of this particle out of line (same particle, same log)
   SMX_D void adopt(const SpecPolicy& o) {

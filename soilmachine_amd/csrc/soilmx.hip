@@ -29,6 +29,8 @@
 #include <chrono>
 #include "soil_coop.h"
 #include "soil_noise.h"
+#include "soil_batch.h"
+#include <algorithm>
 
 using namespace smx;
 
@@ -199,6 +201,88 @@ __global__ void __launch_bounds__(64) k_spec_abandon(DevState s, SpecShared sh) 
 __global__ void __launch_bounds__(256) k_spec_end(DevState s, SpecShared sh, uint32_t whole_phase) {
   const uint32_t done = whole_phase ? sh.ctrl[SC_N] : sh.ctrl[SC_TOP];   // top-level particles executed
   spec_end_team(s, sh, done, sh.ctrl[SC_NESTED_COMMITTED], threadIdx.x, blockDim.x);
+}
+
+
+// ---------------- batched engine kernels (protocol: soil_batch.h) ----------------
+// One particle per LANE. 64-thread workgroups: a phase has 10^3..10^6 particles and the chip has 1024 SIMDs, so
+// single-wave workgroups spread the waves evenly over CUs and XCDs (workgroups go round-robin over the XCDs).
+template <bool WIND>
+__global__ void __launch_bounds__(64) k_batch_spawn(DevState s, BatchShared bs, uint32_t nslots, const BChild* kids) {
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= nslots) return;
+  BatchPolicy pol(s, bs);
+  Sim<BatchPolicy> sim(s, sh, pol);
+  if constexpr (WIND) batch_wind_spawn(sim, bs, i); else batch_water_spawn(sim, bs, i, kids ? kids + i : nullptr);
+  sim.flush_counters(); pol.finish(s);
+}
+template <bool WIND>
+__global__ void __launch_bounds__(64) k_batch_epoch(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch) {
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= nlive) return;
+  BatchPolicy pol(s, bs);
+  Sim<BatchPolicy> sim(s, sh, pol);
+  if constexpr (WIND) batch_wind_epoch(sim, bs, bs.live[i], epoch);
+  else { Frame st[MAX_FRAMES]; batch_water_epoch(sim, bs, bs.live[i], epoch, st); }
+  sim.flush_counters(); pol.finish(s);
+}
+// rebuild the list of slots that still run (order is irrelevant: a slot's identity is its index, not its lane)
+template <bool WIND>
+__global__ void __launch_bounds__(256) k_batch_compact(BatchShared bs, uint32_t nslots) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool alive = i < nslots && (WIND ? bs.wind[i].state : bs.water[i].state) != B_DONE;
+  const unsigned long long m = __ballot(alive);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == 0 && m) base = atomicAdd(&bs.ctrl[BC_NLIVE], (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, 0);
+  if (alive) bs.live[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+__global__ void __launch_bounds__(256) k_batch_iota(uint32_t* live, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) live[i] = i;
+}
+// between kernels: nodes released during the last kernel go back on the free stack
+__global__ void __launch_bounds__(256) k_batch_merge_freed(DevState s, BatchShared bs) {
+  uint32_t nf = bs.ctrl[BC_NFREED];
+  if (nf > bs.freed_cap) nf = bs.freed_cap;
+  const uint32_t base = *s.free_count;
+  for (uint32_t i = threadIdx.x; i < nf; i += 256u) s.freelist[base + i] = bs.freed[i];
+  __syncthreads();
+  if (threadIdx.x == 0) { *s.free_count = base + nf; bs.ctrl[BC_NFREED] = 0; }
+}
+template <bool WIND>
+__global__ void __launch_bounds__(256) k_batch_counters(DevState s, BatchShared bs, uint32_t nslots) {
+  unsigned long long acc[4] = {0, 0, 0, 0};
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nslots; i += gridDim.x * 256u) batch_slot_counters(bs, WIND, i, acc);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    for (int off = 32; off > 0; off >>= 1) acc[k] += (unsigned long long)__shfl_down((long long)acc[k], off);
+  if ((threadIdx.x & 63u) == 0) batch_commit_counters(s, WIND, acc);
+}
+// grid pass, one colour: tiles (cx + 3i, cy + 3j); one thread per tile
+__global__ void __launch_bounds__(64) k_batch_grid(DevState s, BatchShared bs, uint32_t col, uint32_t mx, uint32_t my) {
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  unsigned long long vis = 0;
+  if (i < mx * my) {
+    const uint32_t tx = col / 3u + 3u * (i / my), ty = col % 3u + 3u * (i % my);
+    if (tx < (uint32_t)bs.ntx && ty < (uint32_t)bs.nty) {
+      BatchPolicy pol(s, bs);
+      Sim<BatchPolicy> sim(s, sh, pol);
+      Frame st[MAX_FRAMES];
+      vis = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * bs.ntx * bs.nty + (unsigned long long)tx * bs.nty + ty, st);
+      sim.flush_counters(); pol.finish(s);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) vis += (unsigned long long)__shfl_down((long long)vis, off);
+  if (threadIdx.x == 0 && vis) atomicAdd(&s.ctr[C_GRID_ACTIVE], vis);
+}
+__global__ void k_batch_grid_finish(DevState s, unsigned long long visited0) {   // counter parity: every other cell "calls" cascade once
+  const unsigned long long n = (unsigned long long)s.dimx * s.dimy, v = s.ctr[C_GRID_ACTIVE] - visited0;
+  s.ctr[C_WCASCADE_CALLS] += n - v;
 }
 
 __global__ void __launch_bounds__(256) k_map_frequency(float* __restrict__ freq, const float* __restrict__ track, size_t n4, size_t n) {
@@ -384,6 +468,15 @@ struct smx_ctx {
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
   uint32_t* h_ctrl = nullptr;         // pinned host copy of the control block
+  // batched engine (allocated on first use)
+  BatchShared bs{};
+  uint32_t batch_cap = 0;             // slots the particle buffers are sized for
+  bool batch_wind_buf = false;
+  uint32_t* d_draws = nullptr; uint32_t* h_draws = nullptr; uint32_t draws_cap = 0;
+  BChild* d_kids = nullptr; uint32_t kids_cap = 0;
+  uint32_t* h_bctrl = nullptr;
+  int batch_dilate = 0;
+  uint64_t batch_epochs = 0, batch_generations = 0, batch_children_lost = 0;
 };
 
 #define HIPCHK(call)                                                                                  \
@@ -498,6 +591,13 @@ void smx_destroy(smx_ctx* ctx) {
     hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
     hipFree(sh.pending); hipFree(sh.draws); hipFree(sh.scout_cells); hipFree(sh.scout_len); hipFree(sh.ckpt);
   }
+  {
+    BatchShared& bs = ctx->bs;
+    hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
+    if (ctx->h_draws) hipHostFree(ctx->h_draws);
+    if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
+  }
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -515,6 +615,13 @@ int smx_set_soils(smx_ctx* ctx, const smx_soil* soils, int32_t n) {
 }
 int smx_set_scale(smx_ctx* ctx, int32_t scale) { ctx->d.scale = scale; ctx->cfg.scale = scale; return 0; }
 int smx_set_engine(smx_ctx* ctx, int32_t engine) { ctx->cfg.engine = engine; return 0; }
+int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) { ctx->batch_dilate = tiles < 0 ? 0 : tiles; return 0; }
+int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost) {
+  if (epochs) *epochs = ctx->batch_epochs;
+  if (generations) *generations = ctx->batch_generations;
+  if (children_lost) *children_lost = ctx->batch_children_lost;
+  return 0;
+}
 void* smx_stream(smx_ctx* ctx) { return (void*)ctx->stream; }
 
 int smx_srand(smx_ctx* ctx, uint32_t seed) {   // glibc srandom_r, TYPE_3 (stdlib/random_r.c)
@@ -853,9 +960,148 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
   return 0;
 }
 
+
+// ---------------- batched engine: host driver (mirrored for the CPU by tests/hostsim/hostsim.cpp batch_generations) ----------------
+static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
+  BatchShared& bs = ctx->bs;
+  if (!bs.ctrl) {
+    bs.ntx = (ctx->cfg.dimx + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT; bs.nty = (ctx->cfg.dimy + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT;
+    const size_t nt = (size_t)bs.ntx * bs.nty;
+    HIPCHK(hipMalloc(&bs.claim[0], nt * 8)); HIPCHK(hipMalloc(&bs.claim[1], nt * 8));
+    HIPCHK(hipMalloc(&bs.ctrl, BC_COUNT * 4)); HIPCHK(hipMemsetAsync(bs.ctrl, 0, BC_COUNT * 4, ctx->stream));
+    bs.child_cap = 1u << 20; HIPCHK(hipMalloc(&bs.children, (size_t)bs.child_cap * sizeof(BChild)));
+    bs.freed_cap = 1u << 22; HIPCHK(hipMalloc(&bs.freed, (size_t)bs.freed_cap * 4));
+    HIPCHK(hipHostMalloc(&ctx->h_bctrl, BC_COUNT * 4));
+  }
+  if (ctx->batch_cap < nslots) {
+    hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); bs.water = nullptr; bs.wind = nullptr; bs.live = nullptr; ctx->batch_cap = 0;
+    const uint32_t cap = nslots < 4096u ? 4096u : nslots;
+    HIPCHK(hipMalloc(&bs.water, (size_t)cap * sizeof(BWater))); HIPCHK(hipMalloc(&bs.wind, (size_t)cap * sizeof(BWind)));
+    HIPCHK(hipMalloc(&bs.live, (size_t)cap * 4));
+    ctx->batch_cap = cap;
+  }
+  if (ctx->draws_cap < 2u * nslots) {
+    hipFree(ctx->d_draws); if (ctx->h_draws) hipHostFree(ctx->h_draws); ctx->d_draws = nullptr; ctx->h_draws = nullptr; ctx->draws_cap = 0;
+    const uint32_t cap = 2u * (nslots < 4096u ? 4096u : nslots);
+    HIPCHK(hipMalloc(&ctx->d_draws, (size_t)cap * 4)); HIPCHK(hipHostMalloc(&ctx->h_draws, (size_t)cap * 4));
+    ctx->draws_cap = cap;
+  }
+  bs.draws = ctx->d_draws; bs.dilate = ctx->batch_dilate; bs.maxsteps = 1;
+  (void)wind;
+  return 0;
+}
+// generations of one phase: `kids` = children to start from (grid pass), else n top-level particles
+static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BChild> kids) {
+  hipStream_t st = ctx->stream;
+  bool first = kids.empty();
+  uint32_t nslots = first ? n : (uint32_t)kids.size();
+  if (nslots == 0) return 0;
+  RandState r;                                              // the host draws for the device: glibc rand() is a serial recurrence
+  HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  while (nslots > 0) {
+    if (batch_alloc(ctx, nslots, wind)) return -1;
+    const BatchShared& bs = ctx->bs;
+    for (uint32_t i = 0; i < 2u * nslots; i++) {
+      const uint32_t v = r.ring[r.idx % 31] + r.ring[(r.idx - 3) % 31];
+      r.ring[r.idx % 31] = v; r.idx++; r.calls++;
+      ctx->h_draws[i] = v >> 1;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
+    const size_t nt = (size_t)bs.ntx * bs.nty;
+    HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st));
+    const BChild* dk = nullptr;
+    if (!first) {
+      if (ctx->kids_cap < nslots) { hipFree(ctx->d_kids); ctx->d_kids = nullptr; ctx->kids_cap = 0; HIPCHK(hipMalloc(&ctx->d_kids, (size_t)nslots * sizeof(BChild))); ctx->kids_cap = nslots; }
+      HIPCHK(hipMemcpyAsync(ctx->d_kids, kids.data(), (size_t)nslots * sizeof(BChild), hipMemcpyHostToDevice, st));
+      dk = ctx->d_kids;
+    }
+    const unsigned nb = (nslots + 63u) / 64u;
+    if (wind) hipLaunchKernelGGL(k_batch_spawn<true>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk);
+    else hipLaunchKernelGGL(k_batch_spawn<false>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk);
+    hipLaunchKernelGGL(k_batch_iota, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs.live, nslots);
+    uint32_t nlive = nslots, epoch = 0;
+    static const int CHUNK = [] { const char* e = getenv("SMX_BATCH_CHUNK"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
+    static const bool trace = [] { const char* e = getenv("SMX_TRACE_BATCH"); return e && atoi(e) != 0; }();
+    while (nlive > 0) {
+      batch_schedule(nlive, ctx->batch_dilate, ctx->bs.dilate, ctx->bs.maxsteps);   // (bs aliases ctx->bs: passed by value per launch)
+      if (trace) fprintf(stderr, "[soilmx] batched %s gen-slots %u epoch %u live %u dilate %d maxsteps %d\n", wind ? "wind " : "water", nslots, epoch, nlive, bs.dilate, bs.maxsteps);
+      {
+        PhaseTimer tk(ctx, wind ? 5 : 4);
+        const unsigned nbl = (nlive + 63u) / 64u;
+        for (int k = 0; k < CHUNK; k++, epoch++) {
+          if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+          else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+        }
+      }
+      hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);   // frees of the chunk go back on the stack
+      HIPCHK(hipMemsetAsync(bs.ctrl + BC_NLIVE, 0, 4, st));
+      if (wind) hipLaunchKernelGGL(k_batch_compact<true>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots);
+      else hipLaunchKernelGGL(k_batch_compact<false>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots);
+      HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      nlive = ctx->h_bctrl[BC_NLIVE];
+      ctx->batch_epochs += CHUNK;
+    }
+    if (wind) hipLaunchKernelGGL(k_batch_counters<true>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
+    else hipLaunchKernelGGL(k_batch_counters<false>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
+    ctx->batch_generations++;
+    // children -> the next generation, in key order (the order decides slot numbers = priorities and rand() draws)
+    uint32_t nc = ctx->h_bctrl[BC_NCHILD];
+    if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
+    if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
+    if (nc > bs.child_cap) nc = bs.child_cap;
+    kids.resize(nc);
+    if (nc) HIPCHK(hipMemcpyAsync(kids.data(), bs.children, (size_t)nc * sizeof(BChild), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));   // NCHILD, CHILD_LOST
+    HIPCHK(hipStreamSynchronize(st));
+    std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
+    first = false;
+    nslots = wind ? 0u : nc;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int batch_grid(smx_ctx* ctx) {
+  hipStream_t st = ctx->stream;
+  if (batch_alloc(ctx, 1, false)) return -1;
+  const BatchShared& bs = ctx->bs;
+  unsigned long long v0 = 0;
+  HIPCHK(hipMemcpyAsync(&v0, ctx->d.ctr + C_GRID_ACTIVE, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, st));
+  HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, st));
+  hipLaunchKernelGGL(k_grid_classify, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, st, ctx->d);
+  HIPCHK(hipStreamSynchronize(st));
+  const uint32_t ntx = (uint32_t)bs.ntx, nty = (uint32_t)bs.nty;
+  for (uint32_t col = 0; col < 9; col++) {
+    const uint32_t cx = col / 3u, cy = col % 3u;
+    const uint32_t mx = (ntx + 2u - cx) / 3u, my = (nty + 2u - cy) / 3u;
+    if (mx * my == 0) continue;
+    hipLaunchKernelGGL(k_batch_grid, dim3((mx * my + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, col, mx, my);
+    hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
+  }
+  hipLaunchKernelGGL(k_batch_grid_finish, dim3(1), dim3(1), 0, st, ctx->d, v0);
+  HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  uint32_t nc = ctx->h_bctrl[BC_NCHILD];
+  if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
+  if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
+  if (nc > bs.child_cap) nc = bs.child_cap;
+  std::vector<BChild> kids(nc);
+  if (nc) HIPCHK(hipMemcpyAsync(kids.data(), bs.children, (size_t)nc * sizeof(BChild), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
+  if (!kids.empty()) return batch_generations(ctx, false, 0, std::move(kids));
+  return 0;
+}
+
 // ---------------- the hot path ----------------
 int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   PhaseTimer t(ctx, 0);
+  if (ctx->cfg.engine == SMX_ENGINE_BATCHED) return batch_generations(ctx, false, nwater > 0 ? (uint32_t)nwater : 0u, {});
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwater, false);
   PhaseTimer tk(ctx, 4);
   hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwater);
@@ -864,6 +1110,7 @@ int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
 }
 int smx_grid_pass(smx_ctx* ctx) {
   PhaseTimer t(ctx, 1);
+  if (ctx->cfg.engine == SMX_ENGINE_BATCHED) return batch_grid(ctx);
   HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, ctx->stream));
   const unsigned nb = (unsigned)((ctx->ncells + 255) / 256);
@@ -874,6 +1121,7 @@ int smx_grid_pass(smx_ctx* ctx) {
 }
 int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
   PhaseTimer t(ctx, 2);
+  if (ctx->cfg.engine == SMX_ENGINE_BATCHED) return batch_generations(ctx, true, nwind > 0 ? (uint32_t)nwind : 0u, {});
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwind, true);
   PhaseTimer tk(ctx, 5);
   hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwind);

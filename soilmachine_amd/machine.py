@@ -149,6 +149,14 @@ class Layermap:
         self._chk(self.L.smx_get_counters(self.h, C.byref(c)))
         return c.as_dict()
 
+    def set_batch_dilate(self, tiles: int):
+        self._chk(self.L.smx_set_batch_dilate(self.h, int(tiles)))
+
+    def batch_stats(self) -> dict:
+        e, g, l = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.smx_get_batch_stats(self.h, C.byref(e), C.byref(g), C.byref(l)))
+        return {"epochs": int(e.value), "generations": int(g.value), "children_lost": int(l.value)}
+
     def timing(self) -> dict:
         t = capi.Timing()
         self._chk(self.L.smx_get_timing(self.h, C.byref(t)))

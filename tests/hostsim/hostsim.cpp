@@ -18,6 +18,7 @@
 #include "../../soilmachine_amd/csrc/soil_spec.h"
 #include <type_traits>
 #include "../../soilmachine_amd/csrc/soil_coop.h"
+#include "../../soilmachine_amd/csrc/soil_batch.h"
 #include <pthread.h>
 #include <thread>
 #include <algorithm>
@@ -321,4 +322,137 @@ void hs_spec_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int
   if (dowind) { hs_spec_wind(c, nwind, nthreads, wscout, shuffle, st); if (stats) for (int i = 0; i < 6; i++) stats[6 + i] += st[i]; }
   if (dowater) hs_freq(c);
 }
+}  // extern "C"
+
+// ---------------- batched engine (soil_batch.h), emulated: the host driver below mirrors soilmx.hip batch_* ----------
+static int g_batch_dilate = 1;
+struct BatchBuffers {
+  std::vector<unsigned long long> claim0, claim1;
+  std::vector<BWater> water; std::vector<BWind> wind;
+  std::vector<uint32_t> live, freed, ctrl, draws;
+  std::vector<BChild> children;
+  BatchShared bs;
+};
+static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) {
+  const DevState& s = c->d;
+  b.bs.ntx = (s.dimx + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT; b.bs.nty = (s.dimy + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT;
+  const size_t nt = (size_t)b.bs.ntx * b.bs.nty;
+  b.claim0.assign(nt, 0); b.claim1.assign(nt, 0);
+  if (wind) b.wind.resize(nslots); else b.water.resize(nslots);
+  b.live.resize(nslots ? nslots : 1); b.ctrl.assign(BC_COUNT, 0); b.draws.assign(2 * (size_t)nslots + 2, 0);
+  if (b.children.size() < (1u << 16)) b.children.resize(1u << 16);
+  if (b.freed.size() < (1u << 20)) b.freed.resize(1u << 20);
+  b.bs.claim[0] = b.claim0.data(); b.bs.claim[1] = b.claim1.data();
+  b.bs.water = b.water.data(); b.bs.wind = b.wind.data(); b.bs.live = b.live.data();
+  b.bs.children = b.children.data(); b.bs.child_cap = (uint32_t)b.children.size();
+  b.bs.dilate = g_batch_dilate; b.bs.maxsteps = 1;
+  b.bs.freed = b.freed.data(); b.bs.freed_cap = (uint32_t)b.freed.size(); b.bs.ctrl = b.ctrl.data(); b.bs.draws = b.draws.data();
+}
+static void batch_draw(hs_ctx* c, BatchBuffers& b, uint32_t nslots) {   // the next 2*nslots rand() values (host-side generator)
+  RandState& r = c->rnd;
+  for (uint32_t i = 0; i < 2 * nslots; i++) {
+    const uint32_t v = r.ring[r.idx % 31] + r.ring[(r.idx - 3) % 31];
+    r.ring[r.idx % 31] = v; r.idx++; r.calls++;
+    b.draws[i] = v >> 1;
+  }
+}
+static void batch_merge_freed(hs_ctx* c, BatchBuffers& b) {
+  uint32_t nf = b.ctrl[BC_NFREED]; if (nf > b.bs.freed_cap) nf = b.bs.freed_cap;
+  for (uint32_t i = 0; i < nf; i++) c->freelist[c->free_count++] = b.freed[i];
+  b.ctrl[BC_NFREED] = 0;
+}
+static uint32_t g_batch_stats[8];
+extern "C" void hs_set_batch_dilate(int d) { g_batch_dilate = d; }
+// runs generations until no particle and no child is left; `kids` = children to start from (grid pass), else top-level
+static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n, std::vector<BChild> kids, int nthreads, unsigned shuffle) {
+  const DevState& s = c->d;
+  bool first = kids.empty();
+  uint32_t nslots = first ? n : (uint32_t)kids.size();
+  while (nslots > 0) {
+    batch_setup(c, b, nslots, wind);
+    batch_draw(c, b, nslots);
+    const BatchShared& bs = b.bs;
+    parallel_for(nslots, nthreads, [&](uint32_t i) {
+      BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+      if (wind) batch_wind_spawn(sim, bs, i); else batch_water_spawn(sim, bs, i, first ? nullptr : &kids[i]);
+      sim.flush_counters(); pol.finish(s);
+    }, shuffle ? shuffle + 7 : 0);
+    for (uint32_t i = 0; i < nslots; i++) b.live[i] = i;
+    uint32_t nlive = nslots, epoch = 0;
+    while (nlive > 0) {
+      batch_schedule(nlive, g_batch_dilate, b.bs.dilate, b.bs.maxsteps);
+      for (int k = 0; k < 16; k++, epoch++) {
+        parallel_for(nlive, nthreads, [&](uint32_t i) {
+          BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+          Frame st[MAX_FRAMES];
+          if (wind) batch_wind_epoch(sim, bs, bs.live[i], epoch); else batch_water_epoch(sim, bs, bs.live[i], epoch, st);
+          sim.flush_counters(); pol.finish(s);
+        }, shuffle ? shuffle + 11 + epoch : 0);
+      }
+      batch_merge_freed(c, b);
+      uint32_t m = 0;
+      for (uint32_t i = 0; i < nslots; i++) if ((wind ? b.wind[i].state : b.water[i].state) != B_DONE) b.live[m++] = i;
+      nlive = m;
+      g_batch_stats[0] += 16;
+    }
+    g_batch_stats[1]++;
+    { unsigned long long acc[4] = {0, 0, 0, 0}; for (uint32_t i = 0; i < nslots; i++) batch_slot_counters(bs, wind, i, acc); batch_commit_counters(s, wind, acc); }
+    // children -> next generation, in key order
+    uint32_t nc = b.ctrl[BC_NCHILD]; if (nc > b.bs.child_cap) nc = b.bs.child_cap;
+    g_batch_stats[2] += b.ctrl[BC_CHILD_LOST];
+    kids.assign(b.children.begin(), b.children.begin() + nc);
+    std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
+    b.ctrl[BC_NCHILD] = 0;
+    first = false;
+    nslots = wind ? 0 : nc;
+  }
+}
+extern "C" {
+void hs_batched_water(hs_ctx* c, int n, int nthreads, unsigned shuffle) { BatchBuffers b; batch_generations(c, b, false, (uint32_t)n, {}, nthreads, shuffle); }
+void hs_batched_wind(hs_ctx* c, int n, int nthreads, unsigned shuffle) { BatchBuffers b; batch_generations(c, b, true, (uint32_t)n, {}, nthreads, shuffle); }
+void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
+  const DevState& s = c->d;
+  const size_t n = c->n;
+  std::fill(c->a0.begin(), c->a0.end(), 0); std::fill(c->a1.begin(), c->a1.end(), 0); std::fill(c->a2.begin(), c->a2.end(), 0);
+  for (size_t cc = 0; cc < n; cc++) {                       // k_grid_classify
+    const int x = (int)(cc / s.dimy), y = (int)(cc % s.dimy);
+    bool act = (s.flags[cc] & F_SAT) != 0;
+    for (int dx = -1; dx <= 1 && !act; dx++) for (int dy = -1; dy <= 1; dy++) {
+      int nx = x + dx, ny = y + dy; if (nx < 0 || ny < 0 || nx >= s.dimx || ny >= s.dimy) continue;
+      if (s.flags[(size_t)nx * s.dimy + ny] & F_AIR) { act = true; break; }
+    }
+    if (act) c->a0[cc >> 6] |= 1ull << (cc & 63);
+  }
+  BatchBuffers b; batch_setup(c, b, 0, false);
+  const BatchShared& bs = b.bs;
+  const uint32_t ntx = (uint32_t)bs.ntx, nty = (uint32_t)bs.nty;
+  unsigned long long visited = 0;
+  for (uint32_t col = 0; col < 9; col++) {
+    const uint32_t cx = col / 3, cy = col % 3;
+    const uint32_t mx = (ntx + 2 - cx) / 3, my = (nty + 2 - cy) / 3;   // tiles tx = cx + 3*i < ntx
+    std::vector<unsigned long long> vis((size_t)mx * my, 0);
+    parallel_for(mx * my, nthreads, [&](uint32_t i) {
+      const uint32_t tx = cx + 3 * (i / my), ty = cy + 3 * (i % my);
+      if (tx >= ntx || ty >= nty) return;
+      BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+      Frame st[MAX_FRAMES];
+      vis[i] = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * ntx * nty + (unsigned long long)tx * nty + ty, st);
+      sim.flush_counters(); pol.finish(s);
+    }, shuffle ? shuffle + 3 + col : 0);
+    for (unsigned long long v : vis) visited += v;
+    batch_merge_freed(c, b);
+  }
+  c->ctr[C_WCASCADE_CALLS] += n - visited;                   // every other cell still "calls" WaterParticle::cascade once
+  c->ctr[C_GRID_ACTIVE] += visited;
+  uint32_t nc = b.ctrl[BC_NCHILD]; if (nc > b.bs.child_cap) nc = b.bs.child_cap;
+  std::vector<BChild> kids(b.children.begin(), b.children.begin() + nc);
+  std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
+  if (!kids.empty() && !getenv("DBG_GRID_NOCHILD")) { BatchBuffers b2; batch_generations(c, b2, false, 0, kids, nthreads, shuffle); }
+}
+void hs_batched_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int nthreads, unsigned shuffle) {
+  if (dowater) { hs_batched_water(c, nwater, nthreads, shuffle); hs_batched_grid(c, nthreads, shuffle); }
+  if (dowind) hs_batched_wind(c, nwind, nthreads, shuffle);
+  if (dowater) hs_freq(c);
+}
+void hs_batch_stats(uint32_t* out) { for (int i = 0; i < 8; i++) { out[i] = g_batch_stats[i]; g_batch_stats[i] = 0; } }
 }  // extern "C"

@@ -15,7 +15,7 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libhostsim.so")
 SRC = [os.path.join(HERE, "hostsim.cpp")] + [os.path.join(ROOT, "soilmachine_amd", "csrc", f)
-                                              for f in ("soil_core.h", "soil_serial.h", "soil_spec.h")]
+                                              for f in ("soil_core.h", "soil_serial.h", "soil_spec.h", "soil_coop.h", "soil_batch.h")]
 _lib = None
 
 
@@ -48,6 +48,11 @@ def lib():
         L.hs_spec_water.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint, vp]
         L.hs_spec_wind.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint, vp]
         L.hs_set_boundary_threads.argtypes = [C.c_int]
+        L.hs_batched_water.argtypes = [vp, C.c_int, C.c_int, C.c_uint]
+        L.hs_batched_wind.argtypes = [vp, C.c_int, C.c_int, C.c_uint]
+        L.hs_batched_grid.argtypes = [vp, C.c_int, C.c_uint]
+        L.hs_batched_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
+        L.hs_batch_stats.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -99,6 +104,16 @@ class HostSim:
 
     def tick(self, nwater, nwind, dowater=True, dowind=True):
         self.L.hs_tick(self.h, nwater, nwind, int(dowater), int(dowind))
+
+    def batched_tick(self, nwater, nwind, dowater=True, dowind=True, nthreads=1, shuffle=0):
+        """One tick of the BATCHED engine (soil_batch.h) emulated on the host: `nthreads` threads share every "kernel",
+        `shuffle` != 0 permutes the order in which the particles of a kernel are run (the result must not depend on it)."""
+        self.L.hs_batched_tick(self.h, nwater, nwind, int(dowater), int(dowind), nthreads, shuffle)
+
+    def batch_stats(self):
+        st = np.zeros(8, np.uint32)
+        self.L.hs_batch_stats(_p(st))
+        return {"epochs": int(st[0]), "generations": int(st[1]), "children_lost": int(st[2])}
 
     @staticmethod
     def set_boundary_threads(n: int):

@@ -78,6 +78,12 @@ def lib():
         L.so_particle_cascade.argtypes = [vp, C.c_float, C.c_float, C.c_int]
         L.so_water_cascade.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.so_seep.argtypes = [vp, C.c_int, C.c_int]
+        L.so_batched_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        for f in ("so_batched_water", "so_batched_wind"):
+            getattr(L, f).argtypes = [vp, C.c_int]
+        L.so_batched_grid.argtypes = [vp]
+        L.so_batched_set_dilate.argtypes = [vp, C.c_int]
+        L.so_batched_stats.argtypes = [vp, vp]
         L.so_noise_fbm.argtypes = [C.c_float] * 3 + [C.c_int] + [C.c_float] * 3
         L.so_noise_fbm.restype = C.c_float
         _lib = L
@@ -137,6 +143,18 @@ class Oracle:
         c = Counters()
         self.L.so_get_counters(self.h, C.byref(c))
         return c.as_dict()
+
+    # ---- the BATCHED schedule restated (checker of the batched HIP engine; see oracle/soil_oracle.h)
+    def batched_tick(self, nwater: int, nwind: int, dowater: bool = True, dowind: bool = True):
+        self.L.so_batched_tick(self.h, nwater, nwind, int(dowater), int(dowind))
+
+    def batched_set_dilate(self, tiles: int):
+        self.L.so_batched_set_dilate(self.h, int(tiles))
+
+    def batched_stats(self) -> dict:
+        a = np.zeros(3, np.uint64)
+        self.L.so_batched_stats(self.h, _p(a))
+        return {"epochs": int(a[0]), "generations": int(a[1]), "guard_violations": int(a[2])}
 
     def heights(self) -> np.ndarray:
         out = np.zeros(self.dimx * self.dimy)

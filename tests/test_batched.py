@@ -1,0 +1,144 @@
+"""The BATCHED (throughput) engine on the CPU: soil_batch.h compiled for the host (tests/hostsim, the very headers the
+HIP kernels are built from) against its independent restatement in the oracle (oracle/soil_oracle.cpp so_batched_*).
+
+What is and is not claimed (DESIGN.md "Batched engine"):
+  * deterministic: the result does not depend on thread count or on the order in which a kernel's particles run;
+  * bit-exact against the restated schedule, including lakes, floods and nested particles;
+  * every step is isolated: no cell is touched outside the tiles the acting particle holds (the oracle checks every
+    access of its step functions against the reservation);
+  * with a margin as large as the map the schedule degenerates to the reference's particle-after-particle order and
+    reproduces the REFERENCE bit for bit (phases without nested particles);
+  * against the reference in general it is parity tier P2 only (statistical) -- see test_batched_statistics.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from common import golden_snapshot, load_cfg
+from hostsim_lib import HostSim, lib
+from oracle_lib import Oracle
+from soilmachine_amd.snapshot import compare
+
+KEYS = ["steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
+        "cascade_transfers", "wcascade_calls", "rand_calls", "pool_free"]
+
+
+def set_dilate(d):
+    L = lib()
+    L.hs_set_batch_dilate.argtypes = [ctypes.c_int]
+    L.hs_set_batch_dilate(d)
+
+
+def pair(soil, case, tick0, dilate=0):
+    cfg = load_cfg(soil)
+    g = golden_snapshot(case, tick0)
+    set_dilate(dilate)
+    h = HostSim(cfg, g.dimx, g.dimy, seed=0)
+    h.load(g, advance_rand=True)
+    o = Oracle(cfg, g.dimx, g.dimy, seed=0)
+    o.load(g)
+    o.batched_set_dilate(dilate)
+    return h, o
+
+
+CASES = [
+    # soil, golden case, start tick, nwater, nwind, wind?, ticks, dilate, host threads, shuffle seed
+    ("rockgravelpebblessand.soil", "rgps64", 0, 100, 50, True, 3, 0, 1, 0),
+    ("rockgravelpebblessand.soil", "rgps64", 3, 100, 50, True, 2, 1, 4, 7),
+    ("default.soil", "default64", 20, 250, 0, False, 8, 0, 1, 0),          # standing water: floods, nested particles, wet grid pass
+    ("default.soil", "default64", 20, 250, 0, False, 4, 0, 4, 3),
+    ("default.soil", "default64s7", 40, 150, 0, False, 5, 0, 1, 5),
+    ("painted.soil", "painted64", 5, 100, 50, True, 3, 0, 3, 0),
+    ("rocksand.soil", "rocksand48x80", 5, 60, 40, True, 3, 0, 3, 11),      # non-square map, tiles cut by the border
+]
+
+
+@pytest.mark.parametrize("soil,case,t0,nw,nd,wind,ticks,dilate,threads,shuffle", CASES)
+def test_device_headers_equal_restated_schedule(soil, case, t0, nw, nd, wind, ticks, dilate, threads, shuffle):
+    h, o = pair(soil, case, t0, dilate)
+    try:
+        for t in range(ticks):
+            h.batched_tick(nw, nd, True, wind, nthreads=threads, shuffle=shuffle)
+            o.batched_tick(nw, nd, True, wind)
+            bad = compare(h.snapshot(), o.snapshot())
+            assert not bad, f"{case} tick {t}: {bad}"
+        ch, co = h.counters(), o.counters()
+        assert {k: ch[k] for k in KEYS} == {k: co[k] for k in KEYS}
+        st = o.batched_stats()
+        assert st["guard_violations"] == 0                  # isolation: nothing touched outside the held tiles
+        hs = h.batch_stats()
+        assert hs["epochs"] == st["epochs"] and hs["generations"] == st["generations"] and hs["children_lost"] == 0
+        if case == "default64":
+            assert co["floods"] > 500 and co["nested_particles"] > 1000   # the wet regime really was exercised
+    finally:
+        set_dilate(0)
+        h.batch_stats()
+
+
+def test_result_is_independent_of_threads_and_order():
+    cfg = load_cfg("default.soil")
+    g = golden_snapshot("default64", 20)
+    snaps = []
+    for threads, shuffle in [(1, 0), (1, 9), (8, 0), (5, 123)]:
+        h = HostSim(cfg, 64, 64, seed=0)
+        h.load(g, advance_rand=True)
+        for _ in range(3):
+            h.batched_tick(250, 0, True, False, nthreads=threads, shuffle=shuffle)
+        snaps.append((h.snapshot(), h.counters()))
+    for s, c in snaps[1:]:
+        assert not compare(snaps[0][0], s)
+        assert c == snaps[0][1]
+
+
+@pytest.mark.parametrize("soil,case,nw,nd", [("rockgravelpebblessand.soil", "rgps64", 100, 50), ("rocksand.soil", "rocksand48x80", 60, 40)])
+def test_fully_serialised_schedule_reproduces_the_reference(soil, case, nw, nd):
+    """Margin >= map: the lowest slot always wins everything, i.e. particles run one after the other in spawn order =
+    the reference's order. Golden snapshots of the REFERENCE must come out bit for bit (these phases have no floods)."""
+    cfg = load_cfg(soil)
+    g0 = golden_snapshot(case, 0)
+    try:
+        set_dilate(64)
+        h = HostSim(cfg, g0.dimx, g0.dimy, seed=0 if case == "rgps64" else 3)
+        h.load(g0, advance_rand=True)
+        t_end = 3 if case == "rgps64" else 5
+        for _ in range(t_end):
+            h.batched_tick(nw, nd, True, True)
+        assert h.counters()["floods"] == 0
+        bad = compare(h.snapshot(), golden_snapshot(case, t_end))
+        assert not bad, bad
+    finally:
+        set_dilate(0)
+        h.batch_stats()
+
+
+def test_batched_statistics_against_the_exact_engine():
+    """Parity tier P2: the batched schedule is NOT the reference's order. What it must keep: every
+    structural invariant of a Layermap, the amount of work (steps within a few percent), and heights that stay as
+    close to the exact run as the exact run stays to itself under a 1-ulp perturbation (the reference's own noise
+    floor: RMSE 1.0e-3 after 20 ticks at 256^2)."""
+    from test_gpu_fullsize import column_invariants
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 128
+    o = Oracle(cfg, n, n, seed=0)
+    o.initialize()
+    s0 = o.snapshot()
+    ex = Oracle(cfg, n, n, seed=0); ex.load(s0)
+    ba = Oracle(cfg, n, n, seed=0); ba.load(s0)
+    pe = Oracle(cfg, n, n, seed=0)                           # the exact engine on a map perturbed by 1e-12 (chaos floor)
+    sp = o.snapshot(); sp.size = sp.size * (1.0 + 1e-12); pe.load(sp)
+    ticks, nw, nd = 8, 200, 60
+    for _ in range(ticks):
+        ex.tick(nw, nd); ba.batched_tick(nw, nd); pe.tick(nw, nd)
+    se, sb, sq = ex.snapshot(), ba.snapshot(), pe.snapshot()
+    column_invariants(sb)
+    he, hb, hq = se.heights(), sb.heights(), sq.heights()
+    rmse_b = float(np.sqrt(np.mean((he - hb) ** 2)))
+    rmse_floor = float(np.sqrt(np.mean((he - hq) ** 2)))
+    ce, cb = ex.counters(), ba.counters()
+    assert abs(cb["steps_water_all"] - ce["steps_water_all"]) < 0.05 * ce["steps_water_all"]
+    assert abs(cb["steps_wind"] - ce["steps_wind"]) < 0.25 * ce["steps_wind"] + 500
+    assert abs(hb.mean() - he.mean()) < 2e-4 * he.mean()
+    assert abs(sb.nsec - se.nsec) < 0.05 * se.nsec
+    assert rmse_b < max(5.0 * rmse_floor, 5e-3), (rmse_b, rmse_floor)
+    assert ba.batched_stats()["guard_violations"] == 0
