@@ -660,7 +660,8 @@ struct so_ctx {
   // Acting order inside an epoch is irrelevant by construction (winners own disjoint tiles); this
   // restatement walks slots in ascending order.
   // =====================================================================================================
-  static constexpr int B_TILE = 2, B_MAXCHILD = 24;
+  static constexpr int B_GRID = 2, B_MAXCHILD = 24;   // grid pass: 4x4-cell tiles
+  int B_TILE = 2;                                   // claim granularity of the running chunk (b_schedule): tiles of 2^B_TILE cells
   struct BRect { int tx0, tx1, ty0, ty1; bool empty() const { return tx1 < tx0; } };
   struct BChild { uint64_t key; int tx, ty, bx, by, spill; double volume; };
   bool b_defer = false;
@@ -688,12 +689,17 @@ struct so_ctx {
   static bool b_inside(const BRect& a, const BRect& b) {   // b inside a
     return !a.empty() && b.tx0 >= a.tx0 && b.tx1 <= a.tx1 && b.ty0 >= a.ty0 && b.ty1 <= a.ty1;
   }
-  static void b_schedule(uint32_t nlive, int base, int& dilate, int& maxsteps) {
-    int d = 0, k = 1;
-    if (nlive <= 32768u) { d = 1; k = 4; }
-    if (nlive <= 4096u) { d = 2; k = 8; }
-    if (nlive <= 512u) { d = 4; k = 16; }
-    dilate = base > d ? base : d; maxsteps = k;
+  uint32_t b_cell_above = 0xFFFFFFFFu;            // water reserves single cells while more particles than this run (tests lower it)
+  void b_schedule(bool wind, uint32_t nlive, int base, int& tshift, int& dilate, int& maxsteps) const {
+    if (wind) {
+      tshift = 2; dilate = 1; maxsteps = 8;
+      if (nlive <= 4096u) { tshift = 3; dilate = 1; maxsteps = 32; }
+    } else {
+      tshift = 1; dilate = 0; maxsteps = 1;
+      if (nlive > b_cell_above) tshift = 0;
+      if (nlive <= 2048u) { tshift = 1; dilate = 1; maxsteps = 4; }
+    }
+    if (base > dilate) dilate = base;
   }
   // the footprint of the next action, in tiles (soil_batch.h *_intent)
   BRect b_water_need_run(const Water& p) {
@@ -748,12 +754,13 @@ struct so_ctx {
   void b_generations(bool wind, uint32_t n, std::vector<BChild> kids) {
     bool first = kids.empty();
     uint32_t nslots = first ? n : (uint32_t)kids.size();
-    std::vector<uint32_t> tilemin((size_t)b_ntx() * b_nty(), 0xFFFFFFFFu);
+    std::vector<uint32_t> tilemin;
     while (nslots > 0) {
       std::vector<BSlot> sl(nslots);
       std::vector<int> draws(2 * (size_t)nslots);
       for (auto& v : draws) v = rand_();                    // the generation's draws, in slot order: 2i -> y, 2i+1 -> x
       int dilate = b_base_dilate, maxsteps = 1;
+      (void)dilate;
       for (uint32_t i = 0; i < nslots; i++) {               // spawn on the map as it is now; first reservations
         BSlot& q = sl[i];
         const int ry = draws[2 * i] % dimy, rx = draws[2 * i + 1] % dimx;
@@ -763,7 +770,7 @@ struct so_ctx {
           p.pos = {(float)rx, (float)ry};
           p.ix = (int)std::round(p.pos.x); p.iy = (int)std::round(p.pos.y);
           p.surface = surface(p.ix, p.iy); p.param = soils[p.surface]; p.contains = p.param.transports;
-          q.rect = b_dilate(b_wind_need_run(p), dilate);
+          q.rect = {0, -1, 0, -1};
         } else {
           Water& p = q.w;
           p.pos = {(float)rx, (float)ry};
@@ -778,14 +785,26 @@ struct so_ctx {
             p.pos = {(float)c.tx, (float)c.ty};
             p.spill = c.spill; p.volume = c.volume;
           }
-          q.rect = b_dilate(b_water_need_run(p), dilate);
+          q.rect = {0, -1, 0, -1};
         }
       }
       std::vector<char> win(nslots);
       uint32_t nlive = nslots, epoch = 0;
       b_children.clear();
+      int grain = -1;
       while (nlive > 0) {
-        b_schedule(nlive, b_base_dilate, dilate, maxsteps);
+        int tshift;
+        b_schedule(wind, nlive, b_base_dilate, tshift, dilate, maxsteps);
+        if (tshift != grain) {                                // first chunk / new claim granularity: every running particle
+          grain = tshift; B_TILE = tshift;                    // re-issues its reservation from its current state
+          tilemin.assign((size_t)b_ntx() * b_nty(), 0xFFFFFFFFu);
+          for (BSlot& q : sl) {
+            if (q.state == B_DONE) continue;
+            if (wind) q.rect = b_dilate(b_wind_need_run(q.d), dilate);
+            else if (q.state == B_ENDED) { if (!b_water_floods(q.w)) { q.state = B_DONE; q.rect = {0, -1, 0, -1}; } else q.rect = b_water_need_flood(q.w); }
+            else q.rect = b_dilate(b_water_need_run(q.w), dilate);
+          }
+        }
         for (int k = 0; k < 16; k++, epoch++) {
           b_winners(sl, tilemin, win);
           for (uint32_t i = 0; i < nslots; i++) {
@@ -798,7 +817,7 @@ struct so_ctx {
               if (wind) need = b_wind_need_run(q.d);
               else if (q.state == B_RUN || q.state == B_NEW) need = b_water_need_run(q.w);
               else { if (!b_water_floods(q.w)) { q.state = B_DONE; break; } need = b_water_need_flood(q.w); }
-              if (acted >= maxsteps || !b_inside(held, need)) { q.rect = b_dilate(need, dilate); break; }
+              if (acted >= maxsteps || !b_inside(held, need)) { q.rect = (!wind && q.state == B_ENDED) ? need : b_dilate(need, dilate); break; }   // no margin for a flood
               acted++;
               b_guard = &held; b_ctx = wind ? "wind" : (q.state != B_ENDED ? "water-step" : "flood");
               if (q.state == B_NEW) {                         // the particle's constructor reads its spawn cell NOW (water.h:15-17, wind.h:19-21)
@@ -859,7 +878,8 @@ struct so_ctx {
           }
         act[cidx(x, y)] = a ? 1 : 0;
       }
-    const int ntx = b_ntx(), nty = b_nty();
+    const int ntx = (dimx + (1 << B_GRID) - 1) >> B_GRID, nty = (dimy + (1 << B_GRID) - 1) >> B_GRID;
+    B_TILE = B_GRID;                                          // (the access guard below speaks in grid tiles)
     uint64_t visited = 0;
     b_children.clear();
     for (int col = 0; col < 9; col++)
@@ -868,8 +888,8 @@ struct so_ctx {
           b_defer = true; b_parent = (uint64_t)col * ntx * nty + (uint64_t)tx * nty + ty; b_seq = 0;
           const BRect g = {tx - 1 < 0 ? 0 : tx - 1, tx + 1 > ntx - 1 ? ntx - 1 : tx + 1, ty - 1 < 0 ? 0 : ty - 1, ty + 1 > nty - 1 ? nty - 1 : ty + 1};
           b_guard = &g; b_ctx = "grid";
-          for (int x = tx << B_TILE; x < ((tx + 1) << B_TILE) && x < dimx; x++)
-            for (int y = ty << B_TILE; y < ((ty + 1) << B_TILE) && y < dimy; y++) {
+          for (int x = tx << B_GRID; x < ((tx + 1) << B_GRID) && x < dimx; x++)
+            for (int y = ty << B_GRID; y < ((ty + 1) << B_GRID) && y < dimy; y++) {
               if (!act[cidx(x, y)]) continue;
               seep(x, y);
               water_cascade(x, y, 3);
@@ -1046,6 +1066,7 @@ void so_batched_tick(so_ctx* c, int nwater, int nwind, int dowater, int dowind) 
   if (dowater) { c->map_frequency(); c->reset_frequency(); }
 }
 void so_batched_set_dilate(so_ctx* c, int tiles) { c->b_base_dilate = tiles < 0 ? 0 : tiles; }
+void so_batched_set_cell_above(so_ctx* c, uint32_t n) { c->b_cell_above = n; }
 void so_batched_stats(so_ctx* c, uint64_t* out3) { out3[0] = c->b_epochs; out3[1] = c->b_ngen; out3[2] = c->b_guard_violations; }
 void so_dep_enable(so_ctx* c, int on) {
   c->dep_on = on != 0;

@@ -29,7 +29,7 @@
 
 namespace smx {
 
-constexpr int TILE_SHIFT = 2;                 // 4x4 cells per claim tile
+constexpr int GRID_SHIFT = 2;                 // the grid pass works on 4x4-cell tiles (one cascade reaches 4 cells)
 constexpr uint32_t B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3;   // B_NEW: top-level particle that has not acted yet
 constexpr int B_MAXCHILD = 24;                // nested particles one flood / one grid tile may emit per pass
 
@@ -48,8 +48,8 @@ struct BChild {                               // a nested WaterParticle waiting 
 enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_COUNT = 16 };
 
 struct BatchShared {
-  unsigned long long* claim[2];               // [ntx * nty] each
-  int ntx, nty;
+  unsigned long long* claim[2];               // sized for one word per CELL; indexed [tx * nty + ty] at the current granularity
+  int tshift, ntx, nty;                       // claim granularity: tiles of 2^tshift x 2^tshift cells (0 = single cells)
   BWater* water; BWind* wind;                 // slots of the current generation
   uint32_t* live;                             // indices of the slots that are not DONE (rebuilt by batch_compact)
   BChild* children; uint32_t child_cap;
@@ -66,10 +66,10 @@ SMX_D bool brect_contains(const BRect& a, const BRect& b) {   // b inside a
   return !brect_empty(a) && b.tx0 >= a.tx0 && b.tx1 <= a.tx1 && b.ty0 >= a.ty0 && b.ty1 <= a.ty1;
 }
 // tiles of the cell rectangle [x0,x1] x [y0,y1], clipped to the map
-SMX_D BRect brect_cells(const DevState& s, int x0, int x1, int y0, int y1) {
+SMX_D BRect brect_cells(const DevState& s, const BatchShared& bs, int x0, int x1, int y0, int y1) {
   x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
   x1 = x1 > s.dimx - 1 ? s.dimx - 1 : x1; y1 = y1 > s.dimy - 1 ? s.dimy - 1 : y1;
-  BRect r; r.tx0 = x0 >> TILE_SHIFT; r.tx1 = x1 >> TILE_SHIFT; r.ty0 = y0 >> TILE_SHIFT; r.ty1 = y1 >> TILE_SHIFT;
+  BRect r; r.tx0 = x0 >> bs.tshift; r.tx1 = x1 >> bs.tshift; r.ty0 = y0 >> bs.tshift; r.ty1 = y1 >> bs.tshift;
   return r;
 }
 // A reservation covers the tiles the action can touch PLUS a margin of `dilate` tiles: two particles act in the same
@@ -154,36 +154,38 @@ struct BatchPolicy {
 // Particle::cascade(.., 0) in the 3x3 around npos = round(new pos)  ->  bbox(3x3(ipos) u 3x3(npos)).
 // A move() that returns false (stall, out of bounds) has still READ the plus-stencil of ipos to decide that (and
 // writes ipos's track word): the 3x3 around ipos stays reserved, or the decision itself would race with a neighbour.
+// `t` / `mv`: the particle after that move and whether move() returned true -- the epoch loop commits exactly this
+// look-ahead instead of computing the move a second time.
 template <class P>
-SMX_D BRect water_intent_run(Sim<P>& sim, const Water& w, const Blk& blk) {
-  Water t = w;
-  const bool mv = sim.template water_move<true>(t, false, blk);
-  if (!mv) return brect_cells(sim.s, w.ix - 1, w.ix + 1, w.iy - 1, w.iy + 1);
+SMX_D BRect water_intent_run(Sim<P>& sim, const BatchShared& bs, const Water& w, const Blk& blk, Water& t, bool& mv) {
+  t = w;
+  mv = sim.template water_move<true>(t, false, blk);
+  if (!mv) return brect_cells(sim.s, bs, w.ix - 1, w.ix + 1, w.iy - 1, w.iy + 1);
   const int nx = (int)roundf(t.pos.x), ny = (int)roundf(t.pos.y);
   const int x0 = (w.ix < nx ? w.ix : nx) - 1, x1 = (w.ix > nx ? w.ix : nx) + 1;
   const int y0 = (w.iy < ny ? w.iy : ny) - 1, y1 = (w.iy > ny ? w.iy : ny) + 1;
-  return brect_cells(sim.s, x0, x1, y0, y1);
+  return brect_cells(sim.s, bs, x0, x1, y0, y1);
 }
 // Water, move/interact loop over: flood() (water.h:123-145) or nothing. The flood acts around trunc(pos): sediment +
 // water added there, Particle::cascade in the 3x3 around round(pos), seep, and WaterParticle::cascade whose recursion
 // (one level per unit of spill, water.h:278-279) reaches `spill` cells + 1 ... = radius max(spill, 2) in all.
 SMX_D bool water_floods(const Water& w) { return !(w.volume < 0.01 || w.spill <= 0); }   // the gate of water.h:125
-SMX_D BRect water_intent_flood(const DevState& s, const Water& w) {
+SMX_D BRect water_intent_flood(const DevState& s, const BatchShared& bs, const Water& w) {
   const int R = w.spill > 2 ? w.spill : 2;
   const int fx = (int)w.pos.x, fy = (int)w.pos.y;
-  return brect_cells(s, fx - R, fx + R, fy - R, fy + R);
+  return brect_cells(s, bs, fx - R, fx + R, fy - R, fy + R);
 }
 // Wind, running: move() at ipos (plus-stencil, frequency word) + interact(): remove at ipos / add at npos and ipos,
 // Particle::cascade(.., 1) around both with one level of recursion  ->  bbox(5x5(ipos) u 5x5(npos)).
 template <class P>
-SMX_D BRect wind_intent_run(Sim<P>& sim, const Wind& d, const Blk& blk) {
-  Wind t = d;
-  const bool mv = sim.template wind_move<true>(t, blk);
-  if (!mv) return brect_cells(sim.s, d.ix - 1, d.ix + 1, d.iy - 1, d.iy + 1);
+SMX_D BRect wind_intent_run(Sim<P>& sim, const BatchShared& bs, const Wind& d, const Blk& blk, Wind& t, bool& mv) {
+  t = d;
+  mv = sim.template wind_move<true>(t, blk);
+  if (!mv) return brect_cells(sim.s, bs, d.ix - 1, d.ix + 1, d.iy - 1, d.iy + 1);
   const int nx = (int)roundf(t.pos.x), ny = (int)roundf(t.pos.y);
   const int x0 = (d.ix < nx ? d.ix : nx) - 2, x1 = (d.ix > nx ? d.ix : nx) + 2;
   const int y0 = (d.iy < ny ? d.iy : ny) - 2, y1 = (d.iy > ny ? d.iy : ny) + 2;
-  return brect_cells(sim.s, x0, x1, y0, y1);
+  return brect_cells(sim.s, bs, x0, x1, y0, y1);
 }
 
 // ---------------- generation start: construct the particles, publish their first reservations (plane 0, epoch 0) -------
@@ -206,15 +208,12 @@ SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
     w.volume = child->volume;
   }
   w.ix = (int)roundf(w.pos.x); w.iy = (int)roundf(w.pos.y);
-  Blk A;
-  sim.template load_block<0>(w.ix, w.iy, A);
   // A top-level particle reads what it `contains` from its spawn cell (water.h:15-17) when it first ACTS, not now: the
   // reference constructs a particle right before it runs, so it sees what earlier particles did to that cell. (A nested
   // particle takes it from a random cell somewhere on the map, water.h:251 -- that read happens here, where nothing writes.)
   q.w = w; q.state = child ? B_RUN : B_NEW;
   q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad = 0;
-  q.rect = bdilate(bs, water_intent_run(sim, w, A));
-  bclaim(bs, 0, q.rect, btag(0u, slot));
+  q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_water_reclaim
 }
 template <class P>
 SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
@@ -224,11 +223,39 @@ SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
   Wind d;
   sim.wind_init(d, rx, ry);
   q.d = d; q.pad = 0; q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad2 = 0;
-  Blk A;
-  sim.template load_block<1>(d.ix, d.iy, A);
   q.state = B_NEW;                                           // `contains` (wind.h:19-21) is read when the particle first acts
-  q.rect = bdilate(bs, wind_intent_run(sim, d, A));
-  bclaim(bs, 0, q.rect, btag(0u, slot));
+  q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_wind_reclaim
+}
+
+// (Re)issue the reservation of a running particle for epoch `epoch` from its CURRENT state: at the start of a
+// generation, and whenever the schedule changes the claim granularity (the planes are cleared then). Runs in a kernel
+// of its own: nothing is written to the map meanwhile, so the look-ahead may read freely.
+template <class P>
+SMX_D void batch_water_reclaim(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
+  BWater& q = bs.water[slot];
+  if (q.state == B_DONE) return;
+  BRect r;
+  if (q.state == B_ENDED) {
+    if (!water_floods(q.w)) { q.state = B_DONE; q.rect = BRect{0, -1, 0, -1}; return; }
+    r = water_intent_flood(sim.s, bs, q.w);
+  } else {
+    Blk A;
+    sim.template load_block<0>(q.w.ix, q.w.iy, A);
+    Water t; bool mv;
+    r = bdilate(bs, water_intent_run(sim, bs, q.w, A, t, mv));
+  }
+  q.rect = r;
+  bclaim(bs, (int)(epoch & 1u), r, btag(epoch, slot));
+}
+template <class P>
+SMX_D void batch_wind_reclaim(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
+  BWind& q = bs.wind[slot];
+  if (q.state == B_DONE) return;
+  Blk A;
+  sim.template load_block<1>(q.d.ix, q.d.iy, A);
+  Wind t; bool mv;
+  q.rect = bdilate(bs, wind_intent_run(sim, bs, q.d, A, t, mv));
+  bclaim(bs, (int)(epoch & 1u), q.rect, btag(epoch, slot));
 }
 
 // ---------------- one epoch of one particle ----------------
@@ -252,23 +279,26 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
     int acted = 0;
     while (true) {
       BRect need;
+      Water t; bool mv = false;
       if (state == B_RUN || state == B_NEW) {
         if (!haveA) sim.template load_block<0>(w.ix, w.iy, A);
-        need = water_intent_run(sim, w, A);
+        need = water_intent_run(sim, bs, w, A, t, mv);
       } else {                                               // B_ENDED: flood() or nothing (water.h:125)
         if (!water_floods(w)) { state = B_DONE; break; }
-        need = water_intent_flood(s, w);
+        need = water_intent_flood(s, bs, w);
       }
-      if (acted >= bs.maxsteps || !brect_contains(held, need)) { rect = bdilate(bs, need); break; }   // reserve it for the next epoch
+      // reserve it for the next epoch. The margin is for particles that TRAVEL (it buys them several steps per epoch);
+      // a flood is a particle's last action, and floods crowd together on lake shores: no margin there.
+      if (acted >= bs.maxsteps || !brect_contains(held, need)) { rect = (state == B_ENDED) ? need : bdilate(bs, need); break; }
       acted++;
       if (state == B_NEW) {                                  // WaterParticle(map) water.h:15-17, on the map as it is NOW
-        w.surface = Sim<P>::vsurf(A.v8);
-        w.friction = sim.soils[w.surface].friction;
-        w.contains = sim.soils[w.surface].transports;
+        t.contains = sim.soils[Sim<P>::vsurf(A.v8)].transports;   // (move() does not look at `contains`: the look-ahead stands)
         state = B_RUN;
       }
       if (state == B_RUN) {
-        if (sim.water_move(w, q.toplevel != 0u, A)) {        // water.h:43-73 (writes the track word)
+        sim.water_move_commit(w, mv, q.toplevel != 0u, A);   // water.h:43-73: the look-ahead becomes the move (track word, counters)
+        w = t;
+        if (mv) {
           const int r = sim.water_interact(w, A, B);         // water.h:75-121
           if (r == 0) state = B_ENDED;
           else { A = B; haveA = true; }                      // B = the exact block around the new ipos
@@ -307,16 +337,18 @@ SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
     int acted = 0;
     while (true) {
       if (!haveA) sim.template load_block<1>(d.ix, d.iy, A);
-      const BRect need = wind_intent_run(sim, d, A);
+      Wind t; bool mv;
+      const BRect need = wind_intent_run(sim, bs, d, A, t, mv);
       if (acted >= bs.maxsteps || !brect_contains(held, need)) { rect = bdilate(bs, need); break; }
       acted++;
       if (state == B_NEW) {                                  // WindParticle(map) wind.h:19-21 + the gate of wind.h:56-57
-        d.surface = Sim<P>::vsurf(A.v8);
-        d.contains = sim.soils[d.surface].transports;
+        t.contains = sim.soils[Sim<P>::vsurf(A.v8)].transports;   // (move() does not look at `contains`)
         state = B_RUN;
-        if (sim.soils[d.contains].suspension == 0.0) { state = B_DONE; break; }
+        if (sim.soils[t.contains].suspension == 0.0) { d.contains = t.contains; state = B_DONE; break; }
       }
-      if (sim.wind_move(d, A)) {                             // wind.h:54-92 (writes the frequency word)
+      sim.wind_move_commit(mv, A);                           // wind.h:54-92: the look-ahead becomes the move (frequency word, counter)
+      d = t;
+      if (mv) {
         sim.wind_interact(d, A, B);                          // wind.h:94-136 (always true); B = exact block around the new ipos
         A = B; haveA = true;
       } else { state = B_DONE; break; }
@@ -331,22 +363,37 @@ SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
   if (state != B_DONE) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
 }
 
-// The schedule of a generation (part of the engine's definition: the CPU restatement follows the same rule): margin
-// and steps per epoch as a function of how many particles are still running when a chunk of epochs starts.
-// Many particles: tight reservations, every step its own epoch (conflicts are what limits progress). Few particles:
-// wide margins, many steps per kernel (kernel launches are what limits progress).
+// The schedule of a generation (part of the engine's definition: the CPU restatement follows the same rule): claim
+// granularity, margin and actions per epoch as a function of how many particles are still running when a chunk of
+// epochs starts. Measured on the MI355X (profiles/r02_batched_schedules.md):
+//   water  what limits a phase is particles EXCLUDING each other -- they drain into the same pits and queue there, one
+//          step per epoch and neighbourhood -- so reservations stay tight (2x2-cell tiles, no margin, one action per
+//          epoch); only the last few thousand get a small margin and up to 4 actions per epoch.
+//   wind   particles travel far (up to ~13 000 steps, 2-3 cells each) and rarely meet: wide tiles with a margin buy a
+//          lone particle up to 32 steps per kernel launch.
+// `fine_above`: water reserves single cells while more particles than this are running (default: never; the tests lower it).
+struct BSched { int tshift, dilate, maxsteps; };
 #ifdef SMX_HOSTSIM
-inline
+#define SMX_HD inline
 #else
-__host__ __device__ inline
+#define SMX_HD __host__ __device__ inline
 #endif
-void batch_schedule(uint32_t nlive, int base_dilate, int& dilate, int& maxsteps) {
-  int d = 0, k = 1;
-  if (nlive <= 32768u) { d = 1; k = 4; }
-  if (nlive <= 4096u) { d = 2; k = 8; }
-  if (nlive <= 512u) { d = 4; k = 16; }
-  dilate = base_dilate > d ? base_dilate : d;
-  maxsteps = k;
+SMX_HD BSched batch_schedule(bool wind, uint32_t nlive, int base_dilate, uint32_t fine_above = 0xFFFFFFFFu) {
+  BSched k;
+  if (wind) {
+    k.tshift = 2; k.dilate = 1; k.maxsteps = 8;
+    if (nlive <= 4096u) { k.tshift = 3; k.dilate = 1; k.maxsteps = 32; }
+  } else {
+    k.tshift = 1; k.dilate = 0; k.maxsteps = 1;
+    if (nlive > fine_above) k.tshift = 0;
+    if (nlive <= 2048u) { k.tshift = 1; k.dilate = 1; k.maxsteps = 4; }
+  }
+  if (base_dilate > k.dilate) k.dilate = base_dilate;
+  return k;
+}
+SMX_HD void batch_apply_schedule(BatchShared& bs, const DevState& s, const BSched& k) {
+  bs.tshift = k.tshift; bs.dilate = k.dilate; bs.maxsteps = k.maxsteps;
+  bs.ntx = (s.dimx + (1 << k.tshift) - 1) >> k.tshift; bs.nty = (s.dimy + (1 << k.tshift) - 1) >> k.tshift;
 }
 
 // ---------------- grid pass: one colour, one tile ----------------
@@ -360,9 +407,9 @@ SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned l
   dummy.pos = {0.f, 0.f}; dummy.speed = {0.f, 0.f}; dummy.volume = 0.0; dummy.sediment = 0.0; dummy.evaprate = 0.0;
   dummy.spill = 0; dummy.ix = dummy.iy = 0; dummy.friction = 0.f; dummy.surface = dummy.contains = 0;
   unsigned long long visited = 0;
-  const int x0 = tx << TILE_SHIFT, y0 = ty << TILE_SHIFT;
-  for (int x = x0; x < x0 + (1 << TILE_SHIFT) && x < s.dimx; x++)
-    for (int y = y0; y < y0 + (1 << TILE_SHIFT) && y < s.dimy; y++) {
+  const int x0 = tx << GRID_SHIFT, y0 = ty << GRID_SHIFT;
+  for (int x = x0; x < x0 + (1 << GRID_SHIFT) && x < s.dimx; x++)
+    for (int y = y0; y < y0 + (1 << GRID_SHIFT) && y < s.dimy; y++) {
       const size_t c = (size_t)x * s.dimy + y;
       if (!((s.active[c >> 6] >> (c & 63)) & 1ull)) continue;
       int depth = 0;

@@ -887,6 +887,20 @@ struct Sim {
     }
     return true;
   }
+  // the side effects of a move() whose arithmetic was already done by water_move<true> on a copy (batched engine):
+  // updatefrequency (water.h:53, :348-351; `before` = the particle as it entered move()) and the step counters
+  SMX_D void water_move_commit(const Water& before, bool moved, bool toplevel, const Blk& cur) {
+    s.wtrack[fidx(before.ix, before.iy)] = (float)((double)cur.tr + before.volume);
+    if (moved) { n_steps_w_all++; if (toplevel) n_steps_w_top++; }
+  }
+  SMX_D void wind_move_commit(bool moved, const Blk& cur) {   // wind.h:49-52 on the block's centre
+    s.windfreq[cur_fidx(cur)] = (float)(0.5 * cur.tr + 0.5f);
+    if (moved) n_steps_wind++;
+  }
+  SMX_D size_t cur_fidx(const Blk& b) const {                // frequency-order index of a block's centre cell
+    const size_t x = b.c0 / (size_t)s.dimy, y = b.c0 - x * (size_t)s.dimy;
+    return y * (size_t)s.dimx + x;
+  }
   // WaterParticle::interact (water.h:75-121): `cur` is the block around ipos, `nb` receives the block around the
   // new position. 1 = interact() returned true, 0 = false, -1 = the new block could not be acquired (speculative
   // engine): nothing of interact() has happened yet, so the particle can be resumed exactly here.

@@ -218,6 +218,15 @@ __global__ void __launch_bounds__(64) k_batch_spawn(DevState s, BatchShared bs, 
   sim.flush_counters(); pol.finish(s);
 }
 template <bool WIND>
+__global__ void __launch_bounds__(64) k_batch_reclaim(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch) {
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= nlive) return;
+  BatchPolicy pol(s, bs);
+  Sim<BatchPolicy> sim(s, sh, pol);
+  if constexpr (WIND) batch_wind_reclaim(sim, bs, bs.live[i], epoch); else batch_water_reclaim(sim, bs, bs.live[i], epoch);
+}
+template <bool WIND>
 __global__ void __launch_bounds__(64) k_batch_epoch(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch) {
   SMX_LOAD_SOILS(sh)
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
@@ -268,12 +277,13 @@ __global__ void __launch_bounds__(64) k_batch_grid(DevState s, BatchShared bs, u
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   unsigned long long vis = 0;
   if (i < mx * my) {
+    const uint32_t gtx = (uint32_t)((s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), gty = (uint32_t)((s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
     const uint32_t tx = col / 3u + 3u * (i / my), ty = col % 3u + 3u * (i % my);
-    if (tx < (uint32_t)bs.ntx && ty < (uint32_t)bs.nty) {
+    if (tx < gtx && ty < gty) {
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
       Frame st[MAX_FRAMES];
-      vis = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * bs.ntx * bs.nty + (unsigned long long)tx * bs.nty + ty, st);
+      vis = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * gtx * gty + (unsigned long long)tx * gty + ty, st);
       sim.flush_counters(); pol.finish(s);
     }
   }
@@ -965,8 +975,8 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
 static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
   BatchShared& bs = ctx->bs;
   if (!bs.ctrl) {
-    bs.ntx = (ctx->cfg.dimx + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT; bs.nty = (ctx->cfg.dimy + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT;
-    const size_t nt = (size_t)bs.ntx * bs.nty;
+    bs.tshift = -1; bs.ntx = ctx->cfg.dimx; bs.nty = ctx->cfg.dimy;
+    const size_t nt = ctx->ncells;                          // one claim word per cell: enough for every granularity
     HIPCHK(hipMalloc(&bs.claim[0], nt * 8)); HIPCHK(hipMalloc(&bs.claim[1], nt * 8));
     HIPCHK(hipMalloc(&bs.ctrl, BC_COUNT * 4)); HIPCHK(hipMemsetAsync(bs.ctrl, 0, BC_COUNT * 4, ctx->stream));
     bs.child_cap = 1u << 20; HIPCHK(hipMalloc(&bs.children, (size_t)bs.child_cap * sizeof(BChild)));
@@ -1008,8 +1018,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
       ctx->h_draws[i] = v >> 1;
     }
     HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
-    const size_t nt = (size_t)bs.ntx * bs.nty;
-    HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st));
+    ctx->bs.tshift = -1;                                      // (the first chunk clears the planes and issues the first reservations)
     const BChild* dk = nullptr;
     if (!first) {
       if (ctx->kids_cap < nslots) { hipFree(ctx->d_kids); ctx->d_kids = nullptr; ctx->kids_cap = 0; HIPCHK(hipMalloc(&ctx->d_kids, (size_t)nslots * sizeof(BChild))); ctx->kids_cap = nslots; }
@@ -1024,8 +1033,30 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     static const int CHUNK = [] { const char* e = getenv("SMX_BATCH_CHUNK"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
     static const bool trace = [] { const char* e = getenv("SMX_TRACE_BATCH"); return e && atoi(e) != 0; }();
     while (nlive > 0) {
-      batch_schedule(nlive, ctx->batch_dilate, ctx->bs.dilate, ctx->bs.maxsteps);   // (bs aliases ctx->bs: passed by value per launch)
-      if (trace) fprintf(stderr, "[soilmx] batched %s gen-slots %u epoch %u live %u dilate %d maxsteps %d\n", wind ? "wind " : "water", nslots, epoch, nlive, bs.dilate, bs.maxsteps);
+      BSched sc = batch_schedule(wind, nlive, ctx->batch_dilate);
+      {   // experiments only: SMX_BATCH_SCHED="tshift,dilate,maxsteps" (water) / SMX_BATCH_SCHED_WIND pins the schedule
+        static const char* ew = getenv("SMX_BATCH_SCHED"); static const char* ed = getenv("SMX_BATCH_SCHED_WIND");
+        const char* e = wind ? ed : ew; int a, d, k;
+        if (e && sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; }
+        static const char* et = getenv("SMX_BATCH_SCHED_TAIL");   // "thr:tshift,dilate,maxsteps[;thr2:...]" (ascending thr): first thr >= nlive wins
+        if (!wind && et) {
+          const char* q = et; unsigned thr;
+          while (q && sscanf(q, "%u:%d,%d,%d", &thr, &a, &d, &k) == 4) {
+            if (nlive <= thr) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; break; }
+            q = strchr(q, ';'); if (q) q++;
+          }
+        }
+      }
+      const bool regrain = sc.tshift != bs.tshift;             // first chunk, or the claim granularity changes
+      batch_apply_schedule(ctx->bs, ctx->d, sc);               // (bs aliases ctx->bs: passed by value per launch)
+      if (regrain) {
+        const size_t nt = (size_t)bs.ntx * bs.nty;
+        HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st));
+        if (wind) hipLaunchKernelGGL(k_batch_reclaim<true>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+        else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+      }
+      const auto t_chunk = std::chrono::steady_clock::now();
+      const uint32_t live_in = nlive;
       {
         PhaseTimer tk(ctx, wind ? 5 : 4);
         const unsigned nbl = (nlive + 63u) / 64u;
@@ -1042,6 +1073,8 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
       HIPCHK(hipStreamSynchronize(st));
       nlive = ctx->h_bctrl[BC_NLIVE];
       ctx->batch_epochs += CHUNK;
+      if (trace) fprintf(stderr, "[soilmx] batched %s gen-slots %u epochs %u..%u live %u -> %u grain %d dilate %d maxsteps %d  %.3f ms\n", wind ? "wind " : "water", nslots,
+                         epoch - CHUNK, epoch, live_in, nlive, 1 << bs.tshift, bs.dilate, bs.maxsteps, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count());
     }
     if (wind) hipLaunchKernelGGL(k_batch_counters<true>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
     else hipLaunchKernelGGL(k_batch_counters<false>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
@@ -1074,7 +1107,7 @@ static int batch_grid(smx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, st));
   hipLaunchKernelGGL(k_grid_classify, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, st, ctx->d);
   HIPCHK(hipStreamSynchronize(st));
-  const uint32_t ntx = (uint32_t)bs.ntx, nty = (uint32_t)bs.nty;
+  const uint32_t ntx = (uint32_t)((ctx->cfg.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), nty = (uint32_t)((ctx->cfg.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
   for (uint32_t col = 0; col < 9; col++) {
     const uint32_t cx = col / 3u, cy = col % 3u;
     const uint32_t mx = (ntx + 2u - cx) / 3u, my = (nty + 2u - cy) / 3u;

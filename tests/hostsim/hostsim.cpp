@@ -325,7 +325,8 @@ void hs_spec_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int
 }  // extern "C"
 
 // ---------------- batched engine (soil_batch.h), emulated: the host driver below mirrors soilmx.hip batch_* ----------
-static int g_batch_dilate = 1;
+static int g_batch_dilate = 0;
+static uint32_t g_batch_cell_above = 0xFFFFFFFFu;
 struct BatchBuffers {
   std::vector<unsigned long long> claim0, claim1;
   std::vector<BWater> water; std::vector<BWind> wind;
@@ -335,8 +336,8 @@ struct BatchBuffers {
 };
 static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) {
   const DevState& s = c->d;
-  b.bs.ntx = (s.dimx + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT; b.bs.nty = (s.dimy + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT;
-  const size_t nt = (size_t)b.bs.ntx * b.bs.nty;
+  b.bs.tshift = -1; b.bs.ntx = s.dimx; b.bs.nty = s.dimy;
+  const size_t nt = (size_t)s.dimx * s.dimy;                // one claim word per cell: enough for every granularity
   b.claim0.assign(nt, 0); b.claim1.assign(nt, 0);
   if (wind) b.wind.resize(nslots); else b.water.resize(nslots);
   b.live.resize(nslots ? nslots : 1); b.ctrl.assign(BC_COUNT, 0); b.draws.assign(2 * (size_t)nslots + 2, 0);
@@ -363,6 +364,7 @@ static void batch_merge_freed(hs_ctx* c, BatchBuffers& b) {
 }
 static uint32_t g_batch_stats[8];
 extern "C" void hs_set_batch_dilate(int d) { g_batch_dilate = d; }
+extern "C" void hs_set_batch_cell_above(uint32_t n) { g_batch_cell_above = n; }
 // runs generations until no particle and no child is left; `kids` = children to start from (grid pass), else top-level
 static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n, std::vector<BChild> kids, int nthreads, unsigned shuffle) {
   const DevState& s = c->d;
@@ -380,7 +382,17 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
     for (uint32_t i = 0; i < nslots; i++) b.live[i] = i;
     uint32_t nlive = nslots, epoch = 0;
     while (nlive > 0) {
-      batch_schedule(nlive, g_batch_dilate, b.bs.dilate, b.bs.maxsteps);
+      BSched sc = batch_schedule(wind, nlive, g_batch_dilate, g_batch_cell_above);
+      if (const char* e = getenv("HS_SCHED")) { int a, d, k; if (sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; } }   // exploration only
+      const bool regrain = sc.tshift != b.bs.tshift;         // first chunk, or the claim granularity changes
+      batch_apply_schedule(b.bs, s, sc);
+      if (regrain) {
+        std::fill(b.claim0.begin(), b.claim0.end(), 0ull); std::fill(b.claim1.begin(), b.claim1.end(), 0ull);
+        parallel_for(nlive, nthreads, [&](uint32_t i) {
+          BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+          if (wind) batch_wind_reclaim(sim, bs, bs.live[i], epoch); else batch_water_reclaim(sim, bs, bs.live[i], epoch);
+        }, shuffle ? shuffle + 5 : 0);
+      }
       for (int k = 0; k < 16; k++, epoch++) {
         parallel_for(nlive, nthreads, [&](uint32_t i) {
           BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
@@ -396,6 +408,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       g_batch_stats[0] += 16;
     }
     g_batch_stats[1]++;
+    if (getenv("HS_TRACE_BATCH")) fprintf(stderr, "[hostsim] batched %s generation: %u slots, %u epochs\n", wind ? "wind" : "water", nslots, epoch);
     { unsigned long long acc[4] = {0, 0, 0, 0}; for (uint32_t i = 0; i < nslots; i++) batch_slot_counters(bs, wind, i, acc); batch_commit_counters(s, wind, acc); }
     // children -> next generation, in key order
     uint32_t nc = b.ctrl[BC_NCHILD]; if (nc > b.bs.child_cap) nc = b.bs.child_cap;
@@ -425,7 +438,7 @@ void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
   }
   BatchBuffers b; batch_setup(c, b, 0, false);
   const BatchShared& bs = b.bs;
-  const uint32_t ntx = (uint32_t)bs.ntx, nty = (uint32_t)bs.nty;
+  const uint32_t ntx = (uint32_t)((s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), nty = (uint32_t)((s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
   unsigned long long visited = 0;
   for (uint32_t col = 0; col < 9; col++) {
     const uint32_t cx = col / 3, cy = col % 3;

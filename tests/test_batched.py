@@ -30,6 +30,16 @@ def set_dilate(d):
     L.hs_set_batch_dilate(d)
 
 
+def set_fine_above(n, oracle=None):
+    """schedule knob: water reserves single cells while more than n particles run (default: never)"""
+    L = lib()
+    L.hs_set_batch_cell_above.argtypes = [ctypes.c_uint32]
+    L.hs_set_batch_cell_above(n)
+    if oracle is not None:
+        oracle.L.so_batched_set_cell_above.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        oracle.L.so_batched_set_cell_above(oracle.h, n)
+
+
 def pair(soil, case, tick0, dilate=0):
     cfg = load_cfg(soil)
     g = golden_snapshot(case, tick0)
@@ -73,6 +83,29 @@ def test_device_headers_equal_restated_schedule(soil, case, t0, nw, nd, wind, ti
             assert co["floods"] > 500 and co["nested_particles"] > 1000   # the wet regime really was exercised
     finally:
         set_dilate(0)
+        h.batch_stats()
+
+
+@pytest.mark.parametrize("soil,case,t0,nw,nd,wind,fine", [
+    ("default.soil", "default64", 20, 250, 0, False, 100),                 # per-cell reservations, then the switch to tiles
+    ("rockgravelpebblessand.soil", "rgps64", 0, 300, 4300, True, 120),     # > 4096 wind particles: the wind schedule regrains too
+])
+def test_schedule_changes_granularity_mid_generation(soil, case, t0, nw, nd, wind, fine):
+    """While many particles run the schedule may reserve single cells / smaller tiles; when their number drops it
+    switches granularity: planes are cleared and every running particle re-issues its reservation."""
+    h, o = pair(soil, case, t0)
+    try:
+        set_fine_above(fine, o)
+        for t in range(2):
+            h.batched_tick(nw, nd, True, wind, nthreads=2, shuffle=4)
+            o.batched_tick(nw, nd, True, wind)
+            bad = compare(h.snapshot(), o.snapshot())
+            assert not bad, f"{case} tick {t}: {bad}"
+        assert o.batched_stats()["guard_violations"] == 0
+        ch, co = h.counters(), o.counters()
+        assert {k: ch[k] for k in KEYS} == {k: co[k] for k in KEYS}
+    finally:
+        set_fine_above(0xFFFFFFFF)
         h.batch_stats()
 
 
