@@ -2,17 +2,28 @@
 """bench.py -- particle-steps/s and ms/tick of the SoilMachine particle-transport hot path on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-  * a "step" is one tick of SoilMachine.cpp:283-329 (water particles -> grid pass -> wind particles ->
+  * a "step" of the bench = one tick of SoilMachine.cpp:283-329 (water particles -> grid pass -> wind particles ->
     frequency update) over the synthetic 4096^2 layermap of BASELINE.json configs[3]
-    (soil/rockgravelpebblessand.soil: 4 soils, 2 noise layers, NWATER 1000, NWIND 250, SCALE 120, SEED 0);
-    terrain comes from Layermap::initialize on the device, state is resident in HBM before the timed region.
-  * value = particle-steps/s, whole job: a particle-step is one WaterParticle/WindParticle move()==true followed
-    by its interact() (top-level AND nested particles), summed over all ranks / max-over-ranks wall time.
-  * N > 1: the exact engine executes the reference's sequential semantics, which do not shard (DESIGN.md
-    "Multi-GPU"): --gpus N runs N independent replicas (rank r uses SEED r), no data-path collective, weak scaling.
-  * "roofline": algorithmic bytes of the dominant kernel / its HIP-event duration vs the 8 TB/s HBM peak.
+    (soil/rockgravelpebblessand.soil: 4 soils, 2 noise layers, SCALE 120, SEED 0); terrain comes from
+    Layermap::initialize on the device, state is resident in HBM before the timed region.
+  * value = particle-steps/s, whole job: a particle-step is one WaterParticle/WindParticle move()==true followed by its
+    interact(), top-level AND nested particles. The unmodified reference can only count top-level steps,
+    so the CPU baseline is top-level steps/s and the GPU line carries `value_top_level` next to `value` for that ratio.
+  * headline line: the BATCHED (throughput) engine with AREA-SCALED particle counts (NWATER = 250*(N/256)^2
+    = 64 000, NWIND = 16 000 at 4096^2). The batched engine is deterministic and bit-exact against its own CPU
+    restatement, but it is NOT the reference's particle order: parity tier P2 (statistical), never claimed bit-exact.
+    The EXACT engine (bit-identical to the reference, the parity anchor) is reported in the same JSON under "lines",
+    at the soil file's own counts (NWATER 1000 / NWIND 250: the round-1 headline) -- together with the batched engine at
+    those counts and the 1024^2 default.soil lines of BASELINE configs[1] and [2].
+  * every line carries the state digest after its timed region (section count, type hash, sum of heights, rand() draws).
+  * "roofline": algorithmic bytes of the dominant kernel / its HIP-event duration (events on the library's own stream,
+    bracketing nothing but launches of that kernel) vs the 8 TB/s HBM peak; "phases" gives the same for the O(cells)
+    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r02_pmc.json), labelled as such.
   * "cpu_baseline": the reference's own CPU loop (oracle/_ref/soil_ref_lean = the unmodified reference headers,
-    render-only Layermap::update elided) timed on this box's host, 1 core, on a bounded sample of the same workload.
+    render-only Layermap::update elided) timed on this box's host: 1 core on a bounded sample of the headline
+    workload, and an all-cores line (independent processes, different SEEDs -- the reference has no threads).
+  * N > 1: one process per GPU. The exact semantics do not shard; the batched engine shards the map into column strips
+    (soilmachine_amd/strips.py) -- until that path is selected the ranks run independent replicas (SEED = rank).
 """
 from __future__ import annotations
 
@@ -27,51 +38,136 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SOIL = "rockgravelpebblessand.soil"
-B_WATER_STEP = 192      # algorithmic bytes per water step   (SURVEY.md §8d)
+B_WATER_STEP = 192      # algorithmic bytes per water step   (SURVEY.md 8d)
 B_WIND_STEP = 256       # algorithmic bytes per wind step
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 
 
-def cpu_baseline(size: int, nwater: int, nwind: int, seed: int, ticks: int, pool: int) -> dict | None:
-    """Time the reference's own CPU path (bounded sample) on this host. Test/bench infrastructure only."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean")
-    kind = "reference"
-    if not os.path.exists(exe):
-        return None
-    cmd = [exe, "--soil", os.path.join(ROOT, "soilmachine_amd", "soils", SOIL), "--seed", str(seed), "--size", str(size),
-           "--ticks", str(ticks), "--nwater", str(nwater), "--nwind", str(nwind), "--pool", str(pool)]
-    if hasattr(os, "sched_setaffinity"):
-        pass
-    t0 = time.time()
-    out = subprocess.run(["taskset", "-c", "0"] + cmd, capture_output=True, text=True)
-    if out.returncode != 0:
-        out = subprocess.run(cmd, capture_output=True, text=True)
-    wall = time.time() - t0
-    j = None
-    for line in out.stdout.splitlines():
-        if line.startswith("JSON "):
-            j = json.loads(line[5:])
-    if j is None:
-        return None
-    t_tick = j["t_water"] + j["t_grid"] + j["t_wind"] + j["t_freq"]
-    steps_top = j["steps_water_top"] + j["steps_wind"]
-    model = ""
+def host_cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
+                return line.split(":", 1)[1].strip()
     except OSError:
         pass
-    return {
-        "value": steps_top / t_tick if t_tick > 0 else None, "unit": "particle-steps/s", "cores": 1, "kind": kind,
-        "sample": f"{ticks} tick(s) of the same workload ({size}x{size}, {SOIL}, nwater={nwater}, nwind={nwind}, SEED {seed}) "
-                  f"with oracle/_ref/soil_ref_lean, 1 thread; steps = top-level move()==true (nested ones are not countable "
-                  f"in the unmodified reference)",
+    return ""
+
+
+def run_ref_lean(soil: str, size: int, nwater: int, nwind: int, seed: int, ticks: int, pool: int, core: int | None):
+    exe = os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean")
+    cmd = [exe, "--soil", os.path.join(ROOT, "soilmachine_amd", "soils", soil), "--seed", str(seed), "--size", str(size),
+           "--ticks", str(ticks), "--nwater", str(nwater), "--nwind", str(nwind), "--pool", str(pool)]
+    if core is not None:
+        cmd = ["taskset", "-c", str(core)] + cmd
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+
+def parse_ref(out: str):
+    for line in out.splitlines():
+        if line.startswith("JSON "):
+            return json.loads(line[5:])
+    return None
+
+
+def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool: int, all_cores: bool) -> dict | None:
+    """Time the reference's own CPU path on this host (bounded sample). Test/bench infrastructure only.
+    The unmodified reference can only count TOP-LEVEL steps (nested particles run inside WaterParticle::cascade):
+    cpu value = top-level steps/s, to be compared with the GPU line's `value_top_level` (same definition)."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean")):
+        return None
+    t0 = time.time()
+    p = run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, 0)
+    j = parse_ref(p.communicate()[0])
+    if j is None:
+        p = run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, None)
+        j = parse_ref(p.communicate()[0])
+    if j is None:
+        return None
+    wall = time.time() - t0
+    t_tick = j["t_water"] + j["t_grid"] + j["t_wind"] + j["t_freq"]
+    steps = j["steps_water_top"] + j["steps_wind"]
+    out = {
+        "value": steps / t_tick if t_tick > 0 else None, "unit": "particle-steps/s", "cores": 1, "kind": "reference",
+        "sample": f"{ticks} tick(s) of {size}x{size}, {soil}, nwater={nwater}, nwind={nwind}, SEED 0 with oracle/_ref/soil_ref_lean "
+                  f"(the reference's own headers, render-only Layermap::update elided), 1 thread pinned; steps = TOP-LEVEL "
+                  f"move()==true (nested particles are not countable in the unmodified reference): compare with the GPU "
+                  f"line's value_top_level; whole tick in the denominator",
         "ms_per_tick": 1e3 * t_tick / ticks, "ms_water": 1e3 * j["t_water"] / ticks, "ms_grid": 1e3 * j["t_grid"] / ticks,
         "ms_wind": 1e3 * j["t_wind"] / ticks, "ms_freq": 1e3 * j["t_freq"] / ticks,
-        "particle_phase_steps_per_s": steps_top / max(j["t_water"] + j["t_wind"], 1e-9),
-        "host_cpu": model, "host_cores_total": os.cpu_count(), "wall_s": wall, "init_s": j["t_init"],
+        "particle_phase_steps_per_s": steps / max(j["t_water"] + j["t_wind"], 1e-9),
+        "steps_per_tick": steps / ticks, "host_cpu": host_cpu_model(), "host_cores_total": os.cpu_count(), "wall_s": wall,
+        "init_s": j["t_init"],
+    }
+    if all_cores:
+        # the reference is single-threaded: "all cores" = independent processes with different SEEDs (SURVEY.md 8d),
+        # as many as fit the box's memory (each holds its own 4096^2 layermap + POOLSIZE)
+        ncpu = os.cpu_count() or 1
+        try:
+            mem_gb = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2**30
+        except (ValueError, OSError):
+            mem_gb = 64.0
+        per_proc_gb = (pool * 56 + size * size * 24) / 2**30 + 0.5
+        nproc = int(max(1, min(ncpu, 32, (0.5 * mem_gb) // per_proc_gb)))
+        t1 = time.time()
+        procs = [run_ref_lean(soil, size, nwater, nwind, s, ticks, pool, s % ncpu) for s in range(nproc)]
+        js = [parse_ref(q.communicate()[0]) for q in procs]
+        js = [x for x in js if x is not None]
+        if js:
+            agg = sum((x["steps_water_top"] + x["steps_wind"]) /
+                      max(x["t_water"] + x["t_grid"] + x["t_wind"] + x["t_freq"], 1e-9) for x in js)
+            out["all_cores"] = {"value": agg, "unit": "particle-steps/s (sum over independent processes)", "cores": len(js),
+                                "note": f"{len(js)} independent soil_ref_lean processes (SEED 0..{len(js) - 1}), one pinned core each, "
+                                        f"same bounded sample; the reference has no threads", "wall_s": time.time() - t1}
+    return out
+
+
+def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None):
+    """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers)."""
+    from soilmachine_amd.machine import SoilMachine
+    sm = SoilMachine(cfg, n, seed=seed, nwater=nwater, nwind=nwind, dowind=dowind, pool=pool, device=device, engine=engine)
+    m = sm.map
+    sm.tick(warmup, sync=True)
+    c0 = m.counters()
+    b0 = m.batch_stats()
+    m.timing_reset()
+    if barrier:
+        barrier(m)
+    t0 = time.perf_counter()
+    sm.tick(steps)
+    if barrier:
+        barrier(m)
+    else:
+        m.sync()
+    dt = time.perf_counter() - t0
+    c1, tm, b1 = m.counters(), m.timing(), m.batch_stats()
+    steps_w = c1["steps_water_all"] - c0["steps_water_all"]
+    steps_d = c1["steps_wind"] - c0["steps_wind"]
+    r = {
+        "dt": dt, "steps_w": steps_w, "steps_d": steps_d, "tm": tm, "digest": m.digest(),
+        "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"],
+        "nested": c1["nested_particles"] - c0["nested_particles"], "floods": c1["floods"] - c0["floods"],
+        "pool_overflow": c1["pool_overflow"],
+        "engine_stats": dict({k: c1[k] - c0[k] for k in ("spec_rounds", "spec_aborts", "spec_fallbacks", "spec_executed")},
+                             **{k: b1[k] - b0[k] for k in b1}),
+    }
+    sm.map.close()
+    return r
+
+
+def line_of(r, name, workload, engine_name, steps):
+    dt, tm = r["dt"], r["tm"]
+    tot = r["steps_w"] + r["steps_d"]
+    return {
+        "name": name, "workload": workload, "engine": engine_name, "value": tot / dt, "unit": "particle-steps/s",
+        "value_top_level": (r["steps_w_top"] + r["steps_d"]) / dt,
+        "ms_per_tick": 1e3 * dt / steps,
+        "phase_ms_per_tick": {"water": tm["ms_water"] / steps, "grid": tm["ms_grid"] / steps, "wind": tm["ms_wind"] / steps,
+                              "freq": tm["ms_freq"] / steps},
+        "steps_per_tick": {"water": r["steps_w"] / steps, "wind": r["steps_d"] / steps, "nested_particles": r["nested"] / steps,
+                           "floods": r["floods"] / steps},
+        "engine_stats": r["engine_stats"], "digest": r["digest"], "pool_overflow": r["pool_overflow"],
+        "parity": "bit-exact vs the reference (tests/golden)" if engine_name != "batched" else
+                  "P2: deterministic, bit-exact vs its CPU restatement, statistical vs the reference",
     }
 
 
@@ -81,10 +177,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--soil", type=str, default=SOIL)
     ap.add_argument("--nwater", type=int, default=None)
     ap.add_argument("--nwind", type=int, default=None)
-    ap.add_argument("--engine", type=str, default="auto")
+    ap.add_argument("--engine", type=str, default="batched", choices=["auto", "serial", "spec", "batched"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lines", action="store_true", help="only the headline measurement")
     ap.add_argument("--cpu-ticks", type=int, default=1)
     args = ap.parse_args()
 
@@ -94,86 +192,117 @@ def main():
     dist = distrib.init(world, local_rank, use_cuda=torch.cuda.is_available())
 
     from soilmachine_amd import capi
-    from soilmachine_amd.machine import SoilMachine
     from soilmachine_amd.soilfile import loadsoil
 
-    cfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", SOIL))
-    nwater = cfg.NWATER if args.nwater is None else args.nwater
-    nwind = cfg.NWIND if args.nwind is None else args.nwind
+    soil = args.soil
+    cfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", soil))
     n = args.size
-    engine = {"auto": capi.ENGINE_SPECULATIVE, "serial": capi.ENGINE_SERIAL, "spec": capi.ENGINE_SPECULATIVE,
-              "batched": capi.ENGINE_BATCHED}[args.engine]
-    pool = 3 * n * n
+    eng_name = "spec" if args.engine == "auto" else args.engine
+    engine = {"serial": capi.ENGINE_SERIAL, "spec": capi.ENGINE_SPECULATIVE, "batched": capi.ENGINE_BATCHED}[eng_name]
+    area = (n / 256.0) ** 2
+    if eng_name == "batched":       # throughput configuration: area-scaled counts, same ratio as the .soil file
+        nwater = int(250 * area) if args.nwater is None else args.nwater
+        nwind = int(250 * area * cfg.NWIND / max(cfg.NWATER, 1)) if args.nwind is None else args.nwind
+    else:
+        nwater = cfg.NWATER if args.nwater is None else args.nwater
+        nwind = cfg.NWIND if args.nwind is None else args.nwind
+    pool = max(10_000_000, 3 * n * n)
     seed = distrib.replica_seed(rank)   # replicas: independent worlds, SEED = rank (rank 0 == BASELINE's SEED 0)
-    sm = SoilMachine(cfg, n, seed=seed, nwater=nwater, nwind=nwind, pool=pool, device=local_rank, engine=engine)
-    m = sm.map
 
-    def barrier():
+    def barrier(m):
         m.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    sm.tick(args.warmup, sync=True)
-    c0 = m.counters()
-    m.timing_reset()
-    barrier()
-    t0 = time.perf_counter()
-    sm.tick(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = m.counters()
-    tm = m.timing()
-
-    steps_w = c1["steps_water_all"] - c0["steps_water_all"]
-    steps_d = c1["steps_wind"] - c0["steps_wind"]
-    steps = steps_w + steps_d
+    r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier)
+    steps = r["steps_w"] + r["steps_d"]
     dev = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
-    tmax, total_steps = distrib.aggregate(dist, dt, steps, dev)
+    tmax, total_steps = distrib.aggregate(dist, r["dt"], steps, dev)
 
     if rank == 0:
-        # dominant kernel = the particle kernel with the largest summed HIP-event time (every launch is bracketed
-        # by its own event pair on the context's stream inside libsoilmx)
-        spec = engine == capi.ENGINE_SPECULATIVE
-        kspec = "k_spec_exec" if os.environ.get("SMX_COOP", "1") == "0" else "k_spec_exec_coop"   # soilmx.hip spec_phase
-        kernels = {"water": (tm["ms_kernel_water"], tm["launches_kernel_water"], steps_w * B_WATER_STEP,
-                             f"{kspec}<water>" if spec else "k_water_serial"),
-                   "wind": (tm["ms_kernel_wind"], tm["launches_kernel_wind"], steps_d * B_WIND_STEP,
-                            f"{kspec}<wind>" if spec else "k_wind_serial")}
+        tm = r["tm"]
+        kname = {"serial": ("k_water_serial", "k_wind_serial"), "spec": ("k_spec_exec_coop<water>", "k_spec_exec_coop<wind>"),
+                 "batched": ("k_batch_epoch<water>", "k_batch_epoch<wind>")}[eng_name]
+        kernels = {"water": (tm["ms_kernel_water"], tm["launches_kernel_water"], r["steps_w"] * B_WATER_STEP, kname[0]),
+                   "wind": (tm["ms_kernel_wind"], tm["launches_kernel_wind"], r["steps_d"] * B_WIND_STEP, kname[1])}
         dom = max(kernels, key=lambda k: kernels[k][0])
-        ms, launches, nbytes, kname = kernels[dom]
-        ach = (nbytes / max(launches, 1)) / (ms / max(launches, 1) * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = None                                        # HBM bytes per launch from the PMC passes (profiles/r01_pmc.json)
+        ms, launches, nbytes, kn = kernels[dom]
+        ach = (nbytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if pmc.get("workload_size") == n and kname in pmc.get("kernels", {}):
-                traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
-        except (OSError, ValueError):
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+            k = pmc.get("kernels", {}).get(kn)
+            if k and pmc.get("workload") == f"{n}/{nwater}/{nwind}/{eng_name}":
+                traffic = k["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r02_pmc.json (separate rocprofv3 --pmc passes of this command, not measured in this run)"
+        except (OSError, ValueError, KeyError):
             pass
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "avg_launch_ms": ms / max(launches, 1), "launches": launches,
-                    "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
-                    "note": "exact engine: the particle kernels are instruction-issue / dependent-latency bound, "
-                            "not bandwidth bound (DESIGN.md); the O(cells) kernels are the HBM-streaming ones"}
+        ncells = n * n
+        phases = {}
+        def stream(ms_k, launches_k, bytes_per_launch, what):
+            if launches_k and ms_k > 0:
+                g = bytes_per_launch * launches_k / (ms_k * 1e-3) / 1e9
+                return {"kernel": what, "achieved": g, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "avg_launch_us": 1e3 * ms_k / launches_k,
+                        "algorithmic_bytes_per_launch": bytes_per_launch}
+            return None
+        phases["grid_classify"] = stream(tm["ms_kernel_classify"], tm["launches_kernel_classify"], ncells * 1.125, "k_grid_classify8 (1 flag byte/cell in, 1 bit/cell out)")
+        phases["map_frequency"] = stream(tm["ms_kernel_mapfreq"], tm["launches_kernel_mapfreq"], ncells * 12.0, "k_map_frequency (freq r/w + track r, 12 B/cell)")
+        phases["particles_water"] = {"kernel": kname[0], "achieved": kernels["water"][2] / max(kernels["water"][0] * 1e-3, 1e-12) / 1e9, "unit": "GB/s",
+                                     "frac": kernels["water"][2] / max(kernels["water"][0] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                                     "launches": kernels["water"][1], "algorithmic_bytes_per_step": B_WATER_STEP}
+        phases["particles_wind"] = {"kernel": kname[1], "achieved": kernels["wind"][2] / max(kernels["wind"][0] * 1e-3, 1e-12) / 1e9, "unit": "GB/s",
+                                    "frac": kernels["wind"][2] / max(kernels["wind"][0] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                                    "launches": kernels["wind"][1], "algorithmic_bytes_per_step": B_WIND_STEP}
+        roofline = {"bound": "hbm", "kernel": kn, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                    "algorithmic_bytes_per_launch": nbytes / max(launches, 1), "phases": phases,
+                    "note": "particle kernels: a step is a ~1000-instruction dependent chain around 9 scattered 32-byte records; what bounds a "
+                            "phase is particles excluding each other where they drain together (pits, lake shores) and the longest single "
+                            "particle, not bandwidth (DESIGN.md). The O(cells) kernels are the HBM-streaming ones (phases)."}
+
+        workload = (f"{n}x{n} layermap, soil/{soil}, SEED 0, nwater={nwater}, nwind={nwind} per tick"
+                    f"{' (area-scaled, SURVEY 8d)' if eng_name == 'batched' and args.nwater is None else ''}, "
+                    f"tick = water + grid pass + wind + frequency")
+        head = line_of(r, "headline", workload, eng_name, args.steps)
+        lines = []
+        if not args.no_lines and world == 1:
+            k3, w3 = max(2, min(args.steps, 5)), max(1, min(args.warmup, 2))
+            extra = []
+            if eng_name == "batched":
+                extra.append(("exact_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, "spec", pool, k3, w3,
+                              f"{n}x{n}, soil/{soil}, the file's own NWATER={cfg.NWATER} / NWIND={cfg.NWIND} (round-1 headline workload)"))
+                extra.append(("batched_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, "batched", pool, k3, w3,
+                              f"{n}x{n}, soil/{soil}, NWATER={cfg.NWATER} / NWIND={cfg.NWIND}"))
+            dcfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", "default.soil"))
+            for nm, wind in (("configs1_1024_default_hydraulic", 0), ("configs2_1024_default_coupled", 250)):
+                for e in ("spec", "batched"):
+                    extra.append((f"{nm}_{'exact' if e == 'spec' else e}", dcfg, "default.soil", 1024, 250, wind, e, 10_000_000, k3, w3,
+                                  f"1024x1024, soil/default.soil, NWATER=250, NWIND={wind} (BASELINE {nm.split('_')[0]})"))
+            for (nm, c_, s_, n_, nw_, nd_, e_, pool_, k_, w_, wl_) in extra:
+                eng_ = {"spec": capi.ENGINE_SPECULATIVE, "batched": capi.ENGINE_BATCHED}[e_]
+                rr = measure(c_, s_, n_, 0, nw_, nd_, nd_ > 0, eng_, pool_, local_rank, k_, w_)
+                ln = line_of(rr, nm, wl_, "exact (speculative)" if e_ == "spec" else "batched", k_)
+                ln["steps"], ln["warmup"] = k_, w_
+                lines.append(ln)
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(n, nwater, nwind, 0, args.cpu_ticks, pool)
+            # bounded sample: an eighth of the headline's particle counts for one tick (CPU steps/s does not depend on the count)
+            cw, cd = (max(nwater // 8, 1000), max(nwind // 8, 250 if nwind else 0)) if nwater > 8000 else (nwater, nwind)
+            cpu = cpu_baseline(soil, n, cw, cd, args.cpu_ticks, pool, all_cores=True)
         out = {
             "metric": "particle-steps/s", "value": total_steps / tmax, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n}x{n} layermap, soil/{SOIL}, SEED 0, nwater={nwater}, nwind={nwind} per tick, "
-                                   f"exact (reference-order) engine, tick = water + grid pass + wind + frequency",
-                       "engine": args.engine, "parallelism": "replicas" if world > 1 else "single"},
-            "ms_per_tick": 1e3 * tmax / args.steps,
-            "phase_ms_per_tick": {"water": tm["ms_water"] / args.steps, "grid": tm["ms_grid"] / args.steps,
-                                  "wind": tm["ms_wind"] / args.steps, "freq": tm["ms_freq"] / args.steps},
-            "steps_per_tick": {"water": steps_w / args.steps, "wind": steps_d / args.steps,
-                               "nested_particles": (c1["nested_particles"] - c0["nested_particles"]) / args.steps},
-            "engine_stats": dict({k: c1[k] - c0[k] for k in ("spec_rounds", "spec_aborts", "spec_fallbacks", "spec_executed")}, **m.batch_stats()),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": workload, "engine": eng_name, "parallelism": "replicas" if world > 1 else "single",
+                       "parity": head["parity"]},
+            "value_top_level": head["value_top_level"] if world == 1 else None,
+            "steps_definition": "value: move()==true + interact(), top-level AND nested particles; value_top_level: top-level only "
+                                "(what cpu_baseline can count)",
+            "ms_per_tick": 1e3 * tmax / args.steps, "phase_ms_per_tick": head["phase_ms_per_tick"],
+            "steps_per_tick": head["steps_per_tick"], "engine_stats": head["engine_stats"], "digest": head["digest"],
+            "roofline": roofline, "cpu_baseline": cpu, "lines": lines,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -78,6 +78,10 @@ typedef struct smx_timing {
    * engine), each launch bracketed by its own pair of HIP events */
   double ms_kernel_water, ms_kernel_wind;
   uint64_t launches_kernel_water, launches_kernel_wind;
+  /* the O(cells) streaming kernels on their own: grid-pass classification (k_grid_classify), the batched engine's nine
+   * colour passes (k_batch_grid), water.h:358-365 (k_map_frequency) */
+  double ms_kernel_classify, ms_kernel_gridtiles, ms_kernel_mapfreq;
+  uint64_t launches_kernel_classify, launches_kernel_gridtiles, launches_kernel_mapfreq;
 } smx_timing;
 
 /* ---- life cycle: replaces Layermap::Layermap + secpool::reserve (layermap.h:64-119,218-226) ---- */

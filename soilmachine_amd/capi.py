@@ -39,7 +39,10 @@ class Timing(C.Structure):
     _fields_ = [("ms_water", C.c_double), ("ms_grid", C.c_double), ("ms_wind", C.c_double), ("ms_freq", C.c_double),
                 ("launches_water", C.c_uint64), ("launches_grid", C.c_uint64), ("launches_wind", C.c_uint64),
                 ("launches_freq", C.c_uint64), ("ms_kernel_water", C.c_double), ("ms_kernel_wind", C.c_double),
-                ("launches_kernel_water", C.c_uint64), ("launches_kernel_wind", C.c_uint64)]
+                ("launches_kernel_water", C.c_uint64), ("launches_kernel_wind", C.c_uint64),
+                ("ms_kernel_classify", C.c_double), ("ms_kernel_gridtiles", C.c_double), ("ms_kernel_mapfreq", C.c_double),
+                ("launches_kernel_classify", C.c_uint64), ("launches_kernel_gridtiles", C.c_uint64),
+                ("launches_kernel_mapfreq", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -109,6 +109,48 @@ __global__ void __launch_bounds__(256) k_grid_classify(DevState s) {
   }
 }
 
+// The same, eight cells per thread (dimy a multiple of 8: a thread's cells lie in one map row x): three aligned 8-byte
+// loads of flag bytes (rows x-1, x, x+1) + the two flanking bytes of each row instead of nine byte loads per cell; a
+// wave writes eight complete 64-bit words of the bitmap. 1 B/cell read, 1 bit/cell written: an HBM-streaming kernel.
+__global__ void __launch_bounds__(256) k_grid_classify8(DevState s) {
+  __shared__ unsigned long long sm[32];                      // 256 threads x 8 bits
+  const size_t n = (size_t)s.dimx * s.dimy;
+  const size_t c = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  uint32_t act = 0;
+  if (c < n) {
+    const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
+    const bool xm = x > 0, xp = x < s.dimx - 1, ym = y > 0, yp = y + 8 < s.dimy;
+    const unsigned long long zero = 0ull;
+    const unsigned long long r0 = *reinterpret_cast<const unsigned long long*>(s.flags + c);
+    const unsigned long long rm = xm ? *reinterpret_cast<const unsigned long long*>(s.flags + c - s.dimy) : zero;
+    const unsigned long long rp = xp ? *reinterpret_cast<const unsigned long long*>(s.flags + c + s.dimy) : zero;
+    uint32_t lo = 0, hi = 0;                                 // flag bytes left of cell 0 / right of cell 7, the three rows or-ed
+    if (ym) { lo |= s.flags[c - 1]; if (xm) lo |= s.flags[c - s.dimy - 1]; if (xp) lo |= s.flags[c + s.dimy - 1]; }
+    if (yp) { hi |= s.flags[c + 8]; if (xm) hi |= s.flags[c - s.dimy + 8]; if (xp) hi |= s.flags[c + s.dimy + 8]; }
+    const unsigned long long col = r0 | rm | rp;             // per cell: own column of three rows
+    // F_AIR anywhere in the 3x3: the cell's own column or-ed with its left and right neighbours'
+    const unsigned long long airc = col & 0x0101010101010101ull * F_AIR;
+    const unsigned long long left = (airc << 8) | (unsigned long long)(lo & F_AIR);
+    const unsigned long long right = (airc >> 8) | ((unsigned long long)(hi & F_AIR) << 56);
+    const unsigned long long any = airc | left | right | ((r0 & (0x0101010101010101ull * F_SAT)) >> 1);   // F_SAT = 2 -> bit 0
+#pragma unroll
+    for (int k = 0; k < 8; k++) act |= (uint32_t)((any >> (8 * k)) & 1ull) << k;
+  }
+  reinterpret_cast<uint8_t*>(sm)[threadIdx.x] = (uint8_t)act;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const size_t w0 = (size_t)blockIdx.x * 32 + threadIdx.x;   // 2048 cells per block = 32 bitmap words
+    if (w0 * 64 < n) {
+      const unsigned long long m = sm[threadIdx.x];
+      s.active[w0] = m;
+      if (m) {
+        atomicOr(&s.active1[w0 >> 6], 1ull << (w0 & 63));
+        atomicOr(&s.active2[w0 >> 12], 1ull << ((w0 >> 6) & 63));
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(64) k_grid_serial(DevState s) {
   SMX_LOAD_SOILS(sh)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -460,7 +502,7 @@ __global__ void __launch_bounds__(64) k_point_op(DevState s, PointOp o, double* 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct EvPair { hipEvent_t a, b; int phase; };
+struct EvPair { hipEvent_t a, b; int phase; uint32_t launches; };
 
 struct smx_ctx {
   smx_config cfg;
@@ -510,8 +552,11 @@ static void drain_events(smx_ctx* ctx) {
       case 0: ctx->timing.ms_water += ms; ctx->timing.launches_water++; break;
       case 1: ctx->timing.ms_grid += ms; ctx->timing.launches_grid++; break;
       case 2: ctx->timing.ms_wind += ms; ctx->timing.launches_wind++; break;
-      case 4: ctx->timing.ms_kernel_water += ms; ctx->timing.launches_kernel_water++; break;
-      case 5: ctx->timing.ms_kernel_wind += ms; ctx->timing.launches_kernel_wind++; break;
+      case 4: ctx->timing.ms_kernel_water += ms; ctx->timing.launches_kernel_water += p.launches; break;
+      case 5: ctx->timing.ms_kernel_wind += ms; ctx->timing.launches_kernel_wind += p.launches; break;
+      case 6: ctx->timing.ms_kernel_classify += ms; ctx->timing.launches_kernel_classify += p.launches; break;
+      case 7: ctx->timing.ms_kernel_gridtiles += ms; ctx->timing.launches_kernel_gridtiles += p.launches; break;
+      case 8: ctx->timing.ms_kernel_mapfreq += ms; ctx->timing.launches_kernel_mapfreq += p.launches; break;
       default: ctx->timing.ms_freq += ms; ctx->timing.launches_freq++; break;
     }
     ctx->evpool.push_back(p.a); ctx->evpool.push_back(p.b);
@@ -520,7 +565,7 @@ static void drain_events(smx_ctx* ctx) {
 }
 struct PhaseTimer {
   smx_ctx* ctx; EvPair p;
-  PhaseTimer(smx_ctx* c, int phase) : ctx(c) { p.a = ev_get(c); p.b = ev_get(c); p.phase = phase; hipEventRecord(p.a, c->stream); }
+  PhaseTimer(smx_ctx* c, int phase, uint32_t launches = 1) : ctx(c) { p.a = ev_get(c); p.b = ev_get(c); p.phase = phase; p.launches = launches; hipEventRecord(p.a, c->stream); }
   ~PhaseTimer() { hipEventRecord(p.b, ctx->stream); ctx->pending.push_back(p); if (ctx->pending.size() > 512) drain_events(ctx); }
 };
 
@@ -971,6 +1016,7 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
 }
 
 
+static void launch_classify(smx_ctx* ctx);
 // ---------------- batched engine: host driver (mirrored for the CPU by tests/hostsim/hostsim.cpp batch_generations) ----------------
 static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
   BatchShared& bs = ctx->bs;
@@ -1058,7 +1104,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
       const auto t_chunk = std::chrono::steady_clock::now();
       const uint32_t live_in = nlive;
       {
-        PhaseTimer tk(ctx, wind ? 5 : 4);
+        PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)CHUNK);   // CHUNK back-to-back launches of the epoch kernel, nothing else
         const unsigned nbl = (nlive + 63u) / 64u;
         for (int k = 0; k < CHUNK; k++, epoch++) {
           if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
@@ -1105,14 +1151,14 @@ static int batch_grid(smx_ctx* ctx) {
   HIPCHK(hipMemcpyAsync(&v0, ctx->d.ctr + C_GRID_ACTIVE, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, st));
   HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, st));
-  hipLaunchKernelGGL(k_grid_classify, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, st, ctx->d);
+  launch_classify(ctx);
   HIPCHK(hipStreamSynchronize(st));
   const uint32_t ntx = (uint32_t)((ctx->cfg.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), nty = (uint32_t)((ctx->cfg.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
   for (uint32_t col = 0; col < 9; col++) {
     const uint32_t cx = col / 3u, cy = col % 3u;
     const uint32_t mx = (ntx + 2u - cx) / 3u, my = (nty + 2u - cy) / 3u;
     if (mx * my == 0) continue;
-    hipLaunchKernelGGL(k_batch_grid, dim3((mx * my + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, col, mx, my);
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_batch_grid, dim3((mx * my + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, col, mx, my); }
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
   }
   hipLaunchKernelGGL(k_batch_grid_finish, dim3(1), dim3(1), 0, st, ctx->d, v0);
@@ -1131,6 +1177,15 @@ static int batch_grid(smx_ctx* ctx) {
   return 0;
 }
 
+static void launch_classify(smx_ctx* ctx) {                  // which cells can the grid pass change at all? (one flag byte per cell in, one bit out)
+  PhaseTimer tk(ctx, 6);
+  static const bool scalar = [] { const char* e = getenv("SMX_CLASSIFY_SCALAR"); return e && atoi(e) != 0; }();
+  if (ctx->cfg.dimy % 8 == 0 && ctx->ncells % 64 == 0 && !scalar)
+    hipLaunchKernelGGL(k_grid_classify8, dim3((unsigned)((ctx->ncells / 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d);
+  else
+    hipLaunchKernelGGL(k_grid_classify, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d);
+}
+
 // ---------------- the hot path ----------------
 int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   PhaseTimer t(ctx, 0);
@@ -1146,8 +1201,7 @@ int smx_grid_pass(smx_ctx* ctx) {
   if (ctx->cfg.engine == SMX_ENGINE_BATCHED) return batch_grid(ctx);
   HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, ctx->stream));
-  const unsigned nb = (unsigned)((ctx->ncells + 255) / 256);
-  hipLaunchKernelGGL(k_grid_classify, dim3(nb), dim3(256), 0, ctx->stream, ctx->d);
+  launch_classify(ctx);
   hipLaunchKernelGGL(k_grid_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1167,7 +1221,7 @@ int smx_map_frequency(smx_ctx* ctx) {
   unsigned nb = (unsigned)((n4 + 255) / 256);
   if (nb > 2048) nb = 2048;
   if (nb == 0) nb = 1;
-  hipLaunchKernelGGL(k_map_frequency, dim3(nb), dim3(256), 0, ctx->stream, ctx->d.wfreq, ctx->d.wtrack, n4, n);
+  { PhaseTimer tk(ctx, 8); hipLaunchKernelGGL(k_map_frequency, dim3(nb), dim3(256), 0, ctx->stream, ctx->d.wfreq, ctx->d.wtrack, n4, n); }
   HIPCHK(hipGetLastError());
   return 0;
 }
