@@ -150,6 +150,11 @@ int smx_set_engine(smx_ctx* ctx, int32_t engine);
 /* batched engine only: widen every reservation by `tiles` 4x4-cell tiles (0 = default; >= the map's tile count makes
  * the engine run the particles strictly one after the other, i.e. in the reference's order) */
 int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles);
+/* batched engine: column strips (DESIGN.md "Multi-GPU"). The schedule alternates INTERIOR chunks (a particle acts iff its
+ * reservation lies `inset` cells inside one of `nstrips` equal x-strips) and SEAM chunks (iff inside one seam zone of
+ * +-seam_halfwidth cells around a strip boundary). nstrips == 1 (default) = the single-strip schedule. The result is a
+ * function of (nstrips, inset, seam_halfwidth) only -- not of how many devices run the strips. */
+int smx_set_batch_strips(smx_ctx* ctx, int32_t nstrips, int32_t inset, int32_t seam_halfwidth);
 /* batched engine: epochs (kernel rounds), generations and dropped child particles since the context was created */
 int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost);
 void* smx_stream(smx_ctx* ctx);                          /* the hipStream_t all work is queued on */

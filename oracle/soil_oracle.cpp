@@ -723,14 +723,28 @@ struct so_ctx {
   }
 
   enum { B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3 };   // B_NEW: a top-level particle that has not acted yet
-  struct BSlot { Water w; Wind d; int state; BRect rect; bool toplevel; };
+  struct BSlot { Water w; Wind d; int state; BRect rect; bool toplevel; bool claiming; };
+  // column strips (soil_batch.h BStrips): INTERIOR and SEAM chunks alternate; only eligible particles reserve and act
+  int bs_n = 1, bs_a = 16, bs_b = 48, bs_phase = 0;
+  int bs_x(int g) const { return g >= bs_n ? dimx : (int)(((long long)dimx * g / bs_n) / 16 * 16); }
+  bool b_eligible(const BRect& r) const {
+    if (bs_n <= 1) return true;
+    if (r.empty()) return false;
+    const int cx0 = r.tx0 << B_TILE, cx1 = std::min(((r.tx1 + 1) << B_TILE) - 1, dimx - 1);
+    if (bs_phase == 0) {
+      for (int g = 0; g < bs_n; g++) { const int lo = bs_x(g) + (g ? bs_a : 0), hi = bs_x(g + 1) - (g < bs_n - 1 ? bs_a : 0); if (cx0 >= lo && cx1 < hi) return true; }
+    } else {
+      for (int g = 0; g + 1 < bs_n; g++) if (cx0 >= bs_x(g + 1) - bs_b && cx1 < bs_x(g + 1) + bs_b) return true;
+    }
+    return false;
+  }
 
   // winners of an epoch: slot i holds its reservation iff it is the lowest claimant of every tile in it
   void b_winners(const std::vector<BSlot>& sl, std::vector<uint32_t>& tilemin, std::vector<char>& win) {
     const int nty = b_nty();
     std::vector<size_t> touched;
     for (uint32_t i = 0; i < sl.size(); i++) {
-      if (sl[i].state == B_DONE) continue;
+      if (sl[i].state == B_DONE || !sl[i].claiming) continue;
       const BRect& r = sl[i].rect;
       for (int tx = r.tx0; tx <= r.tx1; tx++)
         for (int ty = r.ty0; ty <= r.ty1; ty++) {
@@ -741,7 +755,7 @@ struct so_ctx {
     }
     for (uint32_t i = 0; i < sl.size(); i++) {
       win[i] = 0;
-      if (sl[i].state == B_DONE) continue;
+      if (sl[i].state == B_DONE || !sl[i].claiming) continue;
       const BRect& r = sl[i].rect;
       bool ok = true;
       for (int tx = r.tx0; tx <= r.tx1 && ok; tx++)
@@ -792,17 +806,20 @@ struct so_ctx {
       uint32_t nlive = nslots, epoch = 0;
       b_children.clear();
       int grain = -1;
+      uint32_t chunk = 0;
       while (nlive > 0) {
         int tshift;
         b_schedule(wind, nlive, b_base_dilate, tshift, dilate, maxsteps);
-        if (tshift != grain) {                                // first chunk / new claim granularity: every running particle
-          grain = tshift; B_TILE = tshift;                    // re-issues its reservation from its current state
-          tilemin.assign((size_t)b_ntx() * b_nty(), 0xFFFFFFFFu);
-          for (BSlot& q : sl) {
+        bs_phase = bs_n > 1 ? (int)(chunk & 1u) : 0;          // column strips: INTERIOR and SEAM chunks alternate
+        chunk++;
+        if (tshift != grain || bs_n > 1) {                    // first chunk / new claim granularity / (strips) every chunk:
+          if (tshift != grain) { grain = tshift; B_TILE = tshift; tilemin.assign((size_t)b_ntx() * b_nty(), 0xFFFFFFFFu); }
+          for (BSlot& q : sl) {                               // every running particle re-issues its reservation from its current state
             if (q.state == B_DONE) continue;
             if (wind) q.rect = b_dilate(b_wind_need_run(q.d), dilate);
             else if (q.state == B_ENDED) { if (!b_water_floods(q.w)) { q.state = B_DONE; q.rect = {0, -1, 0, -1}; } else q.rect = b_water_need_flood(q.w); }
             else q.rect = b_dilate(b_water_need_run(q.w), dilate);
+            q.claiming = q.state != B_DONE && b_eligible(q.rect);
           }
         }
         for (int k = 0; k < 16; k++, epoch++) {
@@ -817,7 +834,7 @@ struct so_ctx {
               if (wind) need = b_wind_need_run(q.d);
               else if (q.state == B_RUN || q.state == B_NEW) need = b_water_need_run(q.w);
               else { if (!b_water_floods(q.w)) { q.state = B_DONE; break; } need = b_water_need_flood(q.w); }
-              if (acted >= maxsteps || !b_inside(held, need)) { q.rect = (!wind && q.state == B_ENDED) ? need : b_dilate(need, dilate); break; }   // no margin for a flood
+              if (acted >= maxsteps || !b_inside(held, need)) { q.rect = (!wind && q.state == B_ENDED) ? need : b_dilate(need, dilate); q.claiming = b_eligible(q.rect); break; }   // no margin for a flood
               acted++;
               b_guard = &held; b_ctx = wind ? "wind" : (q.state != B_ENDED ? "water-step" : "flood");
               if (q.state == B_NEW) {                         // the particle's constructor reads its spawn cell NOW (water.h:15-17, wind.h:19-21)
@@ -882,8 +899,15 @@ struct so_ctx {
     B_TILE = B_GRID;                                          // (the access guard below speaks in grid tiles)
     uint64_t visited = 0;
     b_children.clear();
+    for (int ph = 0; ph < (bs_n > 1 ? 2 : 1); ph++)
     for (int col = 0; col < 9; col++)
-      for (int tx = col / 3; tx < ntx; tx += 3)
+      for (int tx = col / 3; tx < ntx; tx += 3) {
+        if (bs_n > 1) {                                       // INTERIOR sweep: tiles whose neighbourhood lies inside one strip; SEAM sweep: the rest
+          const int cx0 = std::max(tx - 1, 0) << B_GRID, cx1 = std::min(((tx + 2) << B_GRID) - 1, dimx - 1);
+          bool interior = false;
+          for (int g = 0; g < bs_n; g++) { const int lo = bs_x(g) + (g ? bs_a : 0), hi = bs_x(g + 1) - (g < bs_n - 1 ? bs_a : 0); if (cx0 >= lo && cx1 < hi) interior = true; }
+          if ((ph == 0) != interior) continue;
+        }
         for (int ty = col % 3; ty < nty; ty += 3) {
           b_defer = true; b_parent = (uint64_t)col * ntx * nty + (uint64_t)tx * nty + ty; b_seq = 0;
           const BRect g = {tx - 1 < 0 ? 0 : tx - 1, tx + 1 > ntx - 1 ? ntx - 1 : tx + 1, ty - 1 < 0 ? 0 : ty - 1, ty + 1 > nty - 1 ? nty - 1 : ty + 1};
@@ -897,6 +921,7 @@ struct so_ctx {
             }
           b_guard = nullptr; b_defer = false;
         }
+      }
     ctr.wcascade_calls += n - visited;                        // the reference "calls" cascade on every cell (water.h:340)
     ctr.grid_active_cells += visited;
     std::vector<BChild> kids = b_children;
@@ -1067,6 +1092,7 @@ void so_batched_tick(so_ctx* c, int nwater, int nwind, int dowater, int dowind) 
 }
 void so_batched_set_dilate(so_ctx* c, int tiles) { c->b_base_dilate = tiles < 0 ? 0 : tiles; }
 void so_batched_set_cell_above(so_ctx* c, uint32_t n) { c->b_cell_above = n; }
+void so_batched_set_strips(so_ctx* c, int n, int a, int b) { c->bs_n = n < 1 ? 1 : n; c->bs_a = a; c->bs_b = b; }
 void so_batched_stats(so_ctx* c, uint64_t* out3) { out3[0] = c->b_epochs; out3[1] = c->b_ngen; out3[2] = c->b_guard_violations; }
 void so_dep_enable(so_ctx* c, int on) {
   c->dep_on = on != 0;

@@ -78,6 +78,7 @@ void so_batched_wind(so_ctx*, int n);
 void so_batched_tick(so_ctx*, int nwater, int nwind, int dowater, int dowind);
 void so_batched_set_dilate(so_ctx*, int tiles);
 void so_batched_set_cell_above(so_ctx*, uint32_t nlive);   // schedule knob: per-cell reservations while more particles run
+void so_batched_set_strips(so_ctx*, int nstrips, int inset, int seam_halfwidth);   // column-strip schedule (INTERIOR / SEAM chunks)
 void so_batched_stats(so_ctx*, uint64_t* out3);
 // dependency analysis between particles of one phase (evidence for DESIGN.md, not a simulation feature):
 // out7 = {tasks, DAG depth (in-place: RAW+WAW+WAR), DAG depth (multi-version: RAW+WAW), conflict-free tasks,

@@ -55,7 +55,7 @@ SYMBOLS = [
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
     "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices",
-    "smx_digest", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats",
+    "smx_digest", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips",
 ]
 
 _lib = None
@@ -109,6 +109,7 @@ def load() -> C.CDLL:
     L.smx_timing_reset.argtypes = [vp]
     L.smx_set_engine.argtypes = [vp, i32]
     L.smx_set_batch_dilate.argtypes = [vp, i32]
+    L.smx_set_batch_strips.argtypes = [vp, i32, i32, i32]
     L.smx_get_batch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.smx_stream.argtypes = [vp]; L.smx_stream.restype = vp
     for name in SYMBOLS:

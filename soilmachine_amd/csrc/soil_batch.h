@@ -31,6 +31,7 @@ namespace smx {
 
 constexpr int GRID_SHIFT = 2;                 // the grid pass works on 4x4-cell tiles (one cascade reaches 4 cells)
 constexpr uint32_t B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3;   // B_NEW: top-level particle that has not acted yet
+constexpr uint32_t B_AWAY = 4;               // column strips on several devices: the particle currently lives on another device
 constexpr int B_MAXCHILD = 24;                // nested particles one flood / one grid tile may emit per pass
 
 struct BRect { int tx0, tx1, ty0, ty1; };     // inclusive tile ranges; tx1 < tx0: empty
@@ -45,6 +46,16 @@ struct BChild {                               // a nested WaterParticle waiting 
   double volume;
 };
 
+// Column strips (DESIGN.md "Multi-GPU"): the map is cut into x-strips [x[g], x[g+1]); chunks of epochs alternate between
+//   INTERIOR  a particle may act iff its whole reservation lies at least `a` cells inside ONE strip (map edges excepted), and
+//   SEAM      iff it lies inside ONE seam zone [x[g+1]-b, x[g+1]+b).
+// b - a is at least the widest reservation (32 cells), so every reservation fits one of the two. In an INTERIOR chunk the
+// strips touch disjoint cells -- one device each, nothing to exchange; a SEAM chunk is run by the device left of the
+// seam, on a halo that is refreshed before and handed back after. Ineligible particles do not reserve anything (they
+// are dormant until the other kind of chunk). With n == 1 everything is interior: the single-device schedule.
+struct BStrips { int n; int x[9]; int a, b; };
+constexpr int STRIP_INTERIOR = 0, STRIP_SEAM = 1;
+
 enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_COUNT = 16 };
 
 struct BatchShared {
@@ -58,6 +69,9 @@ struct BatchShared {
   const uint32_t* draws;                      // rand() values (already >> 1) of this generation: 2 per slot
   int dilate;                                 // reservations are widened by this many tiles on every side (see bdilate)
   int maxsteps;                               // actions one particle may take in one epoch while it stays inside the tiles it holds
+  BStrips strips; int sphase;                 // column strips and the kind of the running chunk
+  uint8_t* dirty;                             // [grid tiles] strips only: columns of this 4x4 tile changed since the last halo exchange
+  int own_x0, own_x1;                         // strips on several devices: particles spawning outside [own_x0, own_x1) live elsewhere
 };
 
 SMX_D unsigned long long btag(uint32_t epoch, uint32_t slot) { return ((unsigned long long)(epoch + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - slot); }
@@ -83,6 +97,35 @@ SMX_D BRect bdilate(const BatchShared& bs, const BRect& r) {
   o.tx0 = r.tx0 - bs.dilate < 0 ? 0 : r.tx0 - bs.dilate; o.tx1 = r.tx1 + bs.dilate > bs.ntx - 1 ? bs.ntx - 1 : r.tx1 + bs.dilate;
   o.ty0 = r.ty0 - bs.dilate < 0 ? 0 : r.ty0 - bs.dilate; o.ty1 = r.ty1 + bs.dilate > bs.nty - 1 ? bs.nty - 1 : r.ty1 + bs.dilate;
   return o;
+}
+// may a particle with this reservation act in the running kind of chunk?
+SMX_D bool beligible(const DevState& s, const BatchShared& bs, const BRect& r) {
+  const BStrips& st = bs.strips;
+  if (st.n <= 1) return true;
+  if (brect_empty(r)) return false;
+  const int cx0 = r.tx0 << bs.tshift;
+  int cx1 = ((r.tx1 + 1) << bs.tshift) - 1; if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
+  if (bs.sphase == STRIP_INTERIOR) {
+    for (int g = 0; g < st.n; g++) {
+      const int lo = st.x[g] + (g ? st.a : 0), hi = st.x[g + 1] - (g < st.n - 1 ? st.a : 0);
+      if (cx0 >= lo && cx1 < hi) return true;
+    }
+  } else {
+    for (int g = 0; g + 1 < st.n; g++)
+      if (cx0 >= st.x[g + 1] - st.b && cx1 < st.x[g + 1] + st.b) return true;
+  }
+  return false;
+}
+// strips: remember which 4x4 grid tiles a particle that acted may have changed (its whole reservation), for the halo exchange
+SMX_D void bmark_dirty(const DevState& s, const BatchShared& bs, const BRect& r) {
+  if (bs.strips.n <= 1 || !bs.dirty || brect_empty(r)) return;
+  const int gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+  const int cx0 = r.tx0 << bs.tshift, cy0 = r.ty0 << bs.tshift;
+  int cx1 = ((r.tx1 + 1) << bs.tshift) - 1, cy1 = ((r.ty1 + 1) << bs.tshift) - 1;
+  if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
+  if (cy1 > s.dimy - 1) cy1 = s.dimy - 1;
+  for (int gx = cx0 >> GRID_SHIFT; gx <= (cx1 >> GRID_SHIFT); gx++)
+    for (int gy = cy0 >> GRID_SHIFT; gy <= (cy1 >> GRID_SHIFT); gy++) bs.dirty[(size_t)gx * gty + gy] = 1;
 }
 SMX_D void bclaim(const BatchShared& bs, int plane, const BRect& r, unsigned long long tag) {
   for (int tx = r.tx0; tx <= r.tx1; tx++)
@@ -191,12 +234,16 @@ SMX_D BRect wind_intent_run(Sim<P>& sim, const BatchShared& bs, const Wind& d, c
 // ---------------- generation start: construct the particles, publish their first reservations (plane 0, epoch 0) -------
 // top-level particle `slot` of a phase: WaterParticle(map) (water.h:11-19) from draws 2*slot (-> y), 2*slot+1 (-> x)
 template <class P>
-SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, const BChild* child) {
+SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, const BChild* child, const uint32_t* contains = nullptr) {
   const DevState& s = sim.s;
   BWater& q = bs.water[slot];
   const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
   Water w;
-  sim.water_init(w, rx, ry);
+  if (contains) {                                            // strips on several devices: the random cell of water.h:251 may lie on another
+    w.pos = {(float)rx, (float)ry}; w.speed = {0.f, 0.f};    // device -- its owner read `contains` for us (batch_child_contains)
+    w.volume = 1.0; w.sediment = 0.0; w.evaprate = 0.001; w.spill = 3;
+    w.ix = rx; w.iy = ry; w.surface = 0; w.friction = 0.f; w.contains = contains[slot];
+  } else sim.water_init(w, rx, ry);
   q.toplevel = child ? 0u : 1u;
   if (child) {                                               // water.h:251-256: position, direction, volume, spill of a nested particle
     const f2 d = {(float)child->bx - (float)child->tx, (float)child->by - (float)child->ty};
@@ -214,6 +261,15 @@ SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
   q.w = w; q.state = child ? B_RUN : B_NEW;
   q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad = 0;
   q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_water_reclaim
+  if (w.ix < bs.own_x0 || w.ix >= bs.own_x1) q.state = B_AWAY;
+}
+// `contains` of a nested particle = soils[surface(random cell)].transports (water.h:15-17 via :251), read by the device
+// that owns the random cell; 0xFFFFFFFF elsewhere (the callers combine the devices' answers with a minimum)
+SMX_D uint32_t batch_child_contains(const DevState& s, const SoilP* soils, const BatchShared& bs, uint32_t slot) {
+  const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
+  if (rx < bs.own_x0 || rx >= bs.own_x1) return 0xFFFFFFFFu;
+  const uint32_t t = s.cells[(size_t)rx * s.dimy + ry].type;
+  return soils[t == EMPTY ? 0u : t].transports;
 }
 template <class P>
 SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
@@ -225,6 +281,7 @@ SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
   q.d = d; q.pad = 0; q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad2 = 0;
   q.state = B_NEW;                                           // `contains` (wind.h:19-21) is read when the particle first acts
   q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_wind_reclaim
+  if (d.ix < bs.own_x0 || d.ix >= bs.own_x1) q.state = B_AWAY;
 }
 
 // (Re)issue the reservation of a running particle for epoch `epoch` from its CURRENT state: at the start of a
@@ -233,7 +290,7 @@ SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
 template <class P>
 SMX_D void batch_water_reclaim(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
   BWater& q = bs.water[slot];
-  if (q.state == B_DONE) return;
+  if (q.state == B_DONE || q.state == B_AWAY) return;
   BRect r;
   if (q.state == B_ENDED) {
     if (!water_floods(q.w)) { q.state = B_DONE; q.rect = BRect{0, -1, 0, -1}; return; }
@@ -245,17 +302,17 @@ SMX_D void batch_water_reclaim(Sim<P>& sim, const BatchShared& bs, uint32_t slot
     r = bdilate(bs, water_intent_run(sim, bs, q.w, A, t, mv));
   }
   q.rect = r;
-  bclaim(bs, (int)(epoch & 1u), r, btag(epoch, slot));
+  if (beligible(sim.s, bs, r)) bclaim(bs, (int)(epoch & 1u), r, btag(epoch, slot));
 }
 template <class P>
 SMX_D void batch_wind_reclaim(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
   BWind& q = bs.wind[slot];
-  if (q.state == B_DONE) return;
+  if (q.state == B_DONE || q.state == B_AWAY) return;
   Blk A;
   sim.template load_block<1>(q.d.ix, q.d.iy, A);
   Wind t; bool mv;
   q.rect = bdilate(bs, wind_intent_run(sim, bs, q.d, A, t, mv));
-  bclaim(bs, (int)(epoch & 1u), q.rect, btag(epoch, slot));
+  if (beligible(sim.s, bs, q.rect)) bclaim(bs, (int)(epoch & 1u), q.rect, btag(epoch, slot));
 }
 
 // ---------------- one epoch of one particle ----------------
@@ -268,7 +325,7 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
   const DevState& s = sim.s;
   BWater& q = bs.water[slot];
   uint32_t state = q.state;
-  if (state == B_DONE) return;
+  if (state == B_DONE || state == B_AWAY) return;
   BRect rect = q.rect;
   const int cur = (int)(epoch & 1u), nxt = cur ^ 1;
   if (bholds(bs, cur, rect, btag(epoch, slot))) {
@@ -313,20 +370,21 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
       }
     }
     q.w = w; q.state = state;
+    if (acted) bmark_dirty(s, bs, held);
     if (state == B_DONE) rect = BRect{0, -1, 0, -1};
     q.rect = rect;
     sim.flush_counters();
     q.c_steps += sim.pol.a_steps; q.c_casc += sim.pol.a_casc; q.c_tr += sim.pol.a_tr;
     sim.pol.a_steps = sim.pol.a_casc = sim.pol.a_tr = 0;
   }
-  if (state != B_DONE) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
+  if (state != B_DONE && beligible(s, bs, rect)) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
 }
 
 template <class P>
 SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
   BWind& q = bs.wind[slot];
   uint32_t state = q.state;
-  if (state == B_DONE) return;
+  if (state == B_DONE || state == B_AWAY) return;
   BRect rect = q.rect;
   const int cur = (int)(epoch & 1u), nxt = cur ^ 1;
   if (bholds(bs, cur, rect, btag(epoch, slot))) {
@@ -354,13 +412,14 @@ SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
       } else { state = B_DONE; break; }
     }
     q.d = d; q.state = state;
+    if (acted) bmark_dirty(sim.s, bs, held);
     if (state == B_DONE) rect = BRect{0, -1, 0, -1};
     q.rect = rect;
     sim.flush_counters();
     q.c_steps += sim.pol.a_steps; q.c_casc += sim.pol.a_casc; q.c_tr += sim.pol.a_tr;
     sim.pol.a_steps = sim.pol.a_casc = sim.pol.a_tr = 0;
   }
-  if (state != B_DONE) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
+  if (state != B_DONE && beligible(sim.s, bs, rect)) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
 }
 
 // The schedule of a generation (part of the engine's definition: the CPU restatement follows the same rule): claim
@@ -391,6 +450,13 @@ SMX_HD BSched batch_schedule(bool wind, uint32_t nlive, int base_dilate, uint32_
   if (base_dilate > k.dilate) k.dilate = base_dilate;
   return k;
 }
+// n equal strips, boundaries on multiples of 16 cells (the widest claim tile is 8 cells, the grid tiles are 4)
+SMX_HD BStrips batch_make_strips(int dimx, int n, int a, int b) {
+  BStrips st; st.n = n < 1 ? 1 : (n > 8 ? 8 : n); st.a = a; st.b = b;
+  for (int g = 0; g <= st.n; g++) st.x[g] = g == st.n ? dimx : (int)(((long long)dimx * g / st.n) / 16 * 16);
+  for (int g = st.n + 1; g < 9; g++) st.x[g] = dimx;
+  return st;
+}
 SMX_HD void batch_apply_schedule(BatchShared& bs, const DevState& s, const BSched& k) {
   bs.tshift = k.tshift; bs.dilate = k.dilate; bs.maxsteps = k.maxsteps;
   bs.ntx = (s.dimx + (1 << k.tshift) - 1) >> k.tshift; bs.nty = (s.dimy + (1 << k.tshift) - 1) >> k.tshift;
@@ -418,6 +484,13 @@ SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned l
       sim.water_drive(dummy, false, false, st, depth);
       visited++;
     }
+  if (visited && sim.pol.bs.strips.n > 1 && sim.pol.bs.dirty) {   // strips: the tile and its neighbours may have changed
+    const BatchShared& bs = sim.pol.bs;
+    const int gtx = (s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+    for (int ax = tx - 1; ax <= tx + 1; ax++)
+      for (int ay = ty - 1; ay <= ty + 1; ay++)
+        if (ax >= 0 && ay >= 0 && ax < gtx && ay < gty) bs.dirty[(size_t)ax * gty + ay] = 1;
+  }
   sim.flush_counters();                                      // (cascade counters of the grid pass go straight to DevState::ctr)
   if (sim.pol.a_casc) SMX_A_ADD64(&s.ctr[C_CASCADE_CALLS], (unsigned long long)sim.pol.a_casc);
   if (sim.pol.a_tr) SMX_A_ADD64(&s.ctr[C_CASCADE_TRANSFERS], (unsigned long long)sim.pol.a_tr);
@@ -425,10 +498,25 @@ SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned l
   return visited;
 }
 
+// grid pass under column strips: a tile's seep + cascade reaches one tile around it. It is processed in the INTERIOR
+// sweep if that neighbourhood lies `a` cells inside one strip, else in the SEAM sweep (exactly once either way).
+SMX_D bool batch_grid_tile_phase(const DevState& s, const BatchShared& bs, int tx) {
+  const BStrips& st = bs.strips;
+  if (st.n <= 1) return bs.sphase == STRIP_INTERIOR;
+  const int cx0 = (tx - 1 < 0 ? 0 : tx - 1) << GRID_SHIFT;
+  int cx1 = ((tx + 2) << GRID_SHIFT) - 1; if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
+  bool interior = false;
+  for (int g = 0; g < st.n; g++) {
+    const int lo = st.x[g] + (g ? st.a : 0), hi = st.x[g + 1] - (g < st.n - 1 ? st.a : 0);
+    if (cx0 >= lo && cx1 < hi) interior = true;
+  }
+  return (bs.sphase == STRIP_INTERIOR) == interior;
+}
+
 // generation end: the per-slot counters of slot `i` (device: wave-reduced before the atomics)
 SMX_D void batch_slot_counters(const BatchShared& bs, bool wind, uint32_t i, unsigned long long (&acc)[4]) {
-  if (wind) { const BWind& q = bs.wind[i]; acc[0] += q.c_steps; acc[2] += q.c_casc; acc[3] += q.c_tr; }
-  else { const BWater& q = bs.water[i]; acc[0] += q.c_steps; if (q.toplevel) acc[1] += q.c_steps; acc[2] += q.c_casc; acc[3] += q.c_tr; }
+  if (wind) { const BWind& q = bs.wind[i]; if (q.state == B_AWAY) return; acc[0] += q.c_steps; acc[2] += q.c_casc; acc[3] += q.c_tr; }
+  else { const BWater& q = bs.water[i]; if (q.state == B_AWAY) return; acc[0] += q.c_steps; if (q.toplevel) acc[1] += q.c_steps; acc[2] += q.c_casc; acc[3] += q.c_tr; }
 }
 SMX_D void batch_commit_counters(const DevState& s, bool wind, const unsigned long long (&acc)[4]) {
   if (acc[0]) SMX_A_ADD64(&s.ctr[wind ? C_STEPS_WIND : C_STEPS_WATER_ALL], acc[0]);

@@ -283,7 +283,8 @@ __global__ void __launch_bounds__(64) k_batch_epoch(DevState s, BatchShared bs, 
 template <bool WIND>
 __global__ void __launch_bounds__(256) k_batch_compact(BatchShared bs, uint32_t nslots) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  const bool alive = i < nslots && (WIND ? bs.wind[i].state : bs.water[i].state) != B_DONE;
+  const uint32_t st_ = i < nslots ? (WIND ? bs.wind[i].state : bs.water[i].state) : B_DONE;
+  const bool alive = st_ != B_DONE && st_ != B_AWAY;
   const unsigned long long m = __ballot(alive);
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t base = 0;
@@ -321,7 +322,7 @@ __global__ void __launch_bounds__(64) k_batch_grid(DevState s, BatchShared bs, u
   if (i < mx * my) {
     const uint32_t gtx = (uint32_t)((s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), gty = (uint32_t)((s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
     const uint32_t tx = col / 3u + 3u * (i / my), ty = col % 3u + 3u * (i % my);
-    if (tx < gtx && ty < gty) {
+    if (tx < gtx && ty < gty && batch_grid_tile_phase(s, bs, (int)tx)) {
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
       Frame st[MAX_FRAMES];
@@ -528,6 +529,8 @@ struct smx_ctx {
   BChild* d_kids = nullptr; uint32_t kids_cap = 0;
   uint32_t* h_bctrl = nullptr;
   int batch_dilate = 0;
+  int strips_n = 1, strips_a = 16, strips_b = 48;
+  int own_x0 = 0, own_x1 = -1;        // strips on several devices: the columns this context owns (-1: to the map's edge)
   uint64_t batch_epochs = 0, batch_generations = 0, batch_children_lost = 0;
 };
 
@@ -649,7 +652,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -671,6 +674,12 @@ int smx_set_soils(smx_ctx* ctx, const smx_soil* soils, int32_t n) {
 int smx_set_scale(smx_ctx* ctx, int32_t scale) { ctx->d.scale = scale; ctx->cfg.scale = scale; return 0; }
 int smx_set_engine(smx_ctx* ctx, int32_t engine) { ctx->cfg.engine = engine; return 0; }
 int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) { ctx->batch_dilate = tiles < 0 ? 0 : tiles; return 0; }
+int smx_set_batch_strips(smx_ctx* ctx, int32_t nstrips, int32_t inset, int32_t seam_halfwidth) {
+  if (nstrips < 1 || nstrips > 8 || inset < 0 || seam_halfwidth - inset < 32) { ctx->err = "smx_set_batch_strips: 1..8 strips, seam_halfwidth - inset >= 32"; return -2; }
+  if (nstrips > 1 && ctx->cfg.dimx / nstrips < 2 * seam_halfwidth + 16) { ctx->err = "smx_set_batch_strips: strips narrower than two seam zones"; return -2; }
+  ctx->strips_n = nstrips; ctx->strips_a = inset; ctx->strips_b = seam_halfwidth;
+  return 0;
+}
 int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost) {
   if (epochs) *epochs = ctx->batch_epochs;
   if (generations) *generations = ctx->batch_generations;
@@ -1027,6 +1036,10 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
     HIPCHK(hipMalloc(&bs.ctrl, BC_COUNT * 4)); HIPCHK(hipMemsetAsync(bs.ctrl, 0, BC_COUNT * 4, ctx->stream));
     bs.child_cap = 1u << 20; HIPCHK(hipMalloc(&bs.children, (size_t)bs.child_cap * sizeof(BChild)));
     bs.freed_cap = 1u << 22; HIPCHK(hipMalloc(&bs.freed, (size_t)bs.freed_cap * 4));
+    {
+      const size_t ngt = (size_t)((ctx->cfg.dimx + 3) >> 2) * ((ctx->cfg.dimy + 3) >> 2);
+      HIPCHK(hipMalloc(&bs.dirty, ngt)); HIPCHK(hipMemsetAsync(bs.dirty, 0, ngt, ctx->stream));
+    }
     HIPCHK(hipHostMalloc(&ctx->h_bctrl, BC_COUNT * 4));
   }
   if (ctx->batch_cap < nslots) {
@@ -1043,6 +1056,8 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
     ctx->draws_cap = cap;
   }
   bs.draws = ctx->d_draws; bs.dilate = ctx->batch_dilate; bs.maxsteps = 1;
+  bs.strips = batch_make_strips(ctx->cfg.dimx, ctx->strips_n, ctx->strips_a, ctx->strips_b); bs.sphase = STRIP_INTERIOR;
+  bs.own_x0 = ctx->own_x0; bs.own_x1 = ctx->own_x1 < 0 ? ctx->cfg.dimx : ctx->own_x1;
   (void)wind;
   return 0;
 }
@@ -1075,7 +1090,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     if (wind) hipLaunchKernelGGL(k_batch_spawn<true>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk);
     else hipLaunchKernelGGL(k_batch_spawn<false>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk);
     hipLaunchKernelGGL(k_batch_iota, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs.live, nslots);
-    uint32_t nlive = nslots, epoch = 0;
+    uint32_t nlive = nslots, epoch = 0, chunk = 0;
     static const int CHUNK = [] { const char* e = getenv("SMX_BATCH_CHUNK"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
     static const bool trace = [] { const char* e = getenv("SMX_TRACE_BATCH"); return e && atoi(e) != 0; }();
     while (nlive > 0) {
@@ -1093,11 +1108,15 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
           }
         }
       }
+      const bool strips = bs.strips.n > 1;
       const bool regrain = sc.tshift != bs.tshift;             // first chunk, or the claim granularity changes
       batch_apply_schedule(ctx->bs, ctx->d, sc);               // (bs aliases ctx->bs: passed by value per launch)
-      if (regrain) {
+      ctx->bs.sphase = strips ? (int)(chunk & 1u) : STRIP_INTERIOR;   // column strips: INTERIOR and SEAM chunks alternate
+      if (strips && chunk > 0) epoch++;                        // (reservations of the previous chunk must not look current)
+      chunk++;
+      if (regrain || strips) {                                 // under strips every chunk starts with fresh reservations
         const size_t nt = (size_t)bs.ntx * bs.nty;
-        HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st));
+        if (regrain) { HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st)); }
         if (wind) hipLaunchKernelGGL(k_batch_reclaim<true>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
         else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
       }
@@ -1154,7 +1173,10 @@ static int batch_grid(smx_ctx* ctx) {
   launch_classify(ctx);
   HIPCHK(hipStreamSynchronize(st));
   const uint32_t ntx = (uint32_t)((ctx->cfg.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), nty = (uint32_t)((ctx->cfg.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
+  ctx->bs.tshift = GRID_SHIFT;
+  for (int ph = 0; ph < (bs.strips.n > 1 ? 2 : 1); ph++)
   for (uint32_t col = 0; col < 9; col++) {
+    ctx->bs.sphase = ph;
     const uint32_t cx = col / 3u, cy = col % 3u;
     const uint32_t mx = (ntx + 2u - cx) / 3u, my = (nty + 2u - cy) / 3u;
     if (mx * my == 0) continue;

@@ -152,6 +152,9 @@ class Layermap:
     def set_batch_dilate(self, tiles: int):
         self._chk(self.L.smx_set_batch_dilate(self.h, int(tiles)))
 
+    def set_batch_strips(self, nstrips: int, inset: int = 16, seam_halfwidth: int = 48):
+        self._chk(self.L.smx_set_batch_strips(self.h, int(nstrips), int(inset), int(seam_halfwidth)))
+
     def batch_stats(self) -> dict:
         e, g, l = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.L.smx_get_batch_stats(self.h, C.byref(e), C.byref(g), C.byref(l)))

@@ -1,0 +1,302 @@
+"""Column strips: ONE layermap sharded over several devices (batched engine only; DESIGN.md "Multi-GPU").
+
+The map is cut into x-strips (Layermap index is x*dimy + y, layermap.h:151: an x-strip is one contiguous block). The
+batched engine's schedule alternates two kinds of 16-epoch chunks (csrc/soil_batch.h BStrips):
+
+  INTERIOR  a particle acts iff its whole reservation lies `a` cells inside one strip  -> strips touch disjoint cells,
+            every rank runs its own, nothing is exchanged;
+  SEAM      a particle acts iff its reservation lies inside one seam zone [x_b - b, x_b + b) around a strip boundary
+            -> the rank LEFT of the boundary runs the seam on a halo of b columns.
+
+Per chunk the ranks agree on the number of running particles (one all-reduce of 4 bytes: the schedule depends on it);
+around every SEAM chunk neighbours exchange, point to point, (i) the halo columns that changed (dirty 4x4 tiles only)
+and (ii) the particles that sit in the halo. Nested particles are all-gathered once per generation (they are sorted by
+key: slot numbers = priorities must be global). The result is a function of (nstrips, a, b) only: running the strips on
+one device with smx_set_batch_strips() gives the same bits (tests/test_strips.py, loop-back), as does any transport.
+
+Every rank allocates the full-size arrays and keeps only its strip + halo current (addresses stay global; at 288 GB per
+device the unused part costs nothing that matters). Each rank initialises the whole terrain itself (3 ms at 4096^2):
+no initial scatter.
+
+Transports: ThreadComm (ranks = threads of one process; loop-back on one device or on the host-sim), TorchComm
+(torch.distributed: gloo on the CPU, nccl = RCCL over xGMI on the GPUs).
+"""
+from __future__ import annotations
+
+import queue
+import threading
+
+import numpy as np
+
+CHILD_DT = np.dtype([("key", "<u8"), ("tx", "<i4"), ("ty", "<i4"), ("bx", "<i4"), ("by", "<i4"), ("spill", "<i4"),
+                     ("pad", "<i4"), ("volume", "<f8")])
+assert CHILD_DT.itemsize == 40
+INTERIOR, SEAM = 0, 1
+
+
+class StripGeometry:
+    """n equal strips with boundaries on multiples of 16 cells (== csrc/soil_batch.h batch_make_strips)."""
+
+    def __init__(self, dimx: int, n: int, a: int = 16, b: int = 48):
+        if b - a < 32:
+            raise ValueError("seam half-width - inset must be >= 32 cells (the widest reservation)")
+        if n > 1 and dimx // n < 2 * b + 16:
+            raise ValueError("strips narrower than two seam zones")
+        self.n, self.a, self.b, self.dimx = n, a, b, dimx
+        self.x = [dimx if g == n else (dimx * g // n) // 16 * 16 for g in range(n + 1)]
+
+
+# ------------------------------------------------------------------------------------------------ transports
+class ThreadComm:
+    """Ranks are threads of this process (loop-back transport). world = ThreadComm.world(n) -> one comm per rank."""
+
+    class _Shared:
+        def __init__(self, n):
+            self.n = n
+            self.barrier = threading.Barrier(n)
+            self.slots = [None] * n
+            self.q = {(s, d): queue.Queue() for s in range(n) for d in range(n)}
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.size = shared, rank, shared.n
+        self.bytes_sent = 0
+        self.messages = 0
+
+    @staticmethod
+    def world(n):
+        sh = ThreadComm._Shared(n)
+        return [ThreadComm(sh, r) for r in range(n)]
+
+    def _gather(self, v):
+        self.sh.slots[self.rank] = v
+        self.sh.barrier.wait()
+        out = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return out
+
+    def allreduce_sum(self, v: int) -> int:
+        return int(sum(self._gather(int(v))))
+
+    def allreduce_min_u32(self, a: np.ndarray) -> np.ndarray:
+        return np.minimum.reduce(self._gather(a))
+
+    def allgather_bytes(self, b: bytes):
+        return self._gather(b)
+
+    def send(self, dst: int, b: bytes):
+        self.bytes_sent += len(b); self.messages += 1
+        self.sh.q[(self.rank, dst)].put(b)
+
+    def recv(self, src: int) -> bytes:
+        return self.sh.q[(src, self.rank)].get()
+
+
+class TorchComm:
+    """torch.distributed transport: backend "gloo" (CPU tensors) or "nccl" (= RCCL; tensors on this rank's GPU)."""
+
+    def __init__(self, dist, device=None):
+        import torch
+        self.t, self.dist = torch, dist
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        self.dev = device if device is not None else torch.device("cpu")
+        self.bytes_sent = 0
+        self.messages = 0
+
+    def allreduce_sum(self, v: int) -> int:
+        x = self.t.tensor([int(v)], dtype=self.t.int64, device=self.dev)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
+        return int(x.item())
+
+    def allreduce_min_u32(self, a: np.ndarray) -> np.ndarray:
+        x = self.t.from_numpy(a.astype(np.int64)).to(self.dev)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.MIN)
+        return x.cpu().numpy().astype(np.uint32)
+
+    def allgather_bytes(self, b: bytes):
+        n = self.t.tensor([len(b)], dtype=self.t.int64, device=self.dev)
+        sizes = [self.t.zeros(1, dtype=self.t.int64, device=self.dev) for _ in range(self.size)]
+        self.dist.all_gather(sizes, n)
+        m = max(int(s.item()) for s in sizes)
+        buf = self.t.zeros(max(m, 1), dtype=self.t.uint8, device=self.dev)
+        if len(b):
+            buf[:len(b)] = self.t.frombuffer(bytearray(b), dtype=self.t.uint8).to(self.dev)
+        outs = [self.t.zeros(max(m, 1), dtype=self.t.uint8, device=self.dev) for _ in range(self.size)]
+        self.dist.all_gather(outs, buf)
+        return [bytes(o[:int(s.item())].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
+
+    def send(self, dst: int, b: bytes):
+        self.bytes_sent += len(b); self.messages += 1
+        n = self.t.tensor([len(b)], dtype=self.t.int64, device=self.dev)
+        self.dist.send(n, dst)
+        if len(b):
+            self.dist.send(self.t.frombuffer(bytearray(b), dtype=self.t.uint8).to(self.dev), dst)
+
+    def recv(self, src: int) -> bytes:
+        n = self.t.zeros(1, dtype=self.t.int64, device=self.dev)
+        self.dist.recv(n, src)
+        k = int(n.item())
+        if k == 0:
+            return b""
+        buf = self.t.zeros(k, dtype=self.t.uint8, device=self.dev)
+        self.dist.recv(buf, src)
+        return bytes(buf.cpu().numpy().tobytes())
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+class StripRank:
+    """The tick of SoilMachine.cpp:283-329 on ONE strip. `backend` = DeviceStripBackend (libsoilmx) or the host-sim's."""
+
+    def __init__(self, backend, comm, geom: StripGeometry):
+        self.be, self.comm, self.g = backend, comm, geom
+        assert comm.size == geom.n
+        r = comm.rank
+        self.x0, self.x1 = geom.x[r], geom.x[r + 1]
+        backend.set_strips(geom.n, geom.a, geom.b)
+        backend.set_own(self.x0, self.x1)
+        self.stats = {"chunks": 0, "seam_chunks": 0, "generations": 0}
+
+    # -- halo traffic (nearest neighbours only). A rank holds, besides its strip, the b columns right of its right boundary.
+    def _send_band_left(self, particles: bool):
+        """band [x0, x0 + b) of this strip -> the rank on the left (which runs that seam)"""
+        r, g = self.comm.rank, self.g
+        if r > 0:
+            self.comm.send(r - 1, self.be.pack_columns(self.x0, self.x0 + g.b))
+            if particles:
+                self.comm.send(r - 1, self.be.pack_particles(self.x0, self.x0 + g.b))
+
+    def _recv_band_from_right(self, particles: bool):
+        r, g = self.comm.rank, self.g
+        if r < g.n - 1:
+            self.be.unpack_columns(self.comm.recv(r + 1))
+            if particles:
+                self.be.unpack_particles(self.comm.recv(r + 1))
+
+    def _send_band_right(self, particles: bool):
+        """the halo [x1, x1 + b) goes home to the rank on the right, with every particle that sits beyond x1"""
+        r, g = self.comm.rank, self.g
+        if r < g.n - 1:
+            self.comm.send(r + 1, self.be.pack_columns(self.x1, self.x1 + g.b))
+            if particles:
+                self.comm.send(r + 1, self.be.pack_particles(self.x1, g.dimx))
+
+    def _recv_band_from_left(self, particles: bool):
+        r = self.comm.rank
+        if r > 0:
+            self.be.unpack_columns(self.comm.recv(r - 1))
+            if particles:
+                self.be.unpack_particles(self.comm.recv(r - 1))
+
+    def sync_halos(self):
+        self._send_band_left(False)
+        self._recv_band_from_right(False)
+
+    # -- one particle phase: generations of chunks
+    def _phase(self, wind: bool, n: int, kids=None):
+        be, comm = self.be, self.comm
+        nslots = n if kids is None else len(kids)
+        while nslots > 0:
+            contains = be.gen_begin(wind, nslots, kids)
+            if kids is not None:
+                contains = comm.allreduce_min_u32(contains)          # each child's `contains` comes from the owner of its random cell
+            nlive = comm.allreduce_sum(be.gen_spawn(contains if kids is not None else None))
+            while nlive > 0:
+                seam = self.g.n > 1 and be.next_phase() == SEAM
+                if seam:
+                    self._send_band_left(True)
+                    self._recv_band_from_right(True)
+                local = be.chunk(nlive)
+                if seam:
+                    self._send_band_right(True)
+                    self._recv_band_from_left(True)
+                    self.stats["seam_chunks"] += 1
+                self.stats["chunks"] += 1
+                nlive = comm.allreduce_sum(local)
+            mine = be.gen_end()
+            self.stats["generations"] += 1
+            if wind:
+                break
+            parts = [np.frombuffer(b, dtype=CHILD_DT) for b in comm.allgather_bytes(mine.tobytes())]
+            kids = np.concatenate(parts) if parts else np.zeros(0, CHILD_DT)
+            kids = kids[np.argsort(kids["key"], kind="stable")]
+            nslots = len(kids)
+        if self.g.n > 1:
+            self.sync_halos()                                        # the halo is current again (frequency planes, next phase)
+
+    def _grid(self):
+        be, g, r = self.be, self.g, self.comm.rank
+        be.grid_begin()
+        be.grid_sweep(INTERIOR, self.x0 >> 2, self.x1 >> 2)
+        if g.n > 1:
+            self.sync_halos()
+            if r < g.n - 1:
+                be.grid_sweep(SEAM, (self.x1 - g.b) >> 2, (self.x1 + g.b) >> 2)
+            self._send_band_right(False)
+            self._recv_band_from_left(False)
+        mine = be.gen_end()
+        parts = [np.frombuffer(b, dtype=CHILD_DT) for b in self.comm.allgather_bytes(mine.tobytes())]
+        kids = np.concatenate(parts) if parts else np.zeros(0, CHILD_DT)
+        kids = kids[np.argsort(kids["key"], kind="stable")]
+        if len(kids):
+            self._phase(False, 0, kids)
+        elif g.n > 1:
+            self.sync_halos()
+
+    def tick(self, nwater: int, nwind: int, dowater: bool = True, dowind: bool = True):
+        if dowater:
+            self._phase(False, nwater)
+            self._grid()
+        if dowind:
+            self._phase(True, nwind)
+        if dowater:
+            self.be.map_frequency()
+            self.be.reset_frequency()
+
+
+def run_threads(ranks, fn):
+    """loop-back: run fn(rank_object) for every StripRank in its own thread (the transports block on each other)"""
+    errs = []
+
+    def wrap(rk):
+        try:
+            fn(rk)
+        except BaseException as e:   # noqa: BLE001 -- re-raised below
+            errs.append(e)
+            try:
+                rk.comm.sh.barrier.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=wrap, args=(rk,)) for rk in ranks]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+
+
+def merge_owned(geom: StripGeometry, snaps, dimy: int):
+    """One global Snapshot from per-rank snapshots: every column from the rank that owns it."""
+    from .snapshot import Snapshot
+    s0 = snaps[0]
+    owner = np.zeros(geom.dimx * dimy, np.int32)
+    for r in range(geom.n):
+        owner[geom.x[r] * dimy: geom.x[r + 1] * dimy] = r
+    count = np.zeros_like(s0.count)
+    cols = {k: [] for k in ("type", "size", "floor", "sat")}
+    starts = [np.concatenate([[0], np.cumsum(s.count.astype(np.int64))]) for s in snaps]
+    for r in range(geom.n):
+        c0, c1 = geom.x[r] * dimy, geom.x[r + 1] * dimy
+        count[c0:c1] = snaps[r].count[c0:c1]
+        a, b = starts[r][c0], starts[r][c1]
+        for k in cols:
+            cols[k].append(getattr(snaps[r], k)[a:b])
+    planes = {}
+    for k in ("wfreq", "wtrack", "windfreq"):       # frequency order: index y*dimx + x
+        out = np.zeros_like(getattr(s0, k)).reshape(dimy, geom.dimx)
+        for r in range(geom.n):
+            out[:, geom.x[r]:geom.x[r + 1]] = getattr(snaps[r], k).reshape(dimy, geom.dimx)[:, geom.x[r]:geom.x[r + 1]]
+        planes[k] = out.reshape(-1)
+    return Snapshot(s0.dimx, s0.dimy, s0.scale, s0.nsoils, s0.rand_calls, s0.pool_free, count,
+                    np.concatenate(cols["type"]), np.concatenate(cols["size"]), np.concatenate(cols["floor"]),
+                    np.concatenate(cols["sat"]), planes["wfreq"], planes["wtrack"], planes["windfreq"])

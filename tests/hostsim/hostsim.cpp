@@ -23,6 +23,7 @@
 #include <thread>
 #include <algorithm>
 #include <random>
+#include <map>
 
 using namespace smx;
 
@@ -38,6 +39,8 @@ struct hs_ctx {
   unsigned long long ctr[C_COUNT];
   std::vector<unsigned long long> a0, a1, a2;
   size_t n;
+  std::vector<uint8_t> dirty;                                // strips: 4x4 grid tiles changed since the last halo exchange
+  int own_x0 = 0, own_x1 = -1;
 };
 
 static void rebind(hs_ctx* c) {
@@ -63,6 +66,7 @@ hs_ctx* hs_create(int dimx, int dimy, int scale, uint64_t cap) {
   memset(c->ctr, 0, sizeof(c->ctr));
   size_t nw0 = (c->n + 63) >> 6, nw1 = (nw0 + 63) >> 6, nw2 = (nw1 + 63) >> 6;
   c->a0.assign(nw0 + 64, 0); c->a1.assign(nw1 + 64, 0); c->a2.assign(nw2 + 64, 0);
+  c->dirty.assign((size_t)((dimx + 3) >> 2) * ((dimy + 3) >> 2), 0);
   c->soils.resize(1);
   memset(&c->soils[0], 0, sizeof(SoilP)); c->soils[0].porosity = 1.0f;
   rebind(c);
@@ -327,6 +331,7 @@ void hs_spec_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int
 // ---------------- batched engine (soil_batch.h), emulated: the host driver below mirrors soilmx.hip batch_* ----------
 static int g_batch_dilate = 0;
 static uint32_t g_batch_cell_above = 0xFFFFFFFFu;
+static int g_strips_n = 1, g_strips_a = 16, g_strips_b = 48;
 struct BatchBuffers {
   std::vector<unsigned long long> claim0, claim1;
   std::vector<BWater> water; std::vector<BWind> wind;
@@ -347,6 +352,8 @@ static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) 
   b.bs.water = b.water.data(); b.bs.wind = b.wind.data(); b.bs.live = b.live.data();
   b.bs.children = b.children.data(); b.bs.child_cap = (uint32_t)b.children.size();
   b.bs.dilate = g_batch_dilate; b.bs.maxsteps = 1;
+  b.bs.strips = batch_make_strips(s.dimx, g_strips_n, g_strips_a, g_strips_b); b.bs.sphase = STRIP_INTERIOR;
+  b.bs.dirty = c->dirty.data(); b.bs.own_x0 = c->own_x0; b.bs.own_x1 = c->own_x1 < 0 ? s.dimx : c->own_x1;
   b.bs.freed = b.freed.data(); b.bs.freed_cap = (uint32_t)b.freed.size(); b.bs.ctrl = b.ctrl.data(); b.bs.draws = b.draws.data();
 }
 static void batch_draw(hs_ctx* c, BatchBuffers& b, uint32_t nslots) {   // the next 2*nslots rand() values (host-side generator)
@@ -365,6 +372,7 @@ static void batch_merge_freed(hs_ctx* c, BatchBuffers& b) {
 static uint32_t g_batch_stats[8];
 extern "C" void hs_set_batch_dilate(int d) { g_batch_dilate = d; }
 extern "C" void hs_set_batch_cell_above(uint32_t n) { g_batch_cell_above = n; }
+extern "C" void hs_set_batch_strips(int n, int a, int b) { g_strips_n = n; g_strips_a = a; g_strips_b = b; }
 // runs generations until no particle and no child is left; `kids` = children to start from (grid pass), else top-level
 static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n, std::vector<BChild> kids, int nthreads, unsigned shuffle) {
   const DevState& s = c->d;
@@ -380,14 +388,18 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       sim.flush_counters(); pol.finish(s);
     }, shuffle ? shuffle + 7 : 0);
     for (uint32_t i = 0; i < nslots; i++) b.live[i] = i;
-    uint32_t nlive = nslots, epoch = 0;
+    uint32_t nlive = nslots, epoch = 0, chunk = 0;
     while (nlive > 0) {
       BSched sc = batch_schedule(wind, nlive, g_batch_dilate, g_batch_cell_above);
       if (const char* e = getenv("HS_SCHED")) { int a, d, k; if (sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; } }   // exploration only
+      const bool strips = b.bs.strips.n > 1;
       const bool regrain = sc.tshift != b.bs.tshift;         // first chunk, or the claim granularity changes
       batch_apply_schedule(b.bs, s, sc);
-      if (regrain) {
-        std::fill(b.claim0.begin(), b.claim0.end(), 0ull); std::fill(b.claim1.begin(), b.claim1.end(), 0ull);
+      b.bs.sphase = strips ? (int)(chunk & 1u) : STRIP_INTERIOR;   // column strips: INTERIOR and SEAM chunks alternate
+      if (strips && chunk > 0) epoch++;                      // (reservations of the previous chunk must not look current)
+      chunk++;
+      if (regrain || strips) {                               // under strips every chunk starts with fresh reservations: eligibility changed
+        if (regrain) { std::fill(b.claim0.begin(), b.claim0.end(), 0ull); std::fill(b.claim1.begin(), b.claim1.end(), 0ull); }
         parallel_for(nlive, nthreads, [&](uint32_t i) {
           BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
           if (wind) batch_wind_reclaim(sim, bs, bs.live[i], epoch); else batch_water_reclaim(sim, bs, bs.live[i], epoch);
@@ -403,7 +415,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       }
       batch_merge_freed(c, b);
       uint32_t m = 0;
-      for (uint32_t i = 0; i < nslots; i++) if ((wind ? b.wind[i].state : b.water[i].state) != B_DONE) b.live[m++] = i;
+      for (uint32_t i = 0; i < nslots; i++) { const uint32_t st_ = wind ? b.wind[i].state : b.water[i].state; if (st_ != B_DONE && st_ != B_AWAY) b.live[m++] = i; }
       nlive = m;
       g_batch_stats[0] += 16;
     }
@@ -440,13 +452,17 @@ void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
   const BatchShared& bs = b.bs;
   const uint32_t ntx = (uint32_t)((s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), nty = (uint32_t)((s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
   unsigned long long visited = 0;
+  b.bs.tshift = GRID_SHIFT;
+  for (int ph = 0; ph < (b.bs.strips.n > 1 ? 2 : 1); ph++)
   for (uint32_t col = 0; col < 9; col++) {
+    b.bs.sphase = ph;
     const uint32_t cx = col / 3, cy = col % 3;
     const uint32_t mx = (ntx + 2 - cx) / 3, my = (nty + 2 - cy) / 3;   // tiles tx = cx + 3*i < ntx
     std::vector<unsigned long long> vis((size_t)mx * my, 0);
     parallel_for(mx * my, nthreads, [&](uint32_t i) {
       const uint32_t tx = cx + 3 * (i / my), ty = cy + 3 * (i % my);
       if (tx >= ntx || ty >= nty) return;
+      if (!batch_grid_tile_phase(s, bs, (int)tx)) return;
       BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
       Frame st[MAX_FRAMES];
       vis[i] = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * ntx * nty + (unsigned long long)tx * nty + ty, st);
@@ -468,4 +484,196 @@ void hs_batched_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, 
   if (dowater) hs_freq(c);
 }
 void hs_batch_stats(uint32_t* out) { for (int i = 0; i < 8; i++) { out[i] = g_batch_stats[i]; g_batch_stats[i] = 0; } }
+}  // extern "C"
+
+// ---------------- column strips on several contexts (soilmachine_amd/strips.py drives this step by step) ----------------
+// One hs_ctx per strip, each holding the FULL-size map but keeping only its strip + right halo current. The same
+// step-wise entry points exist in libsoilmx (smx_d_*): generation begin / spawn / chunk / generation end, halo columns
+// and migrating particles packed into byte buffers that the driver moves between contexts (in-process, gloo or RCCL).
+struct DPhase { BatchBuffers b; bool wind = false, first = true; uint32_t nslots = 0, epoch = 0, chunk = 0; std::vector<BChild> kids; };
+static std::map<hs_ctx*, DPhase*> g_dp;
+static DPhase& dp_of(hs_ctx* c) { DPhase*& p = g_dp[c]; if (!p) p = new DPhase(); return *p; }
+extern "C" {
+void hs_d_set_own(hs_ctx* c, int x0, int x1) { c->own_x0 = x0; c->own_x1 = x1; }
+// generation begin: the generation's draws (identical on every context) + the children list; contains_out[i] = what this
+// context can say about child i's `contains` (0xFFFFFFFF if the random cell is not in its strip)
+void hs_d_gen_begin(hs_ctx* c, int wind, uint32_t nslots, const BChild* kids, uint32_t* contains_out) {
+  DPhase& d = dp_of(c);
+  d.wind = wind != 0; d.first = kids == nullptr; d.nslots = nslots; d.epoch = 0; d.chunk = 0;
+  d.kids.assign(kids ? kids : nullptr, kids ? kids + nslots : nullptr);
+  batch_setup(c, d.b, nslots, d.wind);
+  batch_draw(c, d.b, nslots);
+  d.b.ctrl[BC_NCHILD] = 0; d.b.ctrl[BC_CHILD_LOST] = 0;
+  if (kids && contains_out) for (uint32_t i = 0; i < nslots; i++) contains_out[i] = batch_child_contains(c->d, c->d.soils, d.b.bs, i);
+}
+void hs_d_gen_spawn(hs_ctx* c, const uint32_t* contains, uint32_t* nlive_local) {
+  DPhase& d = dp_of(c); const DevState& s = c->d; const BatchShared& bs = d.b.bs;
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < d.nslots; i++) {
+    BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+    if (d.wind) batch_wind_spawn(sim, bs, i); else batch_water_spawn(sim, bs, i, d.first ? nullptr : &d.kids[i], d.first ? nullptr : contains);
+    const uint32_t st = d.wind ? d.b.wind[i].state : d.b.water[i].state;
+    if (st != B_DONE && st != B_AWAY) d.b.live[m++] = i;
+  }
+  *nlive_local = m;
+}
+int hs_d_next_phase(hs_ctx* c) { DPhase& d = dp_of(c); return d.b.bs.strips.n > 1 ? (int)(d.chunk & 1u) : STRIP_INTERIOR; }
+// one chunk of 16 epochs; the schedule follows the GLOBAL number of running particles
+void hs_d_chunk(hs_ctx* c, uint32_t nlive_global, uint32_t* nlive_local) {
+  DPhase& d = dp_of(c); const DevState& s = c->d; BatchBuffers& b = d.b; const BatchShared& bs = b.bs;
+  uint32_t nlive = 0;                                        // residents that run: rebuild the list (particles may have arrived / left)
+  for (uint32_t i = 0; i < d.nslots; i++) { const uint32_t st = d.wind ? b.wind[i].state : b.water[i].state; if (st != B_DONE && st != B_AWAY) b.live[nlive++] = i; }
+  const BSched sc = batch_schedule(d.wind, nlive_global, g_batch_dilate, g_batch_cell_above);
+  const bool strips = b.bs.strips.n > 1, regrain = sc.tshift != b.bs.tshift;
+  batch_apply_schedule(b.bs, s, sc);
+  b.bs.sphase = strips ? (int)(d.chunk & 1u) : STRIP_INTERIOR;
+  if (strips && d.chunk > 0) d.epoch++;
+  d.chunk++;
+  if (regrain) { std::fill(b.claim0.begin(), b.claim0.end(), 0ull); std::fill(b.claim1.begin(), b.claim1.end(), 0ull); }
+  if (regrain || strips)
+    for (uint32_t i = 0; i < nlive; i++) {
+      BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+      if (d.wind) batch_wind_reclaim(sim, bs, bs.live[i], d.epoch); else batch_water_reclaim(sim, bs, bs.live[i], d.epoch);
+    }
+  for (int k = 0; k < 16; k++, d.epoch++)
+    for (uint32_t i = 0; i < nlive; i++) {
+      BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+      Frame st[MAX_FRAMES];
+      if (d.wind) batch_wind_epoch(sim, bs, bs.live[i], d.epoch); else batch_water_epoch(sim, bs, bs.live[i], d.epoch, st);
+      sim.flush_counters(); pol.finish(s);
+    }
+  batch_merge_freed(c, b);
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < d.nslots; i++) { const uint32_t st = d.wind ? b.wind[i].state : b.water[i].state; if (st != B_DONE && st != B_AWAY) m++; }
+  *nlive_local = m;
+}
+void hs_d_gen_end(hs_ctx* c, BChild* out, uint32_t cap, uint32_t* n) {
+  DPhase& d = dp_of(c); const DevState& s = c->d;
+  { unsigned long long acc[4] = {0, 0, 0, 0}; for (uint32_t i = 0; i < d.nslots; i++) batch_slot_counters(d.b.bs, d.wind, i, acc); batch_commit_counters(s, d.wind, acc); }
+  uint32_t nc = d.b.ctrl[BC_NCHILD]; if (nc > d.b.bs.child_cap) nc = d.b.bs.child_cap; if (nc > cap) nc = cap;
+  for (uint32_t i = 0; i < nc; i++) out[i] = d.b.children[i];
+  *n = nc;
+  d.b.ctrl[BC_NCHILD] = 0;
+}
+// halo columns: every column of the DIRTY 4x4 grid tiles inside x in [x0, x1) -> [u32 nrec][u32 data bytes][u32 offs[nrec]][records],
+// record = {u32 cell, u32 count, f32 wtrack, f32 windfreq, u32 flags, u32 pad, count x {f64 size, floor, sat; u32 type, pad}} bottom -> top
+uint64_t hs_d_pack_columns(hs_ctx* c, int x0, int x1, uint8_t* buf, uint64_t cap) {
+  const DevState& s = c->d;
+  const int gty = (s.dimy + 3) >> 2;
+  std::vector<uint32_t> offs; std::vector<uint8_t> data;
+  for (int gx = x0 >> 2; gx < ((x1 + 3) >> 2); gx++)
+    for (int gy = 0; gy < gty; gy++) {
+      uint8_t& dflag = c->dirty[(size_t)gx * gty + gy];
+      if (!dflag) continue;
+      dflag = 0;
+      for (int x = gx << 2; x < (gx << 2) + 4 && x < s.dimx; x++)
+        for (int y = gy << 2; y < (gy << 2) + 4 && y < s.dimy; y++) {
+          const size_t cc = (size_t)x * s.dimy + y, fi = (size_t)y * s.dimx + x;
+          std::vector<const Sec*> col;
+          if (c->cells[cc].type != EMPTY) { const Sec* t = &c->cells[cc]; while (true) { col.push_back(t); if (t->prev == NIL) break; t = &c->pool[t->prev]; } }
+          offs.push_back((uint32_t)data.size());
+          const uint32_t hdr[6] = {(uint32_t)cc, (uint32_t)col.size(), 0, 0, c->flags[cc], 0};
+          size_t o = data.size(); data.resize(o + 24 + 32 * col.size());
+          memcpy(&data[o], hdr, 24); memcpy(&data[o + 8], &c->wtrack[fi], 4); memcpy(&data[o + 12], &c->windfreq[fi], 4);
+          for (size_t k = col.size(); k-- > 0;) { uint8_t* r = &data[o + 24 + 32 * (col.size() - 1 - k)]; memcpy(r, &col[k]->size, 8); memcpy(r + 8, &col[k]->floor, 8); memcpy(r + 16, &col[k]->sat, 8); memcpy(r + 24, &col[k]->type, 4); memset(r + 28, 0, 4); }
+        }
+    }
+  const uint64_t total = 8 + 4 * offs.size() + data.size();
+  if (total > cap) return ~0ull;
+  const uint32_t nrec = (uint32_t)offs.size(), nb = (uint32_t)data.size();
+  memcpy(buf, &nrec, 4); memcpy(buf + 4, &nb, 4);
+  if (nrec) memcpy(buf + 8, offs.data(), 4 * offs.size());
+  if (nb) memcpy(buf + 8 + 4 * offs.size(), data.data(), data.size());
+  return total;
+}
+void hs_d_unpack_columns(hs_ctx* c, const uint8_t* buf, uint64_t bytes) {
+  if (bytes < 8) return;
+  uint32_t nrec, nb; memcpy(&nrec, buf, 4); memcpy(&nb, buf + 4, 4);
+  const uint8_t* data = buf + 8 + 4 * (size_t)nrec;
+  const DevState& s = c->d;
+  for (uint32_t i = 0; i < nrec; i++) {
+    uint32_t off; memcpy(&off, buf + 8 + 4 * (size_t)i, 4);
+    const uint8_t* r = data + off;
+    uint32_t cc, count, flags; memcpy(&cc, r, 4); memcpy(&count, r + 4, 4); memcpy(&flags, r + 16, 4);
+    const size_t x = cc / (size_t)s.dimy, y = cc % (size_t)s.dimy, fi = y * (size_t)s.dimx + x;
+    memcpy(&c->wtrack[fi], r + 8, 4); memcpy(&c->windfreq[fi], r + 12, 4);
+    long long live = 0;                                       // give the old chain back, build the new one
+    if (c->cells[cc].type != EMPTY) { live--; uint32_t pv = c->cells[cc].prev; while (pv != NIL) { const uint32_t nx = c->pool[pv].prev; c->freelist[c->free_count++] = pv; pv = nx; live--; } }
+    Sec cell; cell.size = cell.floor = cell.sat = 0; cell.type = EMPTY; cell.prev = NIL;
+    uint32_t pv = NIL;
+    for (uint32_t k = 0; k < count; k++) {
+      Sec t; const uint8_t* q = r + 24 + 32 * (size_t)k;
+      memcpy(&t.size, q, 8); memcpy(&t.floor, q + 8, 8); memcpy(&t.sat, q + 16, 8); memcpy(&t.type, q + 24, 4); t.prev = pv;
+      if (k + 1 == count) cell = t; else { const uint32_t nd = c->freelist[--c->free_count]; c->pool[nd] = t; pv = nd; }
+      live++;
+    }
+    c->cells[cc] = cell; c->flags[cc] = (uint8_t)flags;
+    c->ctr[C_LIVE_SECTIONS] += (unsigned long long)live;
+  }
+}
+// migrating particles: residents (running) with ipos.x in [x0, x1) -> {u32 slot, record}; they become B_AWAY here
+uint64_t hs_d_pack_particles(hs_ctx* c, int x0, int x1, uint8_t* buf, uint64_t cap) {
+  DPhase& d = dp_of(c);
+  const size_t rs = d.wind ? sizeof(BWind) : sizeof(BWater);
+  uint32_t n = 0; uint64_t o = 4;
+  for (uint32_t i = 0; i < d.nslots; i++) {
+    uint32_t& st = d.wind ? d.b.wind[i].state : d.b.water[i].state;
+    if (st == B_DONE || st == B_AWAY) continue;
+    const int ix = d.wind ? d.b.wind[i].d.ix : d.b.water[i].w.ix;
+    if (ix < x0 || ix >= x1) continue;
+    if (o + 4 + rs > cap) return ~0ull;
+    memcpy(buf + o, &i, 4); memcpy(buf + o + 4, d.wind ? (const void*)&d.b.wind[i] : (const void*)&d.b.water[i], rs);
+    o += 4 + rs; n++;
+    st = B_AWAY;
+  }
+  memcpy(buf, &n, 4);
+  return o;
+}
+void hs_d_unpack_particles(hs_ctx* c, const uint8_t* buf, uint64_t bytes) {
+  DPhase& d = dp_of(c);
+  if (bytes < 4) return;
+  const size_t rs = d.wind ? sizeof(BWind) : sizeof(BWater);
+  uint32_t n; memcpy(&n, buf, 4);
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t i; memcpy(&i, buf + 4 + k * (4 + rs), 4);
+    memcpy(d.wind ? (void*)&d.b.wind[i] : (void*)&d.b.water[i], buf + 8 + k * (4 + rs), rs);
+  }
+}
+// grid pass, strip by strip: classification, then one sweep (9 colours) over the tiles tx in [tx_lo, tx_hi) that belong to `phase`
+void hs_d_grid_begin(hs_ctx* c) {
+  const DevState& s = c->d; const size_t n = c->n;
+  std::fill(c->a0.begin(), c->a0.end(), 0);
+  for (size_t cc = 0; cc < n; cc++) {
+    const int x = (int)(cc / s.dimy), y = (int)(cc % s.dimy);
+    bool act = (s.flags[cc] & F_SAT) != 0;
+    for (int dx = -1; dx <= 1 && !act; dx++) for (int dy = -1; dy <= 1; dy++) {
+      int nx = x + dx, ny = y + dy; if (nx < 0 || ny < 0 || nx >= s.dimx || ny >= s.dimy) continue;
+      if (s.flags[(size_t)nx * s.dimy + ny] & F_AIR) { act = true; break; }
+    }
+    if (act) c->a0[cc >> 6] |= 1ull << (cc & 63);
+  }
+  DPhase& d = dp_of(c);
+  d.wind = false; d.nslots = 0; d.first = true;
+  batch_setup(c, d.b, 0, false);
+  d.b.ctrl[BC_NCHILD] = 0;
+}
+void hs_d_grid_sweep(hs_ctx* c, int phase, int tx_lo, int tx_hi) {
+  DPhase& d = dp_of(c); const DevState& s = c->d; BatchBuffers& b = d.b; const BatchShared& bs = b.bs;
+  const int ntx = (s.dimx + 3) >> 2, nty = (s.dimy + 3) >> 2;
+  b.bs.tshift = GRID_SHIFT; b.bs.sphase = phase;
+  unsigned long long visited = 0;
+  for (int col = 0; col < 9; col++) {
+    for (int tx = col / 3; tx < ntx; tx += 3) {
+      if (tx < tx_lo || tx >= tx_hi || !batch_grid_tile_phase(s, bs, tx)) continue;
+      for (int ty = col % 3; ty < nty; ty += 3) {
+        BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+        Frame st[MAX_FRAMES];
+        visited += batch_grid_tile(sim, tx, ty, (unsigned long long)col * ntx * nty + (unsigned long long)tx * nty + ty, st);
+        sim.flush_counters(); pol.finish(s);
+      }
+    }
+    batch_merge_freed(c, b);
+  }
+  c->ctr[C_GRID_ACTIVE] += visited;
+}
 }  // extern "C"

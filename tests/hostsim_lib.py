@@ -53,6 +53,19 @@ def lib():
         L.hs_batched_grid.argtypes = [vp, C.c_int, C.c_uint]
         L.hs_batched_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
         L.hs_batch_stats.argtypes = [vp]
+        L.hs_set_batch_strips.argtypes = [C.c_int] * 3
+        L.hs_d_set_own.argtypes = [vp, C.c_int, C.c_int]
+        L.hs_d_gen_begin.argtypes = [vp, C.c_int, C.c_uint32, vp, vp]
+        L.hs_d_gen_spawn.argtypes = [vp, vp, vp]
+        L.hs_d_next_phase.argtypes = [vp]
+        L.hs_d_chunk.argtypes = [vp, C.c_uint32, vp]
+        L.hs_d_gen_end.argtypes = [vp, vp, C.c_uint32, vp]
+        for f in ("hs_d_pack_columns", "hs_d_pack_particles"):
+            getattr(L, f).argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]; getattr(L, f).restype = C.c_uint64
+        for f in ("hs_d_unpack_columns", "hs_d_unpack_particles"):
+            getattr(L, f).argtypes = [vp, vp, C.c_uint64]
+        L.hs_d_grid_begin.argtypes = [vp]
+        L.hs_d_grid_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -128,3 +141,63 @@ class HostSim:
         st = np.zeros(12, np.uint32)
         self.L.hs_spec_tick(self.h, nwater, nwind, int(dowater), int(dowind), nthreads, scout, shuffle, _p(st))
         return st
+
+
+class HostSimStripBackend:
+    """soilmachine_amd.strips backend on the host-sim (one HostSim = one strip's context)."""
+
+    def __init__(self, hs: HostSim):
+        self.hs, self.L, self.h = hs, hs.L, hs.h
+        self._buf = np.zeros(1 << 24, np.uint8)
+
+    def set_strips(self, n, a, b): self.L.hs_set_batch_strips(n, a, b)     # (process-global in the host-sim)
+    def set_own(self, x0, x1): self.L.hs_d_set_own(self.h, x0, x1)
+
+    def gen_begin(self, wind, nslots, kids):
+        from soilmachine_amd.strips import CHILD_DT
+        if kids is None:
+            self.L.hs_d_gen_begin(self.h, int(wind), nslots, None, None)
+            return None
+        kids = np.ascontiguousarray(kids, dtype=CHILD_DT)
+        out = np.zeros(nslots, np.uint32)
+        self.L.hs_d_gen_begin(self.h, int(wind), nslots, _p(kids), _p(out))
+        return out
+
+    def gen_spawn(self, contains):
+        n = C.c_uint32()
+        c = None if contains is None else np.ascontiguousarray(contains, np.uint32)
+        self.L.hs_d_gen_spawn(self.h, None if c is None else _p(c), C.byref(n))
+        return int(n.value)
+
+    def next_phase(self): return int(self.L.hs_d_next_phase(self.h))
+
+    def chunk(self, nlive_global):
+        n = C.c_uint32()
+        self.L.hs_d_chunk(self.h, nlive_global, C.byref(n))
+        return int(n.value)
+
+    def gen_end(self):
+        from soilmachine_amd.strips import CHILD_DT
+        out = np.zeros(1 << 16, CHILD_DT); n = C.c_uint32()
+        self.L.hs_d_gen_end(self.h, _p(out), len(out), C.byref(n))
+        return out[:int(n.value)].copy()
+
+    def _pack(self, fn, x0, x1):
+        k = int(fn(self.h, x0, x1, _p(self._buf), self._buf.size))
+        if k == 2**64 - 1:
+            raise RuntimeError("strip pack buffer too small")
+        return self._buf[:k].tobytes()
+
+    def pack_columns(self, x0, x1): return self._pack(self.L.hs_d_pack_columns, x0, x1)
+    def pack_particles(self, x0, x1): return self._pack(self.L.hs_d_pack_particles, x0, x1)
+
+    def unpack_columns(self, b):
+        a = np.frombuffer(b, np.uint8); self.L.hs_d_unpack_columns(self.h, _p(a), len(b))
+
+    def unpack_particles(self, b):
+        a = np.frombuffer(b, np.uint8); self.L.hs_d_unpack_particles(self.h, _p(a), len(b))
+
+    def grid_begin(self): self.L.hs_d_grid_begin(self.h)
+    def grid_sweep(self, phase, lo, hi): self.L.hs_d_grid_sweep(self.h, phase, lo, hi)
+    def map_frequency(self): self.L.hs_freq(self.h)
+    def reset_frequency(self): pass                                       # (hs_freq does both)
