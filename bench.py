@@ -22,8 +22,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
   * "cpu_baseline": the reference's own CPU loop (oracle/_ref/soil_ref_lean = the unmodified reference headers,
     render-only Layermap::update elided) timed on this box's host: 1 core on a bounded sample of the headline
     workload, and an all-cores line (independent processes, different SEEDs -- the reference has no threads).
-  * N > 1: one process per GPU. The exact semantics do not shard; the batched engine shards the map into column strips
-    (soilmachine_amd/strips.py) -- until that path is selected the ranks run independent replicas (SEED = rank).
+  * N > 1: one process per GPU. The batched engine (default) shards the ONE map into N column strips
+    (soilmachine_amd/strips.py: halo columns + migrating particles point to point over RCCL, live count by all-reduce;
+    same total work at every N: "scaling": "strong"). The exact engines do not shard (sequential semantics): with
+    --engine spec/serial the ranks run independent replicas (SEED = rank, "weak").
 """
 from __future__ import annotations
 
@@ -154,6 +156,38 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
     return r
 
 
+def measure_strips(cfg, n, nwater, nwind, pool, device, steps, warmup, dist, barrier, torch):
+    """ONE map sharded into world-size column strips (soilmachine_amd/strips.py): every rank holds a context with the
+    full-size map, initialises the terrain itself and keeps its strip + halo current; halo columns and migrating
+    particles travel point to point over RCCL (backend nccl), the live-particle count by all-reduce."""
+    from soilmachine_amd import capi
+    from soilmachine_amd.machine import Layermap
+    from soilmachine_amd.strips import DeviceStripBackend, StripGeometry, StripRank, TorchComm
+    world = dist.get_world_size()
+    m = Layermap(cfg, n, n, seed=0, pool=pool, device=device, engine=capi.ENGINE_BATCHED)
+    dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
+    rk = StripRank(DeviceStripBackend(m, buf_mb=256), TorchComm(dist, dev if dist.get_backend() == "nccl" else None), StripGeometry(n, world))
+    for _ in range(warmup):
+        rk.tick(nwater, nwind, True, nwind > 0)
+    m.sync()
+    c0, b0 = m.counters(), m.batch_stats()
+    m.timing_reset()
+    barrier(m)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rk.tick(nwater, nwind, True, nwind > 0)
+    barrier(m)
+    dt = time.perf_counter() - t0
+    c1, tm, b1 = m.counters(), m.timing(), m.batch_stats()
+    r = {"dt": dt, "steps_w": c1["steps_water_all"] - c0["steps_water_all"], "steps_d": c1["steps_wind"] - c0["steps_wind"], "tm": tm,
+         "digest": {"note": "strips: each rank holds its own strip; no global digest in the timed run"},
+         "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"],
+         "nested": c1["nested_particles"] - c0["nested_particles"], "floods": c1["floods"] - c0["floods"], "pool_overflow": c1["pool_overflow"],
+         "engine_stats": dict({k: b1[k] - b0[k] for k in b1}, strip_stats=rk.stats, bytes_sent=rk.comm.bytes_sent, messages=rk.comm.messages)}
+    m.close()
+    return r
+
+
 def line_of(r, name, workload, engine_name, steps):
     dt, tm = r["dt"], r["tm"]
     tot = r["steps_w"] + r["steps_d"]
@@ -190,6 +224,8 @@ def main():
     from soilmachine_amd import distrib
     rank, local_rank, world = distrib.env_rank()
     dist = distrib.init(world, local_rank, use_cuda=torch.cuda.is_available())
+    if torch.cuda.is_available():
+        local_rank %= max(torch.cuda.device_count(), 1)          # (several ranks may share a device when SMX_DIST_BACKEND=gloo)
 
     from soilmachine_amd import capi
     from soilmachine_amd.soilfile import loadsoil
@@ -216,9 +252,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier)
+    strips = world > 1 and eng_name == "batched"
+    if strips:
+        r = measure_strips(cfg, n, nwater, nwind, pool, local_rank, args.steps, args.warmup, dist, barrier, torch)
+    else:
+        r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier)
     steps = r["steps_w"] + r["steps_d"]
-    dev = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
+    dev = torch.device("cuda", local_rank) if (torch.cuda.is_available() and (dist is None or dist.get_backend() == "nccl")) else torch.device("cpu")
     tmax, total_steps = distrib.aggregate(dist, r["dt"], steps, dev)
 
     if rank == 0:
@@ -294,8 +334,9 @@ def main():
         out = {
             "metric": "particle-steps/s", "value": total_steps / tmax, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "engine": eng_name, "parallelism": "replicas" if world > 1 else "single",
+            "scaling": "strong" if strips else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "engine": eng_name,
+                       "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
                        "parity": head["parity"]},
             "value_top_level": head["value_top_level"] if world == 1 else None,
             "steps_definition": "value: move()==true + interact(), top-level AND nested particles; value_top_level: top-level only "

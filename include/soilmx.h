@@ -155,6 +155,29 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles);
  * +-seam_halfwidth cells around a strip boundary). nstrips == 1 (default) = the single-strip schedule. The result is a
  * function of (nstrips, inset, seam_halfwidth) only -- not of how many devices run the strips. */
 int smx_set_batch_strips(smx_ctx* ctx, int32_t nstrips, int32_t inset, int32_t seam_halfwidth);
+/* ---- column strips on SEVERAL devices, step by step (driver: soilmachine_amd/strips.py; one context per strip, each with
+ * the full-size map of which it keeps its strip + right halo current). A generation of a particle phase:
+ *   smx_d_gen_begin   draws the generation's rand() values (identical on every rank) and, for nested particles
+ *                     (`children` = BChild records: u64 key, i32 tx,ty,bx,by,spill,pad, f64 volume), answers what this rank
+ *                     knows about each child's `contains` (0xFFFFFFFF = random cell not in my strip; ranks combine by min)
+ *   smx_d_gen_spawn   constructs the particles; those outside [own_x0, own_x1) live on another rank
+ *   smx_d_chunk       16 epochs; the schedule follows the GLOBAL number of running particles; chunks alternate INTERIOR /
+ *                     SEAM (smx_d_next_phase tells which comes next: 0 interior, 1 seam)
+ *   smx_d_gen_end     counters + this rank's newly spawned children
+ * smx_d_pack_columns / _particles serialise the changed halo columns (dirty 4x4 tiles with x in [x0,x1)) and the running
+ * particles with ipos.x in [x0,x1) (they leave this rank) into a caller-provided host buffer; _unpack_ applies them. */
+int smx_d_set_own(smx_ctx* ctx, int32_t own_x0, int32_t own_x1);
+int smx_d_gen_begin(smx_ctx* ctx, int32_t wind, uint32_t nslots, const void* children, uint32_t* contains_out);
+int smx_d_gen_spawn(smx_ctx* ctx, const uint32_t* contains, uint32_t* nlive_local);
+int smx_d_next_phase(smx_ctx* ctx);
+int smx_d_chunk(smx_ctx* ctx, uint32_t nlive_global, uint32_t* nlive_local);
+int smx_d_gen_end(smx_ctx* ctx, void* children_out, uint32_t cap, uint32_t* n);
+int smx_d_pack_columns(smx_ctx* ctx, int32_t x0, int32_t x1, void* buf, uint64_t cap, uint64_t* bytes);
+int smx_d_unpack_columns(smx_ctx* ctx, const void* buf, uint64_t bytes);
+int smx_d_pack_particles(smx_ctx* ctx, int32_t x0, int32_t x1, void* buf, uint64_t cap, uint64_t* bytes);
+int smx_d_unpack_particles(smx_ctx* ctx, const void* buf, uint64_t bytes);
+int smx_d_grid_begin(smx_ctx* ctx);                                            /* classification of the grid pass       */
+int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t tx_lo, int32_t tx_hi); /* nine colours over this rank's 4x4 tiles */
 /* batched engine: epochs (kernel rounds), generations and dropped child particles since the context was created */
 int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost);
 void* smx_stream(smx_ctx* ctx);                          /* the hipStream_t all work is queued on */

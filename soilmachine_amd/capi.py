@@ -56,6 +56,8 @@ SYMBOLS = [
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
     "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices",
     "smx_digest", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips",
+    "smx_d_set_own", "smx_d_gen_begin", "smx_d_gen_spawn", "smx_d_next_phase", "smx_d_chunk", "smx_d_gen_end", "smx_d_pack_columns",
+    "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep",
 ]
 
 _lib = None
@@ -110,6 +112,18 @@ def load() -> C.CDLL:
     L.smx_set_engine.argtypes = [vp, i32]
     L.smx_set_batch_dilate.argtypes = [vp, i32]
     L.smx_set_batch_strips.argtypes = [vp, i32, i32, i32]
+    L.smx_d_set_own.argtypes = [vp, i32, i32]
+    L.smx_d_gen_begin.argtypes = [vp, i32, u32, vp, vp]
+    L.smx_d_gen_spawn.argtypes = [vp, vp, C.POINTER(u32)]
+    L.smx_d_next_phase.argtypes = [vp]
+    L.smx_d_chunk.argtypes = [vp, u32, C.POINTER(u32)]
+    L.smx_d_gen_end.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    L.smx_d_pack_columns.argtypes = [vp, i32, i32, vp, u64, C.POINTER(u64)]
+    L.smx_d_unpack_columns.argtypes = [vp, vp, u64]
+    L.smx_d_pack_particles.argtypes = [vp, i32, i32, vp, u64, C.POINTER(u64)]
+    L.smx_d_unpack_particles.argtypes = [vp, vp, u64]
+    L.smx_d_grid_begin.argtypes = [vp]
+    L.smx_d_grid_sweep.argtypes = [vp, i32, i32, i32]
     L.smx_get_batch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.smx_stream.argtypes = [vp]; L.smx_stream.restype = vp
     for name in SYMBOLS:

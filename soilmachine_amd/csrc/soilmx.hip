@@ -250,13 +250,13 @@ __global__ void __launch_bounds__(256) k_spec_end(DevState s, SpecShared sh, uin
 // One particle per LANE. 64-thread workgroups: a phase has 10^3..10^6 particles and the chip has 1024 SIMDs, so
 // single-wave workgroups spread the waves evenly over CUs and XCDs (workgroups go round-robin over the XCDs).
 template <bool WIND>
-__global__ void __launch_bounds__(64) k_batch_spawn(DevState s, BatchShared bs, uint32_t nslots, const BChild* kids) {
+__global__ void __launch_bounds__(64) k_batch_spawn(DevState s, BatchShared bs, uint32_t nslots, const BChild* kids, const uint32_t* contains) {
   SMX_LOAD_SOILS(sh)
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   if (i >= nslots) return;
   BatchPolicy pol(s, bs);
   Sim<BatchPolicy> sim(s, sh, pol);
-  if constexpr (WIND) batch_wind_spawn(sim, bs, i); else batch_water_spawn(sim, bs, i, kids ? kids + i : nullptr);
+  if constexpr (WIND) batch_wind_spawn(sim, bs, i); else batch_water_spawn(sim, bs, i, kids ? kids + i : nullptr, kids ? contains : nullptr);
   sim.flush_counters(); pol.finish(s);
 }
 template <bool WIND>
@@ -336,6 +336,125 @@ __global__ void __launch_bounds__(64) k_batch_grid(DevState s, BatchShared bs, u
 __global__ void k_batch_grid_finish(DevState s, unsigned long long visited0) {   // counter parity: every other cell "calls" cascade once
   const unsigned long long n = (unsigned long long)s.dimx * s.dimy, v = s.ctr[C_GRID_ACTIVE] - visited0;
   s.ctr[C_WCASCADE_CALLS] += n - v;
+}
+
+// ---------------- column strips on several devices: halo columns, migrating particles (driver: soilmachine_amd/strips.py) ----------------
+__global__ void __launch_bounds__(64) k_batch_child_contains(DevState s, BatchShared bs, uint32_t nslots, uint32_t* out) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i < nslots) out[i] = batch_child_contains(s, s.soils, bs, i);
+}
+struct XCursor { unsigned long long bytes; uint32_t nrec, lost; };
+// every column of the DIRTY 4x4 grid tiles whose x lies in [gx0, gx1) tiles: one thread per tile walks its 16 columns twice
+// (size, then content); space comes from two atomic cursors, so records land in any order (they are independent)
+__global__ void __launch_bounds__(64) k_strip_pack_columns(DevState s, BatchShared bs, int gx0, int gx1, uint8_t* data, unsigned long long cap,
+                                                            uint32_t* offs, uint32_t offs_cap, XCursor* cur) {
+  const int gty = (s.dimy + 3) >> 2;
+  const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (t >= (long long)(gx1 - gx0) * gty) return;
+  const int gx = gx0 + (int)(t / gty), gy = (int)(t % gty);
+  uint8_t& dflag = bs.dirty[(size_t)gx * gty + gy];
+  if (!dflag) return;
+  dflag = 0;
+  uint32_t ncol = 0; unsigned long long need = 0;
+  for (int x = gx << 2; x < (gx << 2) + 4 && x < s.dimx; x++)
+    for (int y = gy << 2; y < (gy << 2) + 4 && y < s.dimy; y++) {
+      const Sec& c = s.cells[(size_t)x * s.dimy + y];
+      uint32_t k = 0;
+      if (c.type != EMPTY) { k = 1; for (uint32_t pv = c.prev; pv != NIL; pv = s.pool[pv].prev) k++; }
+      need += 24ull + 32ull * k; ncol++;
+    }
+  const unsigned long long base = atomicAdd(&cur->bytes, need);
+  const uint32_t rbase = atomicAdd(&cur->nrec, ncol);
+  if (base + need > cap || rbase + ncol > offs_cap) { atomicAdd(&cur->lost, 1u); return; }
+  unsigned long long o = base; uint32_t r = rbase;
+  for (int x = gx << 2; x < (gx << 2) + 4 && x < s.dimx; x++)
+    for (int y = gy << 2; y < (gy << 2) + 4 && y < s.dimy; y++) {
+      const size_t cc = (size_t)x * s.dimy + y, fi = (size_t)y * s.dimx + x;
+      const Sec& c = s.cells[cc];
+      uint32_t k = 0;
+      if (c.type != EMPTY) { k = 1; for (uint32_t pv = c.prev; pv != NIL; pv = s.pool[pv].prev) k++; }
+      offs[r++] = (uint32_t)(o - base) + (uint32_t)base;       // (offsets are relative to the start of the data area; < 4 GiB)
+      uint32_t* h = reinterpret_cast<uint32_t*>(data + o);
+      h[0] = (uint32_t)cc; h[1] = k; h[2] = __float_as_uint(s.wtrack[fi]); h[3] = __float_as_uint(s.windfreq[fi]); h[4] = s.flags[cc]; h[5] = 0;
+      // sections bottom -> top: the chain is top -> bottom, so fill from the back
+      const Sec* t2 = &c;
+      for (uint32_t j = k; j-- > 0;) {
+        double* q = reinterpret_cast<double*>(data + o + 24 + 32ull * j);
+        q[0] = t2->size; q[1] = t2->floor; q[2] = t2->sat;
+        reinterpret_cast<uint32_t*>(q + 3)[0] = t2->type; reinterpret_cast<uint32_t*>(q + 3)[1] = 0;
+        if (t2->prev != NIL) t2 = &s.pool[t2->prev];
+      }
+      o += 24ull + 32ull * k;
+    }
+}
+// one thread per received column: give the old chain back (deferred, like every free of a batched kernel), build the new one
+__global__ void __launch_bounds__(64) k_strip_unpack_columns(DevState s, BatchShared bs, const uint8_t* data, const uint32_t* offs, uint32_t nrec) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= nrec) return;
+  const uint8_t* r = data + offs[i];
+  const uint32_t* h = reinterpret_cast<const uint32_t*>(r);
+  const uint32_t cc = h[0], count = h[1];
+  const size_t x = cc / (size_t)s.dimy, y = cc % (size_t)s.dimy, fi = y * (size_t)s.dimx + x;
+  s.wtrack[fi] = __uint_as_float(h[2]); s.windfreq[fi] = __uint_as_float(h[3]);
+  BatchPolicy pol(s, bs);
+  long long live = 0;
+  Sec& c = s.cells[cc];
+  if (c.type != EMPTY) { live--; uint32_t pv = c.prev; while (pv != NIL) { const uint32_t nx = s.pool[pv].prev; pol.node_free(s, pv); pv = nx; live--; } }
+  Sec cell; cell.size = 0.0; cell.floor = 0.0; cell.sat = 0.0; cell.type = EMPTY; cell.prev = NIL;
+  uint32_t pv = NIL;
+  for (uint32_t k = 0; k < count; k++) {
+    const double* q = reinterpret_cast<const double*>(r + 24 + 32ull * k);
+    Sec t; t.size = q[0]; t.floor = q[1]; t.sat = q[2]; t.type = reinterpret_cast<const uint32_t*>(q + 3)[0]; t.prev = pv;
+    if (k + 1 == count) cell = t;
+    else { const uint32_t nd = pol.node_alloc(s); if (nd == NIL) { atomicAdd(&s.ctr[C_POOL_OVERFLOW], 1ull); break; } s.pool[nd] = t; pv = nd; }
+    live++;
+  }
+  c = cell; s.flags[cc] = (uint8_t)h[4];
+  if (live) atomicAdd(&s.ctr[C_LIVE_SECTIONS], (unsigned long long)live);
+}
+template <bool WIND>
+__global__ void __launch_bounds__(256) k_strip_pack_particles(BatchShared bs, uint32_t nslots, int x0, int x1, uint8_t* data, unsigned long long cap, XCursor* cur) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nslots) return;
+  uint32_t& st = WIND ? bs.wind[i].state : bs.water[i].state;
+  if (st == B_DONE || st == B_AWAY) return;
+  const int ix = WIND ? bs.wind[i].d.ix : bs.water[i].w.ix;
+  if (ix < x0 || ix >= x1) return;
+  constexpr unsigned long long rs = 4 + (WIND ? sizeof(BWind) : sizeof(BWater));
+  const uint32_t k = atomicAdd(&cur->nrec, 1u);
+  if ((k + 1ull) * rs > cap) { atomicAdd(&cur->lost, 1u); return; }
+  uint8_t* o = data + k * rs;
+  memcpy(o, &i, 4);
+  if constexpr (WIND) memcpy(o + 4, &bs.wind[i], sizeof(BWind)); else memcpy(o + 4, &bs.water[i], sizeof(BWater));
+  st = B_AWAY;
+}
+template <bool WIND>
+__global__ void __launch_bounds__(256) k_strip_unpack_particles(BatchShared bs, const uint8_t* data, uint32_t n) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= n) return;
+  constexpr unsigned long long rs = 4 + (WIND ? sizeof(BWind) : sizeof(BWater));
+  const uint8_t* o = data + k * rs;
+  uint32_t i; memcpy(&i, o, 4);
+  if constexpr (WIND) memcpy(&bs.wind[i], o + 4, sizeof(BWind)); else memcpy(&bs.water[i], o + 4, sizeof(BWater));
+}
+// grid pass of one strip: like k_batch_grid, restricted to the tiles tx in [tx_lo, tx_hi)
+__global__ void __launch_bounds__(64) k_batch_grid_range(DevState s, BatchShared bs, uint32_t col, uint32_t mx, uint32_t my, int tx_lo, int tx_hi) {
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  unsigned long long vis = 0;
+  if (i < mx * my) {
+    const uint32_t gtx = (uint32_t)((s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), gty = (uint32_t)((s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
+    const uint32_t tx = col / 3u + 3u * (i / my), ty = col % 3u + 3u * (i % my);
+    if (tx < gtx && ty < gty && (int)tx >= tx_lo && (int)tx < tx_hi && batch_grid_tile_phase(s, bs, (int)tx)) {
+      BatchPolicy pol(s, bs);
+      Sim<BatchPolicy> sim(s, sh, pol);
+      Frame st[MAX_FRAMES];
+      vis = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * gtx * gty + (unsigned long long)tx * gty + ty, st);
+      sim.flush_counters(); pol.finish(s);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) vis += (unsigned long long)__shfl_down((long long)vis, off);
+  if (threadIdx.x == 0 && vis) atomicAdd(&s.ctr[C_GRID_ACTIVE], vis);
 }
 
 __global__ void __launch_bounds__(256) k_map_frequency(float* __restrict__ freq, const float* __restrict__ track, size_t n4, size_t n) {
@@ -531,6 +650,11 @@ struct smx_ctx {
   int batch_dilate = 0;
   int strips_n = 1, strips_a = 16, strips_b = 48;
   int own_x0 = 0, own_x1 = -1;        // strips on several devices: the columns this context owns (-1: to the map's edge)
+  // step-wise generation state (smx_d_*)
+  bool d_wind = false, d_first = true; uint32_t d_nslots = 0, d_epoch = 0, d_chunk = 0;
+  uint32_t* d_contains = nullptr; uint32_t contains_cap = 0;
+  uint8_t* d_xdata = nullptr; uint32_t* d_xoffs = nullptr; XCursor* d_xcur = nullptr;
+  unsigned long long xdata_cap = 0; uint32_t xoffs_cap = 0;
   uint64_t batch_epochs = 0, batch_generations = 0, batch_children_lost = 0;
 };
 
@@ -652,7 +776,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1087,8 +1211,8 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
       dk = ctx->d_kids;
     }
     const unsigned nb = (nslots + 63u) / 64u;
-    if (wind) hipLaunchKernelGGL(k_batch_spawn<true>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk);
-    else hipLaunchKernelGGL(k_batch_spawn<false>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk);
+    if (wind) hipLaunchKernelGGL(k_batch_spawn<true>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk, (const uint32_t*)nullptr);
+    else hipLaunchKernelGGL(k_batch_spawn<false>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_batch_iota, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs.live, nslots);
     uint32_t nlive = nslots, epoch = 0, chunk = 0;
     static const int CHUNK = [] { const char* e = getenv("SMX_BATCH_CHUNK"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
@@ -1208,6 +1332,221 @@ static void launch_classify(smx_ctx* ctx) {                  // which cells can 
     hipLaunchKernelGGL(k_grid_classify, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d);
 }
 
+}  // extern "C"
+
+// ---------------- column strips, step by step (the same entry points exist in tests/hostsim as hs_d_*) ----------------
+static int xbuf_alloc(smx_ctx* ctx) {
+  if (ctx->d_xdata) return 0;
+  ctx->xdata_cap = 256ull << 20; ctx->xoffs_cap = 8u << 20;
+  HIPCHK(hipMalloc(&ctx->d_xdata, ctx->xdata_cap)); HIPCHK(hipMalloc(&ctx->d_xoffs, (size_t)ctx->xoffs_cap * 4)); HIPCHK(hipMalloc(&ctx->d_xcur, sizeof(XCursor)));
+  return 0;
+}
+extern "C" {
+int smx_d_set_own(smx_ctx* ctx, int32_t x0, int32_t x1) { ctx->own_x0 = x0; ctx->own_x1 = x1; return 0; }
+int smx_d_gen_begin(smx_ctx* ctx, int32_t wind, uint32_t nslots, const void* kids_host, uint32_t* contains_out) {
+  hipStream_t st = ctx->stream;
+  ctx->d_wind = wind != 0; ctx->d_first = kids_host == nullptr; ctx->d_nslots = nslots; ctx->d_epoch = 0; ctx->d_chunk = 0;
+  if (batch_alloc(ctx, nslots ? nslots : 1, ctx->d_wind)) return -1;
+  RandState r;                                              // every rank holds the same generator state and draws the same values
+  HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (uint32_t i = 0; i < 2u * nslots; i++) {
+    const uint32_t v = r.ring[r.idx % 31] + r.ring[(r.idx - 3) % 31];
+    r.ring[r.idx % 31] = v; r.idx++; r.calls++;
+    ctx->h_draws[i] = v >> 1;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, st));
+  if (nslots) HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
+  ctx->bs.tshift = -1;
+  HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NCHILD, 0, 8, st));
+  if (kids_host) {
+    if (ctx->kids_cap < nslots) { hipFree(ctx->d_kids); ctx->d_kids = nullptr; ctx->kids_cap = 0; HIPCHK(hipMalloc(&ctx->d_kids, (size_t)nslots * sizeof(BChild))); ctx->kids_cap = nslots; }
+    if (ctx->contains_cap < nslots) { hipFree(ctx->d_contains); ctx->d_contains = nullptr; ctx->contains_cap = 0; HIPCHK(hipMalloc(&ctx->d_contains, (size_t)nslots * 4)); ctx->contains_cap = nslots; }
+    HIPCHK(hipMemcpyAsync(ctx->d_kids, kids_host, (size_t)nslots * sizeof(BChild), hipMemcpyHostToDevice, st));
+    if (contains_out) {
+      hipLaunchKernelGGL(k_batch_child_contains, dim3((nslots + 63u) / 64u), dim3(64), 0, st, ctx->d, ctx->bs, nslots, ctx->d_contains);
+      HIPCHK(hipMemcpyAsync(contains_out, ctx->d_contains, (size_t)nslots * 4, hipMemcpyDeviceToHost, st));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+static int d_compact(smx_ctx* ctx, uint32_t* nlive) {
+  hipStream_t st = ctx->stream; const BatchShared& bs = ctx->bs; const uint32_t nslots = ctx->d_nslots;
+  HIPCHK(hipMemsetAsync(bs.ctrl + BC_NLIVE, 0, 4, st));
+  if (nslots) {
+    if (ctx->d_wind) hipLaunchKernelGGL(k_batch_compact<true>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots);
+    else hipLaunchKernelGGL(k_batch_compact<false>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots);
+  }
+  HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *nlive = ctx->h_bctrl[BC_NLIVE];
+  return 0;
+}
+int smx_d_gen_spawn(smx_ctx* ctx, const uint32_t* contains_host, uint32_t* nlive_local) {
+  hipStream_t st = ctx->stream; const uint32_t nslots = ctx->d_nslots;
+  if (nslots == 0) { *nlive_local = 0; return 0; }
+  const BChild* dk = ctx->d_first ? nullptr : ctx->d_kids;
+  if (dk && contains_host) HIPCHK(hipMemcpyAsync(ctx->d_contains, contains_host, (size_t)nslots * 4, hipMemcpyHostToDevice, st));
+  const unsigned nb = (nslots + 63u) / 64u;
+  if (ctx->d_wind) hipLaunchKernelGGL(k_batch_spawn<true>, dim3(nb), dim3(64), 0, st, ctx->d, ctx->bs, nslots, dk, (const uint32_t*)nullptr);
+  else hipLaunchKernelGGL(k_batch_spawn<false>, dim3(nb), dim3(64), 0, st, ctx->d, ctx->bs, nslots, dk, (const uint32_t*)(dk && contains_host ? ctx->d_contains : nullptr));
+  return d_compact(ctx, nlive_local);
+}
+int smx_d_next_phase(smx_ctx* ctx) { return ctx->strips_n > 1 ? (int)(ctx->d_chunk & 1u) : STRIP_INTERIOR; }
+int smx_d_chunk(smx_ctx* ctx, uint32_t nlive_global, uint32_t* nlive_local) {
+  hipStream_t st = ctx->stream; const BatchShared& bs = ctx->bs; const bool wind = ctx->d_wind;
+  uint32_t nlive = 0;
+  if (d_compact(ctx, &nlive)) return -1;                      // residents that run (particles may have arrived or left)
+  const BSched sc = batch_schedule(wind, nlive_global, ctx->batch_dilate);
+  const bool strips = bs.strips.n > 1, regrain = sc.tshift != bs.tshift;
+  batch_apply_schedule(ctx->bs, ctx->d, sc);
+  ctx->bs.sphase = strips ? (int)(ctx->d_chunk & 1u) : STRIP_INTERIOR;
+  if (strips && ctx->d_chunk > 0) ctx->d_epoch++;
+  ctx->d_chunk++;
+  if (regrain) { const size_t nt = (size_t)bs.ntx * bs.nty; HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st)); }
+  if (nlive) {
+    const unsigned nbl = (nlive + 63u) / 64u;
+    if (regrain || strips) {
+      if (wind) hipLaunchKernelGGL(k_batch_reclaim<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch);
+      else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch);
+    }
+    PhaseTimer tk(ctx, wind ? 5 : 4, 16u);
+    for (int k = 0; k < 16; k++) {
+      if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k);
+      else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k);
+    }
+  }
+  ctx->d_epoch += 16;
+  hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
+  ctx->batch_epochs += 16;
+  return d_compact(ctx, nlive_local);
+}
+int smx_d_gen_end(smx_ctx* ctx, void* children_out, uint32_t cap, uint32_t* n) {
+  hipStream_t st = ctx->stream; const BatchShared& bs = ctx->bs; const uint32_t nslots = ctx->d_nslots;
+  if (nslots) {
+    if (ctx->d_wind) hipLaunchKernelGGL(k_batch_counters<true>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
+    else hipLaunchKernelGGL(k_batch_counters<false>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
+  }
+  HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  uint32_t nc = ctx->h_bctrl[BC_NCHILD];
+  if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
+  if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
+  if (nc > bs.child_cap) nc = bs.child_cap;
+  if (nc > cap) { ctx->err = "smx_d_gen_end: children buffer too small"; return -2; }
+  if (nc) HIPCHK(hipMemcpyAsync(children_out, bs.children, (size_t)nc * sizeof(BChild), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *n = nc;
+  ctx->batch_generations++;
+  ctx->d_nslots = 0;
+  return 0;
+}
+// -> [u32 nrec][u32 data bytes][u32 offs[nrec]][records]   (record layout: k_strip_pack_columns)
+int smx_d_pack_columns(smx_ctx* ctx, int32_t x0, int32_t x1, void* host_buf, uint64_t cap, uint64_t* bytes) {
+  hipStream_t st = ctx->stream;
+  if (batch_alloc(ctx, 1, false) || xbuf_alloc(ctx)) return -1;
+  if (x0 < 0) x0 = 0; if (x1 > ctx->cfg.dimx) x1 = ctx->cfg.dimx;
+  const int gx0 = x0 >> 2, gx1 = (x1 + 3) >> 2, gty = (ctx->cfg.dimy + 3) >> 2;
+  HIPCHK(hipMemsetAsync(ctx->d_xcur, 0, sizeof(XCursor), st));
+  const long long nt = (long long)(gx1 - gx0) * gty;
+  if (nt > 0) hipLaunchKernelGGL(k_strip_pack_columns, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, st, ctx->d, ctx->bs, gx0, gx1, ctx->d_xdata, ctx->xdata_cap, ctx->d_xoffs, ctx->xoffs_cap, ctx->d_xcur);
+  XCursor c;
+  HIPCHK(hipMemcpyAsync(&c, ctx->d_xcur, sizeof(c), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (c.lost) { ctx->err = "smx_d_pack_columns: exchange buffer too small"; return -2; }
+  const uint64_t total = 8 + 4ull * c.nrec + c.bytes;
+  if (total > cap) { ctx->err = "smx_d_pack_columns: host buffer too small"; return -2; }
+  uint8_t* hb = (uint8_t*)host_buf;
+  const uint32_t nb = (uint32_t)c.bytes;
+  memcpy(hb, &c.nrec, 4); memcpy(hb + 4, &nb, 4);
+  if (c.nrec) HIPCHK(hipMemcpyAsync(hb + 8, ctx->d_xoffs, 4ull * c.nrec, hipMemcpyDeviceToHost, st));
+  if (c.bytes) HIPCHK(hipMemcpyAsync(hb + 8 + 4ull * c.nrec, ctx->d_xdata, c.bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *bytes = total;
+  return 0;
+}
+int smx_d_unpack_columns(smx_ctx* ctx, const void* host_buf, uint64_t bytes) {
+  hipStream_t st = ctx->stream;
+  if (bytes < 8) return 0;
+  if (batch_alloc(ctx, 1, false) || xbuf_alloc(ctx)) return -1;
+  const uint8_t* hb = (const uint8_t*)host_buf;
+  uint32_t nrec, nb; memcpy(&nrec, hb, 4); memcpy(&nb, hb + 4, 4);
+  if (nrec == 0) return 0;
+  if (nrec > ctx->xoffs_cap || nb > ctx->xdata_cap || 8 + 4ull * nrec + nb > bytes) { ctx->err = "smx_d_unpack_columns: bad buffer"; return -2; }
+  HIPCHK(hipMemcpyAsync(ctx->d_xoffs, hb + 8, 4ull * nrec, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->d_xdata, hb + 8 + 4ull * nrec, nb, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_strip_unpack_columns, dim3((nrec + 63u) / 64u), dim3(64), 0, st, ctx->d, ctx->bs, ctx->d_xdata, ctx->d_xoffs, nrec);
+  hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, ctx->bs);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int smx_d_pack_particles(smx_ctx* ctx, int32_t x0, int32_t x1, void* host_buf, uint64_t cap, uint64_t* bytes) {
+  hipStream_t st = ctx->stream;
+  if (xbuf_alloc(ctx)) return -1;
+  const uint32_t nslots = ctx->d_nslots;
+  const uint64_t rs = 4 + (ctx->d_wind ? sizeof(BWind) : sizeof(BWater));
+  HIPCHK(hipMemsetAsync(ctx->d_xcur, 0, sizeof(XCursor), st));
+  if (nslots) {
+    if (ctx->d_wind) hipLaunchKernelGGL(k_strip_pack_particles<true>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, ctx->bs, nslots, x0, x1, ctx->d_xdata, ctx->xdata_cap, ctx->d_xcur);
+    else hipLaunchKernelGGL(k_strip_pack_particles<false>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, ctx->bs, nslots, x0, x1, ctx->d_xdata, ctx->xdata_cap, ctx->d_xcur);
+  }
+  XCursor c;
+  HIPCHK(hipMemcpyAsync(&c, ctx->d_xcur, sizeof(c), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (c.lost || 4 + c.nrec * rs > cap) { ctx->err = "smx_d_pack_particles: buffer too small"; return -2; }
+  uint8_t* hb = (uint8_t*)host_buf;
+  memcpy(hb, &c.nrec, 4);
+  if (c.nrec) HIPCHK(hipMemcpyAsync(hb + 4, ctx->d_xdata, c.nrec * rs, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *bytes = 4 + c.nrec * rs;
+  return 0;
+}
+int smx_d_unpack_particles(smx_ctx* ctx, const void* host_buf, uint64_t bytes) {
+  hipStream_t st = ctx->stream;
+  if (bytes < 4) return 0;
+  if (xbuf_alloc(ctx)) return -1;
+  const uint8_t* hb = (const uint8_t*)host_buf;
+  uint32_t n; memcpy(&n, hb, 4);
+  if (n == 0) return 0;
+  const uint64_t rs = 4 + (ctx->d_wind ? sizeof(BWind) : sizeof(BWater));
+  if (4 + n * rs > bytes || n * rs > ctx->xdata_cap) { ctx->err = "smx_d_unpack_particles: bad buffer"; return -2; }
+  HIPCHK(hipMemcpyAsync(ctx->d_xdata, hb + 4, n * rs, hipMemcpyHostToDevice, st));
+  if (ctx->d_wind) hipLaunchKernelGGL(k_strip_unpack_particles<true>, dim3((n + 255u) / 256u), dim3(256), 0, st, ctx->bs, ctx->d_xdata, n);
+  else hipLaunchKernelGGL(k_strip_unpack_particles<false>, dim3((n + 255u) / 256u), dim3(256), 0, st, ctx->bs, ctx->d_xdata, n);
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+int smx_d_grid_begin(smx_ctx* ctx) {
+  hipStream_t st = ctx->stream;
+  if (batch_alloc(ctx, 1, false)) return -1;
+  ctx->d_wind = false; ctx->d_nslots = 0; ctx->d_first = true;
+  HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, st));
+  HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, st));
+  HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NCHILD, 0, 8, st));
+  launch_classify(ctx);
+  return 0;
+}
+int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t tx_lo, int32_t tx_hi) {
+  hipStream_t st = ctx->stream; const BatchShared& bs = ctx->bs;
+  const uint32_t ntx = (uint32_t)((ctx->cfg.dimx + 3) >> 2), nty = (uint32_t)((ctx->cfg.dimy + 3) >> 2);
+  ctx->bs.tshift = GRID_SHIFT; ctx->bs.sphase = phase;
+  for (uint32_t col = 0; col < 9; col++) {
+    const uint32_t cx = col / 3u, cy = col % 3u;
+    const uint32_t mx = (ntx + 2u - cx) / 3u, my = (nty + 2u - cy) / 3u;
+    if (mx * my == 0) continue;
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_batch_grid_range, dim3((mx * my + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, col, mx, my, tx_lo, tx_hi); }
+    hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+}  // extern "C"
+
+extern "C" {
 // ---------------- the hot path ----------------
 int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   PhaseTimer t(ctx, 0);

@@ -1,8 +1,9 @@
 """Multi-process plumbing for bench.py (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
 
-The exact engines execute the reference's sequential semantics, which do not shard, so N ranks are
-N independent replicas: no data-path collective, only the timing protocol -- barrier, max-over-ranks wall time,
-sum-over-ranks work."""
+The timing protocol -- barrier, max-over-ranks wall time, sum-over-ranks work -- is the same for both multi-GPU modes:
+column strips of ONE map (batched engine, soilmachine_amd/strips.py: the data-path exchange lives there) and
+independent replicas (the exact engines execute the reference's sequential semantics, which do not shard).
+SMX_DIST_BACKEND=gloo forces the CPU transport (e.g. two ranks sharing one GPU, which RCCL refuses)."""
 from __future__ import annotations
 
 import os
@@ -19,10 +20,10 @@ def init(world: int, local_rank: int, use_cuda: bool):
     import torch
     import torch.distributed as dist
     if use_cuda:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+    dist.init_process_group(backend=os.environ.get("SMX_DIST_BACKEND", "nccl" if use_cuda else "gloo"))
     return dist
 
 

@@ -142,6 +142,68 @@ class TorchComm:
         return bytes(buf.cpu().numpy().tobytes())
 
 
+# ------------------------------------------------------------------------------------------------ device backend
+class DeviceStripBackend:
+    """One strip's context in libsoilmx (include/soilmx.h smx_d_*), wrapped for StripRank. `lm` = machine.Layermap created
+    with engine=capi.ENGINE_BATCHED (full-size map; every rank initialises or imports the same state)."""
+
+    def __init__(self, lm, buf_mb: int = 64):
+        import ctypes as C
+        from . import capi
+        self.C, self.capi, self.lm, self.L, self.h = C, capi, lm, lm.L, lm.h
+        self._buf = np.zeros(buf_mb << 20, np.uint8)
+
+    def _chk(self, rc): self.lm._chk(rc)
+    def set_strips(self, n, a, b): self._chk(self.L.smx_set_batch_strips(self.h, n, a, b))
+    def set_own(self, x0, x1): self._chk(self.L.smx_d_set_own(self.h, x0, x1))
+
+    def gen_begin(self, wind, nslots, kids):
+        if kids is None:
+            self._chk(self.L.smx_d_gen_begin(self.h, int(wind), nslots, None, None))
+            return None
+        kids = np.ascontiguousarray(kids, dtype=CHILD_DT)
+        out = np.zeros(max(nslots, 1), np.uint32)
+        self._chk(self.L.smx_d_gen_begin(self.h, int(wind), nslots, self.capi.ptr(kids), self.capi.ptr(out)))
+        return out[:nslots]
+
+    def gen_spawn(self, contains):
+        n = self.C.c_uint32()
+        c = None if contains is None else np.ascontiguousarray(contains, np.uint32)
+        self._chk(self.L.smx_d_gen_spawn(self.h, None if c is None else self.capi.ptr(c), self.C.byref(n)))
+        return int(n.value)
+
+    def next_phase(self): return int(self.L.smx_d_next_phase(self.h))
+
+    def chunk(self, nlive_global):
+        n = self.C.c_uint32()
+        self._chk(self.L.smx_d_chunk(self.h, int(nlive_global), self.C.byref(n)))
+        return int(n.value)
+
+    def gen_end(self):
+        out = np.zeros(1 << 20, CHILD_DT); n = self.C.c_uint32()
+        self._chk(self.L.smx_d_gen_end(self.h, self.capi.ptr(out), len(out), self.C.byref(n)))
+        return out[:int(n.value)].copy()
+
+    def _pack(self, fn, x0, x1):
+        k = self.C.c_uint64()
+        self._chk(fn(self.h, x0, x1, self.capi.ptr(self._buf), self._buf.size, self.C.byref(k)))
+        return self._buf[:int(k.value)].tobytes()
+
+    def pack_columns(self, x0, x1): return self._pack(self.L.smx_d_pack_columns, x0, x1)
+    def pack_particles(self, x0, x1): return self._pack(self.L.smx_d_pack_particles, x0, x1)
+
+    def unpack_columns(self, b):
+        a = np.frombuffer(b, np.uint8); self._chk(self.L.smx_d_unpack_columns(self.h, self.capi.ptr(a), len(b)))
+
+    def unpack_particles(self, b):
+        a = np.frombuffer(b, np.uint8); self._chk(self.L.smx_d_unpack_particles(self.h, self.capi.ptr(a), len(b)))
+
+    def grid_begin(self): self._chk(self.L.smx_d_grid_begin(self.h))
+    def grid_sweep(self, phase, lo, hi): self._chk(self.L.smx_d_grid_sweep(self.h, phase, lo, hi))
+    def map_frequency(self): self._chk(self.L.smx_map_frequency(self.h))
+    def reset_frequency(self): self._chk(self.L.smx_reset_frequency(self.h))
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 class StripRank:
     """The tick of SoilMachine.cpp:283-329 on ONE strip. `backend` = DeviceStripBackend (libsoilmx) or the host-sim's."""

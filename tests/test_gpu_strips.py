@@ -1,0 +1,117 @@
+"""Column strips on the MI355X. gpurun gives ONE device, so the strips run as several contexts on it:
+through the loop-back transport (threads) and through torch.distributed (gloo, two processes sharing cuda:0 -- RCCL
+refuses two ranks on one device; the nccl transport is the same code path with device tensors). Either way the result
+must equal ONE context running the same (nstrips, inset, seam) schedule, and that schedule must equal its CPU restatement."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from common import load_cfg
+from oracle_lib import Oracle
+from soilmachine_amd import capi
+from soilmachine_amd.machine import Layermap, SoilMachine
+from soilmachine_amd.snapshot import Snapshot, compare
+from soilmachine_amd.strips import DeviceStripBackend, StripGeometry, StripRank, ThreadComm, TorchComm, merge_owned, run_threads
+
+pytestmark = pytest.mark.gpu
+CK = ("steps_water_all", "steps_water_top", "steps_wind", "floods", "nested_particles", "cascade_calls", "cascade_transfers")
+
+
+def start_state(kind, n):
+    if kind == "wet":
+        cfg = load_cfg("default.soil")
+        sm = SoilMachine(cfg, n, seed=0, nwater=250, nwind=0, dowind=False, engine=capi.ENGINE_SPECULATIVE)
+        sm.tick(60, sync=True)                                   # exact engine: lakes
+        return cfg, sm.map.snapshot()
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    return cfg, Layermap(cfg, n, n, seed=0).snapshot()
+
+
+def device_ctx(cfg, s0, n):
+    m = Layermap(cfg, n, n, seed=0, initialize=False, engine=capi.ENGINE_BATCHED)
+    m.load(s0, rand_seed=0)
+    return m
+
+
+def single_context(cfg, s0, n, G, nw, nd, ticks):
+    m = device_ctx(cfg, s0, n)
+    m.set_batch_strips(G)
+    sm = SoilMachine.__new__(SoilMachine)
+    sm.cfg, sm.map, sm.nwater, sm.nwind, sm.dowater, sm.dowind = cfg, m, nw, nd, True, nd > 0
+    sm.tick(ticks, sync=True)
+    return m.snapshot(), m.counters()
+
+
+@pytest.mark.parametrize("kind,G,n,nw,nd,ticks", [("dry", 2, 256, 500, 250, 2), ("wet", 2, 256, 250, 0, 3), ("dry", 3, 384, 700, 350, 2)])
+def test_strip_schedule_on_device_equals_oracle_and_loopback(kind, G, n, nw, nd, ticks):
+    cfg, s0 = start_state(kind, n)
+    ref, cref = single_context(cfg, s0, n, G, nw, nd, ticks)
+    # (1) the schedule itself against its CPU restatement
+    o = Oracle(cfg, n, n, seed=0)
+    o.load(s0)
+    o.L.so_batched_set_strips.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
+    o.L.so_batched_set_strips(o.h, G, 16, 48)
+    for _ in range(ticks):
+        o.batched_tick(nw, nd, True, nd > 0)
+    assert not compare(ref, o.snapshot())
+    co = o.counters()
+    assert {k: cref[k] for k in CK} == {k: co[k] for k in CK}
+    # (2) G contexts exchanging halo columns and migrating particles (loop-back transport)
+    geom = StripGeometry(n, G)
+    ms = [device_ctx(cfg, s0, n) for _ in range(G)]
+    comms = ThreadComm.world(G)
+    ranks = [StripRank(DeviceStripBackend(ms[r]), comms[r], geom) for r in range(G)]
+    run_threads(ranks, lambda rk: [rk.tick(nw, nd, True, nd > 0) for _ in range(ticks)])
+    got = merge_owned(geom, [m.snapshot() for m in ms], n)
+    assert not compare(got, ref)
+    cs = [m.counters() for m in ms]
+    assert {k: sum(c[k] for c in cs) for k in CK} == {k: cref[k] for k in CK}
+    assert all(c["rand_calls"] == cref["rand_calls"] for c in cs)
+    assert ranks[0].stats["seam_chunks"] > 0 and sum(c.bytes_sent for c in comms) > 0
+    if kind == "wet":
+        assert cref["floods"] > 100 and cref["nested_particles"] > 300
+
+
+def _worker(rank, world, port, path, nw, nd, ticks, n, soil):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(path)
+    cfg = load_cfg(soil)
+    s0 = Snapshot(n, n, cfg.SCALE, len(cfg.soils), int(z["rand_calls"]), 0, z["count"], z["type"], z["size"], z["floor"], z["sat"],
+                  z["wfreq"], z["wtrack"], z["windfreq"])
+    m = device_ctx(cfg, s0, n)
+    rk = StripRank(DeviceStripBackend(m), TorchComm(dist), StripGeometry(n, world))
+    for _ in range(ticks):
+        rk.tick(nw, nd, True, nd > 0)
+    s = m.snapshot()
+    c = m.counters()
+    np.savez(path + f".rank{rank}.npz", count=s.count, type=s.type, size=s.size, floor=s.floor, sat=s.sat, wfreq=s.wfreq,
+             wtrack=s.wtrack, windfreq=s.windfreq, rand_calls=s.rand_calls, steps=c["steps_water_all"] + c["steps_wind"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_torch_distributed_equal_single_context(tmp_path):
+    import torch.multiprocessing as mp
+    n, nw, nd, ticks, soil = 256, 400, 200, 2, "rockgravelpebblessand.soil"
+    cfg, s0 = start_state("dry", n)
+    path = str(tmp_path / "s0.npz")
+    np.savez(path, count=s0.count, type=s0.type, size=s0.size, floor=s0.floor, sat=s0.sat, wfreq=s0.wfreq, wtrack=s0.wtrack,
+             windfreq=s0.windfreq, rand_calls=s0.rand_calls)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, path, nw, nd, ticks, n, soil), nprocs=2, join=True)
+    ref, cref = single_context(cfg, s0, n, 2, nw, nd, ticks)
+    snaps, steps = [], 0
+    for r in range(2):
+        z = np.load(path + f".rank{r}.npz")
+        snaps.append(Snapshot(n, n, cfg.SCALE, len(cfg.soils), int(z["rand_calls"]), 0, z["count"], z["type"], z["size"], z["floor"],
+                              z["sat"], z["wfreq"], z["wtrack"], z["windfreq"]))
+        steps += int(z["steps"])
+    assert not compare(merge_owned(StripGeometry(n, 2), snaps, n), ref)
+    assert steps == cref["steps_water_all"] + cref["steps_wind"]
