@@ -112,6 +112,13 @@ int smx_read_frequency(smx_ctx* ctx, float* wfreq, float* wtrack, float* windfre
 int smx_read_heights(smx_ctx* ctx, double* out);        /* Layermap::height(ivec2) for every cell (layermap.h:422) */
 int smx_read_surface(smx_ctx* ctx, uint32_t* out);      /* Layermap::surface(ivec2) for every cell (layermap.h:417) */
 
+/* ---- checkpoint / resume on disk (the reference has none: SURVEY.md 5; io.h:232 "Should be able to also WRITE to file").
+ * File = the snapshot layout of soilmachine_amd/snapshot.py (64-byte header "SMXSNAP1", per-cell section counts, sections
+ * bottom -> top, the three frequency planes) followed by a trailer "SMXRAND1" with the rand() generator's 31-word ring, its
+ * index and the number of draws -- a loaded context continues the libc stream exactly where the saved one stopped. ---- */
+int smx_save(smx_ctx* ctx, const char* path);
+int smx_load(smx_ctx* ctx, const char* path);           /* dims must match the context; SCALE and soils are the caller's */
+
 /* ---- the hot path, phase by phase: replaces SoilMachine.cpp:287-320 ---- */
 int smx_tick_water(smx_ctx* ctx, int32_t nwater);       /* :287-298  NWATER x {WaterParticle ctor; move/interact; flood} */
 int smx_grid_pass(smx_ctx* ctx);                        /* :300-301  WaterParticle::seep(map) (water.h:335-343)          */
@@ -136,6 +143,10 @@ int smx_normals(smx_ctx* ctx, float* out3);             /* Layermap::normal(ivec
  * type; an empty column is (x, 0, y), (0,1,0), colors4[0], 0. colors4 = ncolors x RGBA (SurfParam::color,
  * surface.h:17); out = dimx*dimy*44 bytes, caller-allocated. */
 int smx_fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44);
+/* the same with a horizontal cut through the sediment: mode 0 = Layermap::update's rule with the global SLICE = (int)cut
+ * (layermap.h:477-510: first section starting at or below SLICE/SCALE; a section reaching above it is drawn flat at y = SLICE,
+ * blended with Air's colour where its water table reaches the cut), mode 1 = Layermap::slice(s = cut) (layermap.h:557-613). */
+int smx_fill_vertices_cut(smx_ctx* ctx, const float* colors4, int32_t ncolors, int32_t mode, double cut, void* out_vertices44);
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out);      /* Layermap::height(vec2) (layermap.h:427) */
 
 /* ---- observability ---- */

@@ -54,8 +54,8 @@ SYMBOLS = [
     "smx_initialize", "smx_import_columns", "smx_import_frequency", "smx_num_sections", "smx_export_columns",
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
-    "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices",
-    "smx_digest", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips",
+    "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices", "smx_fill_vertices_cut",
+    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips",
     "smx_d_set_own", "smx_d_gen_begin", "smx_d_gen_spawn", "smx_d_next_phase", "smx_d_chunk", "smx_d_gen_end", "smx_d_pack_columns",
     "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep",
 ]
@@ -104,7 +104,10 @@ def load() -> C.CDLL:
     L.smx_top.argtypes = [vp, i32, i32, C.POINTER(u32), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(i32)]
     L.smx_normals.argtypes = [vp, vp]
     L.smx_fill_vertices.argtypes = [vp, vp, C.c_int32, vp]
+    L.smx_fill_vertices_cut.argtypes = [vp, vp, C.c_int32, C.c_int32, dbl, vp]
     L.smx_heights_bilinear.argtypes = [vp, vp, i32, vp]
+    L.smx_save.argtypes = [vp, C.c_char_p]
+    L.smx_load.argtypes = [vp, C.c_char_p]
     L.smx_digest.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
     L.smx_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.smx_get_timing.argtypes = [vp, C.POINTER(Timing)]

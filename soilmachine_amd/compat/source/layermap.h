@@ -202,8 +202,8 @@ class Layermap {
     vertexpool.index();
     vertexpool.update();
   }
-  // the visible vertex of a column: the top section (the SLICE cut of layermap.h:477-510 would need the buried
-  // sections; with the default SLICE = 2*SCALE nothing is cut)
+  // one column (host-driven edits): the top section from the host mirrors. The SLICE cut of layermap.h:477-510 needs the
+  // buried sections, which live on the device: the whole-map update(Vertexpool&) below applies it (smx_fill_vertices_cut)
   void update(ivec2 p, Vertexpool<Vertex>& vertexpool) {                                            // layermap.h:475-549
     if (section == NULL) return;
     refresh();
@@ -219,7 +219,7 @@ class Layermap {
     if (vertexpool.store.size() >= (size_t)*section + (size_t)dim.x * dim.y) {   // contiguous section: one device pass
       std::vector<float> col(4 * soils.size());
       for (size_t k = 0; k < soils.size(); k++) { col[4 * k] = soils[k].color.x; col[4 * k + 1] = soils[k].color.y; col[4 * k + 2] = soils[k].color.z; col[4 * k + 3] = soils[k].color.w; }
-      check(smx_fill_vertices(ctx, col.data(), (int32_t)soils.size(), vertexpool.get(section, 0)), "smx_fill_vertices");
+      check(smx_fill_vertices_cut(ctx, col.data(), (int32_t)soils.size(), 0, (double)SLICE, vertexpool.get(section, 0)), "smx_fill_vertices_cut");   // SLICE cut: layermap.h:477-510
       return;
     }
     std::vector<float> nrm((size_t)dim.x * dim.y * 3);
@@ -232,7 +232,14 @@ class Layermap {
         else vertexpool.fill(section, (int)c, vec3(i, SCALE * hmirror[c], j), vec3(nrm[3 * c], nrm[3 * c + 1], nrm[3 * c + 2]), soils[ty].color, (int)ty);
       }
   }
-  void slice(Vertexpool<Vertex>& vertexpool, double = 0) { update(vertexpool); }                    // layermap.h:557-613 (no cut)
+  void slice(Vertexpool<Vertex>& vertexpool, double s = SCALE) {                                    // layermap.h:557-613
+    if (section == NULL) return;
+    refresh();
+    if (vertexpool.store.size() < (size_t)*section + (size_t)dim.x * dim.y) { update(vertexpool); return; }
+    std::vector<float> col(4 * soils.size());
+    for (size_t k = 0; k < soils.size(); k++) { col[4 * k] = soils[k].color.x; col[4 * k + 1] = soils[k].color.y; col[4 * k + 2] = soils[k].color.z; col[4 * k + 3] = soils[k].color.w; }
+    check(smx_fill_vertices_cut(ctx, col.data(), (int32_t)soils.size(), 1, s, vertexpool.get(section, 0)), "smx_fill_vertices_cut");
+  }
 
   void initialize(int SEED, ivec2 _dim) {                                                           // layermap.h:163-216
     dim = _dim;

@@ -556,31 +556,51 @@ __global__ void __launch_bounds__(256) k_normals(DevState s, float* __restrict__
 // Layermap::update(Vertexpool&) for the whole map (layermap.h:475-555): one 44-byte vertex per column. A thread
 // builds its vertex in LDS, the block then streams its 256 x 11 floats out as one contiguous run (a 44-byte
 // stride per thread would scatter every store over two lines).
+// mode -1: no cut (the top section). mode 0: Layermap::update's SLICE cut (layermap.h:477-510). mode 1: Layermap::slice(s)
+// (layermap.h:557-613). thr = the cut height in map units, ycut = the y written for a cut column.
+struct VCut { int mode; double thr; float ycut; };
 __global__ void __launch_bounds__(256) k_fill_vertices(DevState s, const float* __restrict__ colors4, uint32_t ncolors,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, VCut cut) {
   __shared__ float stage[256 * 11];
   const size_t n = (size_t)s.dimx * s.dimy;
   const size_t c0 = (size_t)blockIdx.x * 256, c = c0 + threadIdx.x;
   if (c < n) {
     const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
-    const Sec r = s.cells[c];
-    const uint32_t ty = (r.type == EMPTY) ? 0u : r.type;
-    const double h = (r.type == EMPTY) ? 0.0 : r.floor + r.size;
+    Sec r = s.cells[c];
+    bool have = r.type != EMPTY;
+    if (cut.mode >= 0)                                        // the first section that starts at or below the cut
+      while (have && r.floor > cut.thr) { if (r.prev == NIL) have = false; else r = s.pool[r.prev]; }
+    const uint32_t ty = have ? r.type : 0u;
+    const double h = have ? r.floor + r.size : 0.0;
     float* v = stage + threadIdx.x * 11;
     f3 nrm = {0.f, 1.f, 0.f};
     float py = 0.f;
     uint32_t ci = 0;
-    if (!(h == 0.0 && ty == 0u)) {
+    float col[4];
+    bool plain = true;                                        // colour = colors4[ci]
+    if (cut.mode >= 0 && have && h > cut.thr) {               // the section is cut: flat top at the cut height
+      py = cut.ycut;
+      const bool wet = r.floor + r.size * r.sat > cut.thr;
+      ci = (cut.mode == 0 && wet) ? 0u : ty;
+      if (wet) {                                              // mix(a, colour, 0.6) in double (glm), a = Air's colour / red
+        plain = false;
+        const uint32_t ct = ty < ncolors ? ty : 0u;
+        const float a[4] = {cut.mode == 0 ? colors4[0] : 1.f, cut.mode == 0 ? colors4[1] : 0.f, cut.mode == 0 ? colors4[2] : 0.f, cut.mode == 0 ? colors4[3] : 1.f};
+        for (int k = 0; k < 4; k++) col[k] = (float)((double)a[k] * (1.0 - 0.6) + (double)colors4[4 * ct + k] * 0.6);
+      }
+    } else if (cut.mode >= 0 ? have : !(h == 0.0 && ty == 0u)) {
       SerialPolicy pol(s);
       Sim<SerialPolicy> sim(s, s.soils, pol);
       nrm = sim.normal(x, y);
       py = (float)(s.scale * h);
       ci = ty;
+      if (cut.mode == 1 && r.sat == 0.0) { plain = false; col[0] = 1.f; col[1] = 0.f; col[2] = 0.f; col[3] = 1.f; }   // :598-604
     }
     const uint32_t cc = ci < ncolors ? ci : 0u;
+    if (plain) { col[0] = colors4[4 * cc]; col[1] = colors4[4 * cc + 1]; col[2] = colors4[4 * cc + 2]; col[3] = colors4[4 * cc + 3]; }
     v[0] = (float)x; v[1] = py; v[2] = (float)y;
     v[3] = nrm.x; v[4] = nrm.y; v[5] = nrm.z;
-    v[6] = colors4[4 * cc]; v[7] = colors4[4 * cc + 1]; v[8] = colors4[4 * cc + 2]; v[9] = colors4[4 * cc + 3];
+    v[6] = col[0]; v[7] = col[1]; v[8] = col[2]; v[9] = col[3];
     v[10] = (float)(int)ci;
   }
   __syncthreads();
@@ -633,6 +653,8 @@ struct smx_ctx {
   SoilP* d_soils = nullptr;
   int nsoils = 0;
   double* d_scratch = nullptr;        // 1 double for point ops
+  float* d_vtx = nullptr; float* d_vcol = nullptr;   // smx_fill_vertices scratch (kept)
+  void* d_plane = nullptr; size_t plane_cap = 0;     // smx_read_heights / _surface / smx_normals scratch (kept)
   std::vector<EvPair> pending;
   std::vector<hipEvent_t> evpool;
   smx_timing timing{};
@@ -766,6 +788,7 @@ void smx_destroy(smx_ctx* ctx) {
   hipFree(d.cells); hipFree(d.pool); hipFree(d.freelist); hipFree(d.free_count); hipFree(d.flags);
   hipFree(d.wfreq); hipFree(d.wtrack); hipFree(d.windfreq); hipFree(d.rnd); hipFree(d.ctr);
   hipFree(d.active); hipFree(d.active1); hipFree(d.active2); hipFree(ctx->d_scratch); hipFree(ctx->d_soils);
+  hipFree(ctx->d_vtx); hipFree(ctx->d_vcol); hipFree(ctx->d_plane);
   if (ctx->sh.stamp) {
     SpecShared& sh = ctx->sh;
     hipFree(sh.stamp); hipFree(sh.claim); hipFree(sh.ctrl); hipFree(sh.reclaim); hipHostFree(ctx->h_ctrl);
@@ -970,6 +993,63 @@ int smx_export_columns(smx_ctx* ctx, uint32_t* count, uint32_t* type, double* si
   return 0;
 }
 
+struct SnapHdr { char magic[8]; int32_t dimx, dimy, scale, nsoils; uint64_t ncells, nsec, rand_calls, pool_free, reserved; };
+static_assert(sizeof(SnapHdr) == 64, "snapshot header");
+struct RandTrailer { char magic[8]; uint32_t ring[31]; uint32_t idx; uint64_t calls; };
+int smx_save(smx_ctx* ctx, const char* path) {
+  const size_t n = ctx->ncells;
+  uint64_t ns = 0;
+  if (smx_num_sections(ctx, &ns)) return -1;
+  std::vector<uint32_t> count(n), type(ns);
+  std::vector<double> size(ns), floor(ns), sat(ns);
+  std::vector<float> wf(n), wt(n), wi(n);
+  if (smx_export_columns(ctx, count.data(), type.data(), size.data(), floor.data(), sat.data())) return -1;
+  if (smx_read_frequency(ctx, wf.data(), wt.data(), wi.data())) return -1;
+  RandTrailer tr; memcpy(tr.magic, "SMXRAND1", 8);
+  RandState r;
+  HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  memcpy(tr.ring, r.ring, sizeof(tr.ring)); tr.idx = r.idx; tr.calls = r.calls;
+  SnapHdr h; memset(&h, 0, sizeof(h)); memcpy(h.magic, "SMXSNAP1", 8);
+  h.dimx = ctx->cfg.dimx; h.dimy = ctx->cfg.dimy; h.scale = ctx->d.scale; h.nsoils = ctx->nsoils; h.ncells = n; h.nsec = ns;
+  h.rand_calls = r.calls; h.pool_free = ctx->cfg.pool_capacity - ns;
+  FILE* f = fopen(path, "wb");
+  if (!f) { ctx->err = std::string("smx_save: cannot open ") + path; return -7; }
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+  ok = ok && fwrite(count.data(), 4, n, f) == n && fwrite(type.data(), 4, ns, f) == ns && fwrite(size.data(), 8, ns, f) == ns &&
+       fwrite(floor.data(), 8, ns, f) == ns && fwrite(sat.data(), 8, ns, f) == ns && fwrite(wf.data(), 4, n, f) == n &&
+       fwrite(wt.data(), 4, n, f) == n && fwrite(wi.data(), 4, n, f) == n && fwrite(&tr, sizeof(tr), 1, f) == 1;
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { ctx->err = std::string("smx_save: short write to ") + path; return -7; }
+  return 0;
+}
+int smx_load(smx_ctx* ctx, const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { ctx->err = std::string("smx_load: cannot open ") + path; return -7; }
+  SnapHdr h;
+  if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMXSNAP1", 8) != 0) { fclose(f); ctx->err = "smx_load: not a soilmx snapshot"; return -7; }
+  if (h.dimx != ctx->cfg.dimx || h.dimy != ctx->cfg.dimy || h.ncells != ctx->ncells) { fclose(f); ctx->err = "smx_load: snapshot dimensions differ from the context's"; return -2; }
+  const size_t n = ctx->ncells; const uint64_t ns = h.nsec;
+  std::vector<uint32_t> count(n), type(ns);
+  std::vector<double> size(ns), floor(ns), sat(ns);
+  std::vector<float> wf(n), wt(n), wi(n);
+  bool ok = fread(count.data(), 4, n, f) == n && fread(type.data(), 4, ns, f) == ns && fread(size.data(), 8, ns, f) == ns &&
+            fread(floor.data(), 8, ns, f) == ns && fread(sat.data(), 8, ns, f) == ns && fread(wf.data(), 4, n, f) == n &&
+            fread(wt.data(), 4, n, f) == n && fread(wi.data(), 4, n, f) == n;
+  RandTrailer tr; const bool have_rand = ok && fread(&tr, sizeof(tr), 1, f) == 1 && memcmp(tr.magic, "SMXRAND1", 8) == 0;
+  fclose(f);
+  if (!ok) { ctx->err = "smx_load: truncated snapshot"; return -7; }
+  if (smx_import_columns(ctx, count.data(), type.data(), size.data(), floor.data(), sat.data())) return -1;
+  if (smx_import_frequency(ctx, wf.data(), wt.data(), wi.data())) return -1;
+  if (have_rand) {
+    RandState r; memcpy(r.ring, tr.ring, sizeof(r.ring)); r.idx = tr.idx; r.calls = tr.calls;
+    HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  ctx->d.scale = h.scale; ctx->cfg.scale = h.scale;
+  return have_rand ? 0 : 1;   /* 1: state restored, but the file carries no generator state (a bare snapshot): re-seed it yourself */
+}
+
 int smx_read_frequency(smx_ctx* ctx, float* wfreq, float* wtrack, float* windfreq) {
   const size_t n = ctx->ncells;
   if (wfreq) HIPCHK(hipMemcpyAsync(wfreq, ctx->d.wfreq, n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -980,15 +1060,14 @@ int smx_read_frequency(smx_ctx* ctx, float* wfreq, float* wtrack, float* windfre
 }
 
 static int read_plane(smx_ctx* ctx, void* host, size_t bytes, int which) {
-  void* tmp = nullptr;
-  HIPCHK(hipMalloc(&tmp, bytes));
+  if (ctx->plane_cap < bytes) { hipFree(ctx->d_plane); ctx->d_plane = nullptr; ctx->plane_cap = 0; HIPCHK(hipMalloc(&ctx->d_plane, bytes)); ctx->plane_cap = bytes; }
+  void* tmp = ctx->d_plane;
   const unsigned nb = (unsigned)((ctx->ncells + 255) / 256);
   if (which == 0) hipLaunchKernelGGL(k_heights, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (double*)tmp);
   else if (which == 1) hipLaunchKernelGGL(k_surface, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (uint32_t*)tmp);
   else hipLaunchKernelGGL(k_normals, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (float*)tmp);
   hipError_t e = hipMemcpyAsync(host, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  hipFree(tmp);
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
   return 0;
 }
@@ -996,22 +1075,30 @@ int smx_read_heights(smx_ctx* ctx, double* out) { return read_plane(ctx, out, ct
 int smx_read_surface(smx_ctx* ctx, uint32_t* out) { return read_plane(ctx, out, ctx->ncells * 4, 1); }
 int smx_normals(smx_ctx* ctx, float* out3) { return read_plane(ctx, out3, ctx->ncells * 12, 2); }
 
-int smx_fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44) {
+static int fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44, VCut cut) {
   if (!colors4 || ncolors <= 0 || !out_vertices44) { ctx->err = "smx_fill_vertices: colors4/out must be given"; return -2; }
-  float* dcol = nullptr; float* dout = nullptr;
   const size_t bytes = ctx->ncells * 44;
-  HIPCHK(hipMalloc(&dcol, (size_t)ncolors * 16));
-  if (hipMalloc(&dout, bytes) != hipSuccess) { hipFree(dcol); ctx->err = "smx_fill_vertices: out of device memory"; return -1; }
-  hipError_t e = hipMemcpyAsync(dcol, colors4, (size_t)ncolors * 16, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_fill_vertices, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d, dcol,
-                       (uint32_t)ncolors, dout);
-    e = hipMemcpyAsync(out_vertices44, dout, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (!ctx->d_vtx) {                                        // scratch kept for the context's lifetime (738 MB at 4096^2)
+    HIPCHK(hipMalloc(&ctx->d_vcol, 256 * 16));
+    if (hipMalloc(&ctx->d_vtx, bytes) != hipSuccess) { ctx->d_vtx = nullptr; ctx->err = "smx_fill_vertices: out of device memory"; return -1; }
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  hipFree(dcol); hipFree(dout);
-  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
+  if (ncolors > 256) ncolors = 256;
+  HIPCHK(hipMemcpyAsync(ctx->d_vcol, colors4, (size_t)ncolors * 16, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_fill_vertices, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d, ctx->d_vcol,
+                     (uint32_t)ncolors, ctx->d_vtx, cut);
+  HIPCHK(hipMemcpyAsync(out_vertices44, ctx->d_vtx, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+int smx_fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44) {
+  return fill_vertices(ctx, colors4, ncolors, out_vertices44, VCut{-1, 0.0, 0.f});
+}
+int smx_fill_vertices_cut(smx_ctx* ctx, const float* colors4, int32_t ncolors, int32_t mode, double cut, void* out_vertices44) {
+  VCut c;
+  c.mode = mode ? 1 : 0;
+  if (mode == 0) { const int sl = (int)cut; c.thr = (double)((float)sl / (float)ctx->d.scale); c.ycut = (float)sl; }   // (float)SLICE/(float)SCALE, vec3(p.x, SLICE, p.y)
+  else { c.thr = cut / (double)ctx->d.scale; c.ycut = (float)cut; }                                                    // s/SCALE, vec3(p.x, s, p.y)
+  return fill_vertices(ctx, colors4, ncolors, out_vertices44, c);
 }
 
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out) {

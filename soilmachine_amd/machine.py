@@ -115,12 +115,15 @@ class Layermap:
         self._chk(self.L.smx_normals(self.h, capi.ptr(out)))
         return out
 
-    def vertices(self, colors: np.ndarray) -> np.ndarray:
+    def vertices(self, colors: np.ndarray, cut=None, mode: str = "update") -> np.ndarray:
         """Layermap::update(Vertexpool&) (layermap.h:475-555) for the whole map in one device pass: (cells, 11) float32 =
         position[3], normal[3], color[4], index (the reference's 44-byte Vertex); `colors` = (nsoils, 4) RGBA."""
         colors = np.ascontiguousarray(colors, np.float32).reshape(-1, 4)
         out = np.zeros((self.dimx * self.dimy, 11), np.float32)
-        self._chk(self.L.smx_fill_vertices(self.h, capi.ptr(colors), colors.shape[0], capi.ptr(out)))
+        if cut is None:
+            self._chk(self.L.smx_fill_vertices(self.h, capi.ptr(colors), colors.shape[0], capi.ptr(out)))
+        else:   # mode "update": the global SLICE of Layermap::update (layermap.h:477-510); "slice": Layermap::slice(s) (:557-613)
+            self._chk(self.L.smx_fill_vertices_cut(self.h, capi.ptr(colors), colors.shape[0], 0 if mode == "update" else 1, float(cut), capi.ptr(out)))
         return out
 
     def heights_bilinear(self, pos: np.ndarray) -> np.ndarray:
@@ -136,6 +139,17 @@ class Layermap:
         r = C.c_double()
         self._chk(self.L.smx_remove(self.h, x, y, h, C.byref(r)))
         return r.value
+
+    def save(self, path: str):
+        """Checkpoint on disk (columns, frequency planes, rand() generator state): smx_save."""
+        self._chk(self.L.smx_save(self.h, path.encode()))
+
+    def restore(self, path: str):
+        """Resume from a checkpoint written by save() (or a bare snapshot: then the rand stream must be re-seeded)."""
+        rc = self.L.smx_load(self.h, path.encode())
+        if rc not in (0, 1):
+            self._chk(rc)
+        return rc == 0
 
     def digest(self) -> dict:
         """The Appendix-E state digest (sum of heights, section count, type hash) + rand() draws consumed."""

@@ -223,3 +223,30 @@ def layers_array(cfg: SoilConfig) -> np.ndarray:
         for k in LAYER_DTYPE.names:
             a[i][k] = getattr(l, k)
     return a
+
+
+def writesoil(cfg: SoilConfig, path: str) -> None:
+    """The writer the reference only announces (io.h:232 "Should be able to also WRITE to file"): a `.soil` text that
+    ``loadsoil`` -- this module's and the reference's -- parses back into exactly these tables. Because soil indices are
+    handed out at first mention (io.h:125-152) the file first declares every soil by an empty block, in index order, and
+    then defines each one with ALL its keys (so nothing is inherited from the previous block, io.h:35)."""
+    f32 = lambda v: repr(float(np.float32(v)))
+    names = [s.name for s in cfg.soils]
+    out = ["# written by soilmachine_amd.soilfile.writesoil", "", "WORLD {", f"SCALE {cfg.SCALE}", f"SIZEX {cfg.SIZEX}",
+           f"SIZEY {cfg.SIZEY}", f"NWIND {cfg.NWIND}", f"NWATER {cfg.NWATER}", "}", ""]
+    start = 0 if cfg.soils and cfg.soils[0] != _air() else 1          # "Air" is built in (surface.h:41-57) unless it was edited
+    for s in cfg.soils[1:]:
+        out += [f"SOIL {s.name} {{", "}"]
+    out.append("")
+    for s in cfg.soils[start:]:
+        out += [f"SOIL {s.name} {{", f"DENSITY {f32(s.density)}", f"POROSITY {f32(s.porosity)}", f"TRANSPORTS {names[s.transports]}",
+                f"SOLUBILITY {f32(s.solubility)}", f"EQUILIBRIUM {f32(s.equrate)}", f"FRICTION {f32(s.friction)}",
+                f"ERODES {names[s.erodes]}", f"EROSIONRATE {f32(s.erosionrate)}", f"CASCADES {names[s.cascades]}",
+                f"MAXDIFF {f32(s.maxdiff)}", f"SETTLING {f32(s.settling)}", f"ABRADES {names[s.abrades]}",
+                f"SUSPENSION {f32(s.suspension)}", f"ABRASION {f32(s.abrasion)}", "}", ""]
+    for l in cfg.layers:
+        out += [f"LAYER {names[l.type]} {{", f"MIN {f32(l.min)}", f"BIAS {f32(l.bias)}", f"SCALE {f32(l.scale)}",
+                f"OCTAVES {f32(l.octaves)}", f"LACUNARITY {f32(l.lacunarity)}", f"GAIN {f32(l.gain)}",
+                f"FREQUENCY {f32(l.frequency)}", "}", ""]
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")

@@ -132,3 +132,81 @@ def test_initialize_refuses_a_pool_that_cannot_hold_the_terrain():
     o = Oracle(cfg, 64, 64, seed=0, pool=2 * 64 * 64)
     o.initialize()
     assert not compare(m.snapshot(), o.snapshot())
+
+
+@pytest.mark.parametrize("engine", [capi.ENGINE_SPECULATIVE, capi.ENGINE_BATCHED])
+def test_checkpoint_on_disk_resumes_bit_exactly(engine, tmp_path):
+    """smx_save at tick 5, smx_load into a FRESH context, continue: identical to the uninterrupted run (for the exact
+    engine that is the reference's golden tick-20 state). The file carries the rand() generator, not just its position."""
+    from common import golden_snapshot
+    cfg = load_cfg("default.soil")
+    d = DIG["default64"]
+    a = SoilMachine(cfg, 64, seed=0, nwater=d["nwater"], nwind=0, dowind=False, engine=engine)
+    a.tick(5, sync=True)
+    path = str(tmp_path / "ckpt.smx")
+    a.map.save(path)
+    a.tick(15, sync=True)
+    b = SoilMachine(cfg, 64, seed=123, nwater=d["nwater"], nwind=0, dowind=False, engine=engine)    # another seed: everything must come from the file
+    assert b.map.restore(path)
+    b.tick(15, sync=True)
+    sa, sb = a.map.snapshot(), b.map.snapshot()
+    assert not compare(sa, sb)
+    if engine == capi.ENGINE_SPECULATIVE:
+        assert not compare(sb, golden_snapshot("default64", 20))
+    # the file is a plain snapshot for every other reader (soilmachine_amd.snapshot / oracle/snapshot.h): trailer ignored
+    from soilmachine_amd.snapshot import read_snapshot
+    s5 = read_snapshot(path)
+    assert not compare(s5, golden_snapshot("default64", 5)) or engine == capi.ENGINE_BATCHED
+
+
+@pytest.mark.parametrize("mode,cut", [("update", 60), ("update", 25), ("slice", 47.5)])
+def test_vertex_stream_with_slice_cut(mode, cut):
+    """smx_fill_vertices_cut = Layermap::update's SLICE rule (layermap.h:477-510) / Layermap::slice(s) (:557-613): the first
+    section starting at or below the cut; a section reaching above it is drawn flat at the cut, blended where its water
+    table reaches it. Rebuilt here from the exported columns (buried sections included) and checked bit for bit."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 64
+    sm = SoilMachine(cfg, n, seed=3, nwater=150, nwind=80)
+    sm.tick(4, sync=True)
+    m = sm.map
+    for (x, y, sz) in [(5, 5, 0.04), (20, 33, 0.1), (40, 12, 0.02)]:       # some standing water (type 0) and saturation
+        m.add(x, y, sz, 0)
+        m._chk(m.L.smx_water_cascade(m.h, x, y, 3))
+    for _ in range(8):
+        m.remove(9, 9, 10.0)                                       # an empty column
+    s = m.snapshot()
+    nrm = m.normals()
+    colors = np.linspace(0.05, 0.95, 4 * len(cfg.soils), dtype=np.float32).reshape(-1, 4)
+    got = m.vertices(colors, cut=cut, mode=mode)
+    SC = cfg.SCALE
+    thr = float(np.float32(int(cut)) / np.float32(SC)) if mode == "update" else float(cut) / SC
+    ycut = np.float32(int(cut)) if mode == "update" else np.float32(cut)
+    end = np.cumsum(s.count.astype(np.int64))
+    want = np.zeros((n * n, 11), np.float32)
+    ncut = nwet = nempty = 0
+    for c in range(n * n):
+        x, y = divmod(c, n)
+        k = int(end[c]) - 1
+        lo = int(end[c]) - int(s.count[c])
+        while k >= lo and s.floor[k] > thr:
+            k -= 1
+        if k < lo:
+            want[c] = [x, 0, y, 0, 1, 0, *colors[0], 0]; nempty += 1
+            continue
+        ty, top = int(s.type[k]), s.floor[k] + s.size[k]
+        if top > thr:
+            ncut += 1
+            wet = s.floor[k] + s.size[k] * s.sat[k] > thr
+            if wet:
+                nwet += 1
+                a = colors[0] if mode == "update" else np.array([1, 0, 0, 1], np.float32)
+                col = (a.astype(np.float64) * (1.0 - 0.6) + colors[ty].astype(np.float64) * 0.6).astype(np.float32)
+                idx = 0 if mode == "update" else ty
+            else:
+                col, idx = colors[ty], ty
+            want[c] = [x, ycut, y, 0, 1, 0, *col, idx]
+        else:
+            col = np.array([1, 0, 0, 1], np.float32) if (mode == "slice" and s.sat[k] == 0.0) else colors[ty]
+            want[c] = [x, np.float32(SC * top), y, *nrm[c], *col, ty]
+    assert ncut > 100 and nempty >= 1
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -55,3 +55,28 @@ def test_syntax_errors(tmp_path):
     p.write_text("LAYER Nope {\n}\n")
     with pytest.raises(SyntaxError):
         loadsoil(str(p))
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_writesoil_round_trip(name, tmp_path):
+    """The `.soil` writer the reference only announces (io.h:232): what it writes parses back into the same tables,
+    index order included -- with this module's parser and, where the reference is built, with the reference's own."""
+    from soilmachine_amd.soilfile import writesoil
+    cfg = loadsoil(os.path.join(SOILS, name))
+    out = str(tmp_path / ("w_" + name))
+    writesoil(cfg, out)
+    back = loadsoil(out)
+    assert back.to_json() == cfg.to_json() and back.soilmap == cfg.soilmap
+    from oracle_lib import have_ref, run_ref
+    if have_ref():
+        js = str(tmp_path / "ref.json")
+        run_ref(out, ticks=0, size=16, soils_out=js, water=False, wind=False)
+        ref = json.load(open(js))
+        assert [s["name"] for s in ref["soils"]] == [s.name for s in cfg.soils]
+        for a, b in zip(cfg.soils, ref["soils"]):
+            for k in ("transports", "erodes", "cascades", "abrades"):
+                assert getattr(a, k) == b[k], (a.name, k)
+            for k in ("porosity", "solubility", "equrate", "friction", "erosionrate", "maxdiff", "settling", "suspension", "abrasion"):
+                assert np.float32(getattr(a, k)) == np.float32(b[k]), (a.name, k)
+        assert [l["type"] for l in ref["layers"]] == [l.type for l in cfg.layers]
+        assert (ref["scale"], ref["nwater"], ref["nwind"]) == (cfg.SCALE, cfg.NWATER, cfg.NWIND)
