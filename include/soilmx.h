@@ -97,6 +97,10 @@ int smx_set_scale(smx_ctx* ctx, int32_t scale);
 int smx_srand(smx_ctx* ctx, uint32_t seed);
 int smx_rand(smx_ctx* ctx, int32_t* out);               /* draw one value on behalf of the host */
 int smx_rand_advance(smx_ctx* ctx, uint64_t ndraws);    /* discard ndraws values (resume a stream at a known offset) */
+/* the generator itself (glibc TYPE_3: the last 31 words, the running index, draws since smx_srand): hand the stream from one
+ * context to another (the compat Layermap does when the host re-initialises with a new map size, SoilMachine.cpp:111-114) */
+int smx_get_rand_state(smx_ctx* ctx, uint32_t ring31[31], uint32_t* idx, uint64_t* calls);
+int smx_set_rand_state(smx_ctx* ctx, const uint32_t ring31[31], uint32_t idx, uint64_t calls);
 
 /* ---- terrain: replaces Layermap::initialize + SurfLayer::get + FastNoiseLite (layermap.h:163-216, surface.h:82-99) ---- */
 int smx_initialize(smx_ctx* ctx, int32_t seed, const smx_layer* layers, int32_t nlayers);

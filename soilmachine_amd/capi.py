@@ -50,7 +50,7 @@ class Timing(C.Structure):
 
 # every symbol include/soilmx.h declares (tests/test_capi_symbols.py checks the library exports them all)
 SYMBOLS = [
-    "smx_create", "smx_destroy", "smx_last_error", "smx_set_soils", "smx_set_scale", "smx_srand", "smx_rand", "smx_rand_advance",
+    "smx_create", "smx_destroy", "smx_last_error", "smx_set_soils", "smx_set_scale", "smx_srand", "smx_rand", "smx_rand_advance", "smx_get_rand_state", "smx_set_rand_state",
     "smx_initialize", "smx_import_columns", "smx_import_frequency", "smx_num_sections", "smx_export_columns",
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     L.smx_srand.argtypes = [vp, u32]
     L.smx_rand.argtypes = [vp, C.POINTER(i32)]
     L.smx_rand_advance.argtypes = [vp, u64]
+    L.smx_get_rand_state.argtypes = [vp, vp, C.POINTER(u32), C.POINTER(u64)]
+    L.smx_set_rand_state.argtypes = [vp, vp, u32, u64]
     L.smx_initialize.argtypes = [vp, i32, vp, i32]
     L.smx_import_columns.argtypes = [vp] + [vp] * 5
     L.smx_import_frequency.argtypes = [vp] + [vp] * 3

@@ -241,7 +241,35 @@ class Layermap {
     check(smx_fill_vertices_cut(ctx, col.data(), (int32_t)soils.size(), 1, s, vertexpool.get(section, 0)), "smx_fill_vertices_cut");
   }
 
+  // the device context for a map of `_dim` cells. POOLSIZE is the reference's capacity (SoilMachine.cpp:16); maps that
+  // cannot even hold their initial terrain in it (>= 2048^2 with two layers -- the reference would silently drop
+  // columns there, layermap.h:92-95) get 4 sections per cell instead, and say so.
+  void create_context(ivec2 _dim) {
+    smx_config cfg;
+    uint64_t cap = (uint64_t)POOLSIZE;
+    const uint64_t need = 4ull * (uint64_t)_dim.x * (uint64_t)_dim.y;
+    if (cap < (uint64_t)_dim.x * _dim.y * (layers.size() ? layers.size() : 1)) {
+      cout << "soilmx: POOLSIZE " << cap << " cannot hold a " << _dim.x << "x" << _dim.y << " map with " << layers.size() << " layers: using " << need << endl;
+      cap = need;
+    }
+    cfg.dimx = _dim.x; cfg.dimy = _dim.y; cfg.scale = SCALE; cfg.device = 0; cfg.pool_capacity = cap;
+    const char* e = getenv("SMX_ENGINE");
+    cfg.engine = (e && std::string(e) == "serial") ? SMX_ENGINE_SERIAL : (e && std::string(e) == "batched") ? SMX_ENGINE_BATCHED : SMX_ENGINE_SPECULATIVE;
+    cfg.reserved = 0;
+    int rc = smx_create(&cfg, &ctx);
+    if (rc != 0) { cout << "soilmx: smx_create failed: " << (ctx ? smx_last_error(ctx) : "") << endl; exit(1); }
+    upload_tables();
+  }
+
   void initialize(int SEED, ivec2 _dim) {                                                           // layermap.h:163-216
+    if (ctx && (_dim.x != dim.x || _dim.y != dim.y)) {       // the GUI re-seeds after SIZEX/SIZEY edits (SoilMachine.cpp:111-114): the
+      uint32_t ring[31], idx = 0; uint64_t calls = 0;          // reference reallocates `dat` (layermap.h:165-172); the libc stream goes on
+      check(smx_get_rand_state(ctx, ring, &idx, &calls), "smx_get_rand_state");
+      smx_destroy(ctx); ctx = nullptr;
+      create_context(_dim);
+      check(smx_set_rand_state(ctx, ring, idx, calls), "smx_set_rand_state");
+      hmirror.clear(); smirror.clear();
+    }
     dim = _dim;
     std::vector<smx_layer> L(layers.size());
     for (size_t l = 0; l < layers.size(); l++)
@@ -255,15 +283,8 @@ class Layermap {
   Layermap(int SEED, ivec2 _dim) {                                                                  // layermap.h:219-222
     pool.reserve(POOLSIZE);
     pool.free.ctx = &ctx;
-    smx_config cfg;
-    cfg.dimx = _dim.x; cfg.dimy = _dim.y; cfg.scale = SCALE; cfg.device = 0; cfg.pool_capacity = (uint64_t)POOLSIZE;
-    const char* e = getenv("SMX_ENGINE");
-    cfg.engine = (e && std::string(e) == "serial") ? SMX_ENGINE_SERIAL : SMX_ENGINE_SPECULATIVE;
-    cfg.reserved = 0;
     dim = _dim;
-    int rc = smx_create(&cfg, &ctx);
-    if (rc != 0) { cout << "soilmx: smx_create failed: " << (ctx ? smx_last_error(ctx) : "") << endl; exit(1); }
-    upload_tables();
+    create_context(_dim);
     check(smx_srand(ctx, (uint32_t)SEED), "smx_srand");        // the host has just called srand(SEED) (SoilMachine.cpp:41)
     initialize(SEED, _dim);
   }

@@ -863,6 +863,19 @@ int smx_rand(smx_ctx* ctx, int32_t* out) {
   return 0;
 }
 
+int smx_get_rand_state(smx_ctx* ctx, uint32_t ring31[31], uint32_t* idx, uint64_t* calls) {
+  RandState r;
+  HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  memcpy(ring31, r.ring, sizeof(r.ring)); if (idx) *idx = r.idx; if (calls) *calls = r.calls;
+  return 0;
+}
+int smx_set_rand_state(smx_ctx* ctx, const uint32_t ring31[31], uint32_t idx, uint64_t calls) {
+  RandState r; memcpy(r.ring, ring31, sizeof(r.ring)); r.idx = idx; r.calls = calls;
+  HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
 int smx_rand_advance(smx_ctx* ctx, uint64_t ndraws) {
   RandState r;
   HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));

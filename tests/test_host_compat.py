@@ -24,7 +24,7 @@ FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(SOILS, "*.soi
 def dump_soils(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("dump") / "dump_soils")
     subprocess.check_call(["g++", "-std=c++20", "-O1", "-w", "-I" + os.path.join(ROOT, "tools", "hoststub"),
-                           "-I" + os.path.join(ROOT, "oracle", "shim"), "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "soilmachine_amd", "compat"), "-o", exe,
                            os.path.join(ROOT, "tools", "dump_soils.cpp"), "-L" + os.path.join(ROOT, "soilmachine_amd"),
                            "-lsoilmx", "-Wl,-rpath," + os.path.join(ROOT, "soilmachine_amd")])
