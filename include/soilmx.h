@@ -176,7 +176,7 @@ int smx_set_batch_strips(smx_ctx* ctx, int32_t nstrips, int32_t inset, int32_t s
  *                     (`children` = BChild records: u64 key, i32 tx,ty,bx,by,spill,pad, f64 volume), answers what this rank
  *                     knows about each child's `contains` (0xFFFFFFFF = random cell not in my strip; ranks combine by min)
  *   smx_d_gen_spawn   constructs the particles; those outside [own_x0, own_x1) live on another rank
- *   smx_d_chunk       16 epochs; the schedule follows the GLOBAL number of running particles; chunks alternate INTERIOR /
+ *   smx_d_chunk       32 epochs; the schedule follows the GLOBAL number of running particles; chunks alternate INTERIOR /
  *                     SEAM (smx_d_next_phase tells which comes next: 0 interior, 1 seam)
  *   smx_d_gen_end     counters + this rank's newly spawned children
  * smx_d_pack_columns / _particles serialise the changed halo columns (dirty 4x4 tiles with x in [x0,x1)) and the running

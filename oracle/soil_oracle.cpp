@@ -652,7 +652,7 @@ struct so_ctx {
   //     touch (+ a margin of `dilate` tiles); the lowest slot wins a tile; a particle acts in an epoch iff it
   //     holds every tile of its reservation, and may go on (<= maxsteps actions) while the next action stays
   //     inside the tiles it holds; (dilate, maxsteps) follow from the number of running particles at the start
-  //     of every 16-epoch chunk (b_schedule);
+  //     of every 32-epoch chunk (b_schedule);
   //   * nested particles are deferred: children sorted by (parent slot << 8 | sequence) form the next generation
   //     and take the rand() draws after the current generation's;
   //   * grid pass: 9 colour passes over tiles (tx mod 3, ty mod 3), cells of a tile x-major, active set fixed at
@@ -660,7 +660,7 @@ struct so_ctx {
   // Acting order inside an epoch is irrelevant by construction (winners own disjoint tiles); this
   // restatement walks slots in ascending order.
   // =====================================================================================================
-  static constexpr int B_GRID = 2, B_MAXCHILD = 24;   // grid pass: 4x4-cell tiles
+  static constexpr int B_GRID = 2, B_MAXCHILD = 24, B_CHUNK = 32;   // grid pass: 4x4-cell tiles
   int B_TILE = 2;                                   // claim granularity of the running chunk (b_schedule): tiles of 2^B_TILE cells
   struct BRect { int tx0, tx1, ty0, ty1; bool empty() const { return tx1 < tx0; } };
   struct BChild { uint64_t key; int tx, ty, bx, by, spill; double volume; };
@@ -695,9 +695,8 @@ struct so_ctx {
       tshift = 2; dilate = 1; maxsteps = 8;
       if (nlive <= 4096u) { tshift = 3; dilate = 1; maxsteps = 32; }
     } else {
-      tshift = 1; dilate = 0; maxsteps = 1;
-      if (nlive > b_cell_above) tshift = 0;
-      if (nlive <= 2048u) { tshift = 1; dilate = 1; maxsteps = 4; }
+      tshift = 2; dilate = 0; maxsteps = 4;
+      if (nlive > b_cell_above) { tshift = 0; maxsteps = 1; }
     }
     if (base > dilate) dilate = base;
   }
@@ -822,7 +821,7 @@ struct so_ctx {
             q.claiming = q.state != B_DONE && b_eligible(q.rect);
           }
         }
-        for (int k = 0; k < 16; k++, epoch++) {
+        for (int k = 0; k < B_CHUNK; k++, epoch++) {
           b_winners(sl, tilemin, win);
           for (uint32_t i = 0; i < nslots; i++) {
             if (!win[i]) continue;
@@ -868,7 +867,7 @@ struct so_ctx {
             if (q.state == B_DONE) q.rect = {0, -1, 0, -1};
           }
         }
-        b_epochs += 16;
+        b_epochs += B_CHUNK;
         nlive = 0;
         for (const BSlot& q : sl) if (q.state != B_DONE) nlive++;
       }

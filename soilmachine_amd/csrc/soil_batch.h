@@ -32,14 +32,17 @@ namespace smx {
 constexpr int GRID_SHIFT = 2;                 // the grid pass works on 4x4-cell tiles (one cascade reaches 4 cells)
 constexpr uint32_t B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3;   // B_NEW: top-level particle that has not acted yet
 constexpr uint32_t B_AWAY = 4;               // column strips on several devices: the particle currently lives on another device
+constexpr int B_CHUNK = 32;                   // epochs between two looks at the number of running particles (schedule, compaction)
 constexpr int B_MAXCHILD = 24;                // nested particles one flood / one grid tile may emit per pass
 
 struct BRect { int tx0, tx1, ty0, ty1; };     // inclusive tile ranges; tx1 < tx0: empty
 
 // c_*: this slot's share of the step / cascade counters (summed into DevState::ctr when the generation ends: an atomic
 // per particle and epoch on five shared words would serialise the whole epoch)
-struct BWater { Water w; BRect rect; uint32_t state, toplevel; uint32_t c_steps, c_casc, c_tr, pad; };
-struct BWind { Wind d; BRect rect; uint32_t state, pad; uint32_t c_steps, c_casc, c_tr, pad2; };
+// hint/pnx/pny: latency only (never read by the schedule): the particle acted in the previous epoch, and where its look-ahead
+// says the next step lands -- so the blocks of that step can be requested together with the reservation words.
+struct BWater { Water w; BRect rect; uint32_t state, toplevel; uint32_t c_steps, c_casc, c_tr, hint; int pnx, pny; };
+struct BWind { Wind d; BRect rect; uint32_t state, hint; uint32_t c_steps, c_casc, c_tr, pad2; int pnx, pny; };
 struct BChild {                               // a nested WaterParticle waiting for the next generation
   unsigned long long key;                     // (parent << 8) | sequence: the deterministic order of the children
   int tx, ty, bx, by, spill, pad;
@@ -259,7 +262,7 @@ SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
   // reference constructs a particle right before it runs, so it sees what earlier particles did to that cell. (A nested
   // particle takes it from a random cell somewhere on the map, water.h:251 -- that read happens here, where nothing writes.)
   q.w = w; q.state = child ? B_RUN : B_NEW;
-  q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad = 0;
+  q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.hint = 0; q.pnx = -1; q.pny = -1;
   q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_water_reclaim
   if (w.ix < bs.own_x0 || w.ix >= bs.own_x1) q.state = B_AWAY;
 }
@@ -278,7 +281,7 @@ SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
   const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
   Wind d;
   sim.wind_init(d, rx, ry);
-  q.d = d; q.pad = 0; q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad2 = 0;
+  q.d = d; q.hint = 0; q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad2 = 0; q.pnx = -1; q.pny = -1;
   q.state = B_NEW;                                           // `contains` (wind.h:19-21) is read when the particle first acts
   q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_wind_reclaim
   if (d.ix < bs.own_x0 || d.ix >= bs.own_x1) q.state = B_AWAY;
@@ -328,11 +331,21 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
   if (state == B_DONE || state == B_AWAY) return;
   BRect rect = q.rect;
   const int cur = (int)(epoch & 1u), nxt = cur ^ 1;
+  // A particle that acted in the previous epoch is, as a rule, the head of its queue and holds again: request the two
+  // blocks of its next step NOW, together with the reservation words, instead of after them (two dependent memory round
+  // trips less on the chain that bounds a phase). If it does hold, nobody else writes those cells in this kernel, so what
+  // was read early is current; if not, the values are dropped.
+  Blk A, B;
+  bool haveA = false, haveB = false;
+  const int pbx = q.pnx, pby = q.pny;
+  if (q.hint && (state == B_RUN || state == B_NEW)) {
+    sim.template load_block<0>(q.w.ix, q.w.iy, A); haveA = true;
+    if (pbx >= 0) { sim.template load_block<0>(pbx, pby, B); haveB = true; }
+  }
+  uint32_t hint = 0; int pnx = -1, pny = -1;
   if (bholds(bs, cur, rect, btag(epoch, slot))) {
     const BRect held = rect;
     Water w = q.w;
-    Blk A, B;
-    bool haveA = false;
     int acted = 0;
     while (true) {
       BRect need;
@@ -346,7 +359,11 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
       }
       // reserve it for the next epoch. The margin is for particles that TRAVEL (it buys them several steps per epoch);
       // a flood is a particle's last action, and floods crowd together on lake shores: no margin there.
-      if (acted >= bs.maxsteps || !brect_contains(held, need)) { rect = (state == B_ENDED) ? need : bdilate(bs, need); break; }
+      if (acted >= bs.maxsteps || !brect_contains(held, need)) {
+        rect = (state == B_ENDED) ? need : bdilate(bs, need);
+        if (state != B_ENDED && mv) { pnx = (int)roundf(t.pos.x); pny = (int)roundf(t.pos.y); }
+        break;
+      }
       acted++;
       if (state == B_NEW) {                                  // WaterParticle(map) water.h:15-17, on the map as it is NOW
         t.contains = sim.soils[Sim<P>::vsurf(A.v8)].transports;   // (move() does not look at `contains`: the look-ahead stands)
@@ -356,7 +373,9 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
         sim.water_move_commit(w, mv, q.toplevel != 0u, A);   // water.h:43-73: the look-ahead becomes the move (track word, counters)
         w = t;
         if (mv) {
-          const int r = sim.water_interact(w, A, B);         // water.h:75-121
+          const bool pre = haveB && (int)roundf(w.pos.x) == pbx && (int)roundf(w.pos.y) == pby;   // the block requested early is the one needed
+          haveB = false;
+          const int r = sim.water_interact(w, A, B, pre);    // water.h:75-121
           if (r == 0) state = B_ENDED;
           else { A = B; haveA = true; }                      // B = the exact block around the new ipos
         } else state = B_ENDED;
@@ -373,10 +392,13 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
     if (acted) bmark_dirty(s, bs, held);
     if (state == B_DONE) rect = BRect{0, -1, 0, -1};
     q.rect = rect;
+    hint = (acted && state != B_DONE) ? 1u : 0u;
     sim.flush_counters();
     q.c_steps += sim.pol.a_steps; q.c_casc += sim.pol.a_casc; q.c_tr += sim.pol.a_tr;
     sim.pol.a_steps = sim.pol.a_casc = sim.pol.a_tr = 0;
   }
+  if (q.hint != hint) q.hint = hint;
+  if (hint) { q.pnx = pnx; q.pny = pny; }
   if (state != B_DONE && beligible(s, bs, rect)) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
 }
 
@@ -387,11 +409,13 @@ SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
   if (state == B_DONE || state == B_AWAY) return;
   BRect rect = q.rect;
   const int cur = (int)(epoch & 1u), nxt = cur ^ 1;
+  Blk A, B;
+  bool haveA = false;
+  if (q.hint && (state == B_RUN || state == B_NEW)) { sim.template load_block<1>(q.d.ix, q.d.iy, A); haveA = true; }   // (see batch_water_epoch)
+  uint32_t hint = 0;
   if (bholds(bs, cur, rect, btag(epoch, slot))) {
     const BRect held = rect;
     Wind d = q.d;
-    Blk A, B;
-    bool haveA = false;
     int acted = 0;
     while (true) {
       if (!haveA) sim.template load_block<1>(d.ix, d.iy, A);
@@ -415,10 +439,12 @@ SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
     if (acted) bmark_dirty(sim.s, bs, held);
     if (state == B_DONE) rect = BRect{0, -1, 0, -1};
     q.rect = rect;
+    hint = (acted && state != B_DONE) ? 1u : 0u;
     sim.flush_counters();
     q.c_steps += sim.pol.a_steps; q.c_casc += sim.pol.a_casc; q.c_tr += sim.pol.a_tr;
     sim.pol.a_steps = sim.pol.a_casc = sim.pol.a_tr = 0;
   }
+  if (q.hint != hint) q.hint = hint;
   if (state != B_DONE && beligible(sim.s, bs, rect)) bclaim(bs, nxt, rect, btag(epoch + 1u, slot));
 }
 
@@ -426,8 +452,8 @@ SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
 // granularity, margin and actions per epoch as a function of how many particles are still running when a chunk of
 // epochs starts. Measured on the MI355X (profiles/r02_batched_schedules.md):
 //   water  what limits a phase is particles EXCLUDING each other -- they drain into the same pits and queue there, one
-//          step per epoch and neighbourhood -- so reservations stay tight (2x2-cell tiles, no margin, one action per
-//          epoch); only the last few thousand get a small margin and up to 4 actions per epoch.
+//          particle per epoch and neighbourhood -- so reservations get no margin; 4x4-cell tiles leave enough slack for
+//          the particle at the head of a queue to take up to 4 steps per launch without widening anybody's exclusion.
 //   wind   particles travel far (up to ~13 000 steps, 2-3 cells each) and rarely meet: wide tiles with a margin buy a
 //          lone particle up to 32 steps per kernel launch.
 // `fine_above`: water reserves single cells while more particles than this are running (default: never; the tests lower it).
@@ -443,9 +469,8 @@ SMX_HD BSched batch_schedule(bool wind, uint32_t nlive, int base_dilate, uint32_
     k.tshift = 2; k.dilate = 1; k.maxsteps = 8;
     if (nlive <= 4096u) { k.tshift = 3; k.dilate = 1; k.maxsteps = 32; }
   } else {
-    k.tshift = 1; k.dilate = 0; k.maxsteps = 1;
-    if (nlive > fine_above) k.tshift = 0;
-    if (nlive <= 2048u) { k.tshift = 1; k.dilate = 1; k.maxsteps = 4; }
+    k.tshift = 2; k.dilate = 0; k.maxsteps = 4;
+    if (nlive > fine_above) { k.tshift = 0; k.maxsteps = 1; }
   }
   if (base_dilate > k.dilate) k.dilate = base_dilate;
   return k;

@@ -1315,7 +1315,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     else hipLaunchKernelGGL(k_batch_spawn<false>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_batch_iota, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs.live, nslots);
     uint32_t nlive = nslots, epoch = 0, chunk = 0;
-    static const int CHUNK = [] { const char* e = getenv("SMX_BATCH_CHUNK"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
+    static const int CHUNK = [] { const char* e = getenv("SMX_BATCH_CHUNK"); int v = e ? atoi(e) : B_CHUNK; return v < 1 ? 1 : v; }();
     static const bool trace = [] { const char* e = getenv("SMX_TRACE_BATCH"); return e && atoi(e) != 0; }();
     while (nlive > 0) {
       BSched sc = batch_schedule(wind, nlive, ctx->batch_dilate);
@@ -1511,15 +1511,15 @@ int smx_d_chunk(smx_ctx* ctx, uint32_t nlive_global, uint32_t* nlive_local) {
       if (wind) hipLaunchKernelGGL(k_batch_reclaim<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch);
       else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch);
     }
-    PhaseTimer tk(ctx, wind ? 5 : 4, 16u);
-    for (int k = 0; k < 16; k++) {
+    PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)B_CHUNK);
+    for (int k = 0; k < B_CHUNK; k++) {
       if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k);
       else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k);
     }
   }
-  ctx->d_epoch += 16;
+  ctx->d_epoch += B_CHUNK;
   hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
-  ctx->batch_epochs += 16;
+  ctx->batch_epochs += B_CHUNK;
   return d_compact(ctx, nlive_local);
 }
 int smx_d_gen_end(smx_ctx* ctx, void* children_out, uint32_t cap, uint32_t* n) {

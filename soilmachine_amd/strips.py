@@ -1,7 +1,7 @@
 """Column strips: ONE layermap sharded over several devices (batched engine only; DESIGN.md "Multi-GPU").
 
 The map is cut into x-strips (Layermap index is x*dimy + y, layermap.h:151: an x-strip is one contiguous block). The
-batched engine's schedule alternates two kinds of 16-epoch chunks (csrc/soil_batch.h BStrips):
+batched engine's schedule alternates two kinds of 32-epoch chunks (csrc/soil_batch.h BStrips):
 
   INTERIOR  a particle acts iff its whole reservation lies `a` cells inside one strip  -> strips touch disjoint cells,
             every rank runs its own, nothing is exchanged;

@@ -405,7 +405,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
           if (wind) batch_wind_reclaim(sim, bs, bs.live[i], epoch); else batch_water_reclaim(sim, bs, bs.live[i], epoch);
         }, shuffle ? shuffle + 5 : 0);
       }
-      for (int k = 0; k < 16; k++, epoch++) {
+      for (int k = 0; k < B_CHUNK; k++, epoch++) {
         parallel_for(nlive, nthreads, [&](uint32_t i) {
           BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
           Frame st[MAX_FRAMES];
@@ -417,7 +417,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       uint32_t m = 0;
       for (uint32_t i = 0; i < nslots; i++) { const uint32_t st_ = wind ? b.wind[i].state : b.water[i].state; if (st_ != B_DONE && st_ != B_AWAY) b.live[m++] = i; }
       nlive = m;
-      g_batch_stats[0] += 16;
+      g_batch_stats[0] += B_CHUNK;
     }
     g_batch_stats[1]++;
     if (getenv("HS_TRACE_BATCH")) fprintf(stderr, "[hostsim] batched %s generation: %u slots, %u epochs\n", wind ? "wind" : "water", nslots, epoch);
@@ -518,7 +518,7 @@ void hs_d_gen_spawn(hs_ctx* c, const uint32_t* contains, uint32_t* nlive_local) 
   *nlive_local = m;
 }
 int hs_d_next_phase(hs_ctx* c) { DPhase& d = dp_of(c); return d.b.bs.strips.n > 1 ? (int)(d.chunk & 1u) : STRIP_INTERIOR; }
-// one chunk of 16 epochs; the schedule follows the GLOBAL number of running particles
+// one chunk of B_CHUNK epochs; the schedule follows the GLOBAL number of running particles
 void hs_d_chunk(hs_ctx* c, uint32_t nlive_global, uint32_t* nlive_local) {
   DPhase& d = dp_of(c); const DevState& s = c->d; BatchBuffers& b = d.b; const BatchShared& bs = b.bs;
   uint32_t nlive = 0;                                        // residents that run: rebuild the list (particles may have arrived / left)
@@ -535,7 +535,7 @@ void hs_d_chunk(hs_ctx* c, uint32_t nlive_global, uint32_t* nlive_local) {
       BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
       if (d.wind) batch_wind_reclaim(sim, bs, bs.live[i], d.epoch); else batch_water_reclaim(sim, bs, bs.live[i], d.epoch);
     }
-  for (int k = 0; k < 16; k++, d.epoch++)
+  for (int k = 0; k < B_CHUNK; k++, d.epoch++)
     for (uint32_t i = 0; i < nlive; i++) {
       BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
       Frame st[MAX_FRAMES];
