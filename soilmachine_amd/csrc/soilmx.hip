@@ -269,15 +269,25 @@ __global__ void __launch_bounds__(64) k_batch_reclaim(DevState s, BatchShared bs
   if constexpr (WIND) batch_wind_reclaim(sim, bs, bs.live[i], epoch); else batch_water_reclaim(sim, bs, bs.live[i], epoch);
 }
 template <bool WIND>
-__global__ void __launch_bounds__(64) k_batch_epoch(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch) {
+__global__ void __launch_bounds__(64) k_batch_epoch(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch, uint32_t lpw) {
   SMX_LOAD_SOILS(sh)
-  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-  if (i >= nlive) return;
+  // `lpw` particles per wavefront (batch_lanes_per_wave): a wavefront costs the UNION of its lanes' paths, and the chip has
+  // 1024 SIMDs -- a phase that is down to a few thousand particles runs them one per wavefront instead of 64.
+  const uint32_t i = blockIdx.x * lpw + threadIdx.x;
+  if (threadIdx.x >= lpw || i >= nlive) return;
   BatchPolicy pol(s, bs);
   Sim<BatchPolicy> sim(s, sh, pol);
   if constexpr (WIND) batch_wind_epoch(sim, bs, bs.live[i], epoch);
   else { Frame st[MAX_FRAMES]; batch_water_epoch(sim, bs, bs.live[i], epoch, st); }
   sim.flush_counters(); pol.finish(s);
+}
+// how many particles share a wavefront: as few as fill `SMX_BATCH_WAVES` wavefronts (default 256 = one per CU; 0 = always 64;
+// measured in profiles/r02_batched_schedules.md, sweep 5). Which lane runs a slot has no influence on results.
+static uint32_t batch_lanes_per_wave(uint32_t nlive) {
+  static const uint32_t waves = [] { const char* e = getenv("SMX_BATCH_WAVES"); return e ? (uint32_t)atoi(e) : 256u; }();
+  if (!waves) return 64u;
+  const uint32_t l = (nlive + waves - 1u) / waves;
+  return l < 1u ? 1u : (l > 64u ? 64u : l);
 }
 // rebuild the list of slots that still run (order is irrelevant: a slot's identity is its index, not its lane)
 template <bool WIND>
@@ -1258,8 +1268,10 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
     const size_t nt = ctx->ncells;                          // one claim word per cell: enough for every granularity
     HIPCHK(hipMalloc(&bs.claim[0], nt * 8)); HIPCHK(hipMalloc(&bs.claim[1], nt * 8));
     HIPCHK(hipMalloc(&bs.ctrl, BC_COUNT * 4)); HIPCHK(hipMemsetAsync(bs.ctrl, 0, BC_COUNT * 4, ctx->stream));
-    bs.child_cap = 1u << 20; HIPCHK(hipMalloc(&bs.children, (size_t)bs.child_cap * sizeof(BChild)));
-    bs.freed_cap = 1u << 22; HIPCHK(hipMalloc(&bs.freed, (size_t)bs.freed_cap * 4));
+    // nested particles of one generation / pool nodes released in one chunk: sized by the map (a grid pass over a map full
+    // of lakes emits children for a sizeable part of its cells); running out is counted (children_lost) / an error (freed)
+    bs.child_cap = (uint32_t)std::max<size_t>((size_t)1 << 20, ctx->ncells / 2); HIPCHK(hipMalloc(&bs.children, (size_t)bs.child_cap * sizeof(BChild)));
+    bs.freed_cap = (uint32_t)std::max<size_t>((size_t)1 << 22, ctx->ncells / 2); HIPCHK(hipMalloc(&bs.freed, (size_t)bs.freed_cap * 4));
     {
       const size_t ngt = (size_t)((ctx->cfg.dimx + 3) >> 2) * ((ctx->cfg.dimy + 3) >> 2);
       HIPCHK(hipMalloc(&bs.dirty, ngt)); HIPCHK(hipMemsetAsync(bs.dirty, 0, ngt, ctx->stream));
@@ -1348,10 +1360,11 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
       const uint32_t live_in = nlive;
       {
         PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)CHUNK);   // CHUNK back-to-back launches of the epoch kernel, nothing else
-        const unsigned nbl = (nlive + 63u) / 64u;
+        const uint32_t lpw = batch_lanes_per_wave(nlive);
+        const unsigned nbl = (nlive + lpw - 1u) / lpw;
         for (int k = 0; k < CHUNK; k++, epoch++) {
-          if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
-          else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+          if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+          else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
         }
       }
       hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);   // frees of the chunk go back on the stack
@@ -1512,9 +1525,11 @@ int smx_d_chunk(smx_ctx* ctx, uint32_t nlive_global, uint32_t* nlive_local) {
       else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch);
     }
     PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)B_CHUNK);
+    const uint32_t lpw = batch_lanes_per_wave(nlive);
+    const unsigned nbe = (nlive + lpw - 1u) / lpw;
     for (int k = 0; k < B_CHUNK; k++) {
-      if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k);
-      else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k);
+      if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbe), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k, lpw);
+      else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbe), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k, lpw);
     }
   }
   ctx->d_epoch += B_CHUNK;

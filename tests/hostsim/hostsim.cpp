@@ -416,6 +416,11 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       batch_merge_freed(c, b);
       uint32_t m = 0;
       for (uint32_t i = 0; i < nslots; i++) { const uint32_t st_ = wind ? b.wind[i].state : b.water[i].state; if (st_ != B_DONE && st_ != B_AWAY) b.live[m++] = i; }
+      if (getenv("HS_TRACE_BATCH") && atoi(getenv("HS_TRACE_BATCH")) > 1) {
+        unsigned long long acc[4] = {0, 0, 0, 0}; uint32_t mx = 0;
+        for (uint32_t i = 0; i < nslots; i++) { batch_slot_counters(bs, wind, i, acc); const uint32_t cs = wind ? b.wind[i].c_steps : b.water[i].c_steps; if (cs > mx) mx = cs; }
+        fprintf(stderr, "[hostsim] %s slots %u chunk %u live %u -> %u tshift %d maxsteps %d steps %llu maxsteps_slot %u\n", wind ? "wind" : "water", nslots, chunk, nlive, m, sc.tshift, sc.maxsteps, acc[0], mx);
+      }
       nlive = m;
       g_batch_stats[0] += B_CHUNK;
     }

@@ -58,6 +58,28 @@ def _expected_export(heights, scale):
     return (q.astype(np.float64) / np.sqrt(2.0)).astype(np.float32)   # / sqrt(2) (double), then vec4(float)
 
 
+def _soil_colors(path, names):
+    """COLOR of every SOIL block, ordered like `names` (the soilmap order of the parsed file; io.h:25-35 hexcol: two hex
+    digits per channel / 255.0f, alpha 1); the built-in Air entry is surface.h:41-51; a SOIL block without COLOR keeps
+    SurfParam's default grey."""
+    cols = {"Air": np.array([0.0, 0.2, 0.4, 1.0], np.float32)}
+    cur = None
+    for line in open(path):
+        line = line.split("#")[0].strip()
+        w = line.split()
+        if len(w) >= 2 and w[0] == "SOIL":
+            cur = np.array([0.5, 0.5, 0.5, 1.0], np.float32)
+            name = line[4:].split("{")[0].strip()
+        elif line == "}" and cur is not None:
+            cols[name] = cur
+            cur = None
+        elif cur is not None and len(w) >= 2 and w[0] == "COLOR":
+            h = w[1]
+            rgb = [np.float32(16 * "0123456789ABCDEF".index(h[2 * k]) + "0123456789ABCDEF".index(h[2 * k + 1])) for k in range(3)]
+            cur = (np.array(rgb + [np.float32(255.0)], np.float32) / np.float32(255.0)).astype(np.float32)
+    return np.stack([cols[n] for n in names])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("soil,ticks", [("default.soil", 20), ("rockgravelpebblessand.soil", 3)])
 def test_unmodified_host_runs_and_matches_reference(tmp_path, soil, ticks):
@@ -66,7 +88,7 @@ def test_unmodified_host_runs_and_matches_reference(tmp_path, soil, ticks):
     from oracle_lib import Oracle
     cfg = load_cfg(soil)
     env = dict(os.environ, TICKS=str(ticks))
-    out = subprocess.run([HOST, "-SEED", "0", "-soil", os.path.join(SOILS, soil), "-oh", "h"], cwd=tmp_path, env=env,
+    out = subprocess.run([HOST, "-SEED", "0", "-soil", os.path.join(SOILS, soil), "-oh", "h", "-oc", "c"], cwd=tmp_path, env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     got = np.fromfile(tmp_path / "h.f32", dtype=np.float32)
@@ -77,3 +99,13 @@ def test_unmodified_host_runs_and_matches_reference(tmp_path, soil, ticks):
     want = _expected_export(o.heights(), cfg.SCALE)
     assert got.shape == want.shape
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # exportcolor (io.h:234-242): the vertex colour of Layermap::update (layermap.h:475-528, SLICE = 2*SCALE: no cut) =
+    # the soil colour of the top section, Air's for an empty column; written as (b, g, r, 1)
+    rgba = np.fromfile(tmp_path / "c.rgba.f32", dtype=np.float32).reshape(-1, 4)
+    snap = o.snapshot()
+    end = np.cumsum(snap.count.astype(np.int64))
+    top = np.where(snap.count > 0, snap.type[np.maximum(end - 1, 0)], 0).astype(np.int64)
+    col = _soil_colors(os.path.join(SOILS, soil), [sp.name for sp in cfg.soils])
+    wantc = np.concatenate([col[top][:, [2, 1, 0]], np.ones((top.size, 1), np.float32)], axis=1)
+    assert np.array_equal(rgba.view(np.uint32), wantc.view(np.uint32))
+    assert len(np.unique(top)) > 1 or soil == "default.soil"

@@ -44,4 +44,10 @@ if a.cpu:
     T = a.warm + a.ticks
     out["cpu_lean_whole_run"] = dict(ms_tick=1e3 * (j["t_water"] + j["t_grid"] + j["t_wind"] + j["t_freq"]) / T, ms_water=1e3 * j["t_water"] / T,
                                      ms_grid=1e3 * j["t_grid"] / T, wall_s=time.time() - t0, nsec=j["nsec"], typehash=j["typehash"])
+    if a.warm > 0:                                            # the same WINDOW the GPU line times: (run to warm+ticks) - (run to warm)
+        j0 = run_ref(os.path.join(ROOT, "soilmachine_amd", "soils", a.soil), seed=0, size=a.size, ticks=a.warm, nwater=nw,
+                     nwind=a.nwind, wind=a.nwind > 0, lean=True, pool=max(10_000_000, 4 * a.size * a.size))
+        d = lambda k: 1e3 * (j[k] - j0[k]) / a.ticks
+        out["cpu_lean_timed_window"] = dict(ms_tick=d("t_water") + d("t_grid") + d("t_wind") + d("t_freq"), ms_water=d("t_water"), ms_grid=d("t_grid"),
+                                            ticks=[a.warm, a.warm + a.ticks])
 print("RESULT " + json.dumps(out))
