@@ -89,12 +89,21 @@ class Layermap {
   //      in reference order when the next phase starts (INTEGRATION.md "How the unmodified loop batches")
   int pending_water = 0, pending_wind = 0;
   smx_ctx* handle() { return ctx; }
-  void touch() { dirty = true; }
+  void touch() { dirty = true; vstale = true; }
+  // The reference keeps the vertex pool current edit by edit (add/remove/cascade call update(ivec2, vertexpool)); here the
+  // edits happen in device batches, so the pool is brought up to date once per batch, at the first host call after it that
+  // carries the pool (WaterParticle::seep(map, pool), the particle methods): the renderer and the exporters of the host's
+  // own io.h (io.h:234-252) read it without calling update(). SMX_LAZY_VERTICES=1 leaves it to explicit update() calls.
+  bool vstale = false;
+  void present(Vertexpool<Vertex>& vertexpool) {
+    static const bool lazy = [] { const char* e = getenv("SMX_LAZY_VERTICES"); return e && atoi(e) != 0; }();
+    if (section != NULL && vstale && !lazy) update(vertexpool);
+  }
   void flush_water() {
-    if (pending_water) { check(smx_tick_water(ctx, pending_water), "smx_tick_water"); pending_water = 0; dirty = true; }
+    if (pending_water) { check(smx_tick_water(ctx, pending_water), "smx_tick_water"); pending_water = 0; dirty = true; vstale = true; }
   }
   void flush_wind() {
-    if (pending_wind) { check(smx_tick_wind(ctx, pending_wind), "smx_tick_wind"); pending_wind = 0; dirty = true; }
+    if (pending_wind) { check(smx_tick_wind(ctx, pending_wind), "smx_tick_wind"); pending_wind = 0; dirty = true; vstale = true; }
   }
   void flush() { flush_water(); flush_wind(); }
   void upload_tables() {                      // soils[] and SCALE are live-editable from the GUI (SoilMachine.cpp:118,167-186)
@@ -212,30 +221,21 @@ class Layermap {
     if (hmirror[c] == 0.0 && ty == 0) vertexpool.fill(section, (int)c, vec3(p.x, 0, p.y), vec3(0, 1, 0), soils[0].color, 0);
     else vertexpool.fill(section, (int)c, vec3(p.x, SCALE * hmirror[c], p.y), normal(p), soils[ty].color, (int)ty);
   }
+  // The whole map in one device pass (smx_fill_vertices_cut writes the 44-byte records straight into the pool's memory). A
+  // section is one bucket of contiguous vertices -- in the host tree's own pool (source/include/vertexpool.h:97-100: start of
+  // the persistently mapped buffer + baseVert + k) as in any stand-in -- so get(section, 0) is the destination.
   void update(Vertexpool<Vertex>& vertexpool) {                                                     // layermap.h:551-555
     if (section == NULL) return;
     refresh();
     static_assert(sizeof(Vertex) == 44, "Vertex is the 44-byte record smx_fill_vertices writes");
-    if (vertexpool.store.size() >= (size_t)*section + (size_t)dim.x * dim.y) {   // contiguous section: one device pass
-      std::vector<float> col(4 * soils.size());
-      for (size_t k = 0; k < soils.size(); k++) { col[4 * k] = soils[k].color.x; col[4 * k + 1] = soils[k].color.y; col[4 * k + 2] = soils[k].color.z; col[4 * k + 3] = soils[k].color.w; }
-      check(smx_fill_vertices_cut(ctx, col.data(), (int32_t)soils.size(), 0, (double)SLICE, vertexpool.get(section, 0)), "smx_fill_vertices_cut");   // SLICE cut: layermap.h:477-510
-      return;
-    }
-    std::vector<float> nrm((size_t)dim.x * dim.y * 3);
-    check(smx_normals(ctx, nrm.data()), "smx_normals");
-    for (int i = 0; i < dim.x; i++)
-      for (int j = 0; j < dim.y; j++) {
-        const size_t c = (size_t)i * dim.y + j;
-        const uint32_t ty = smirror[c];
-        if (hmirror[c] == 0.0 && ty == 0) vertexpool.fill(section, (int)c, vec3(i, 0, j), vec3(0, 1, 0), soils[0].color, 0);
-        else vertexpool.fill(section, (int)c, vec3(i, SCALE * hmirror[c], j), vec3(nrm[3 * c], nrm[3 * c + 1], nrm[3 * c + 2]), soils[ty].color, (int)ty);
-      }
+    std::vector<float> col(4 * soils.size());
+    for (size_t k = 0; k < soils.size(); k++) { col[4 * k] = soils[k].color.x; col[4 * k + 1] = soils[k].color.y; col[4 * k + 2] = soils[k].color.z; col[4 * k + 3] = soils[k].color.w; }
+    check(smx_fill_vertices_cut(ctx, col.data(), (int32_t)soils.size(), 0, (double)SLICE, vertexpool.get(section, 0)), "smx_fill_vertices_cut");   // SLICE cut: layermap.h:477-510
+    vstale = false;
   }
   void slice(Vertexpool<Vertex>& vertexpool, double s = SCALE) {                                    // layermap.h:557-613
     if (section == NULL) return;
     refresh();
-    if (vertexpool.store.size() < (size_t)*section + (size_t)dim.x * dim.y) { update(vertexpool); return; }
     std::vector<float> col(4 * soils.size());
     for (size_t k = 0; k < soils.size(); k++) { col[4 * k] = soils[k].color.x; col[4 * k + 1] = soils[k].color.y; col[4 * k + 2] = soils[k].color.z; col[4 * k + 3] = soils[k].color.w; }
     check(smx_fill_vertices_cut(ctx, col.data(), (int32_t)soils.size(), 1, s, vertexpool.get(section, 0)), "smx_fill_vertices_cut");

@@ -43,10 +43,11 @@ struct WaterParticle : public Particle {
     if (smx_seep(map.handle(), ipos.x, ipos.y) != 0) { cout << "soilmx: " << smx_last_error(map.handle()) << endl; exit(1); }
     map.touch();
   }
-  static void seep(Layermap& map, Vertexpool<Vertex>&) {                            // water.h:335-343: flush + grid pass
+  static void seep(Layermap& map, Vertexpool<Vertex>& vertexpool) {                 // water.h:335-343: flush + grid pass
     map.flush();
     if (smx_grid_pass(map.handle()) != 0) { cout << "soilmx: " << smx_last_error(map.handle()) << endl; exit(1); }
     map.touch();
+    map.present(vertexpool);
   }
 
   static float* frequency;

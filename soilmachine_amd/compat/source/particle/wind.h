@@ -1,6 +1,8 @@
 // compat/source/particle/wind.h -- drop-in for wind.h:11-140 (WindParticle).
 // `WindParticle particle(map)` counts a spawn request; the batch of NWIND particles runs on the device as soon as
-// the host's wind loop has issued the last one (SoilMachine.cpp:303-307), in reference order.
+// the host's wind loop has issued the last one (SoilMachine.cpp:303-307), in reference order. NWIND is read at every
+// request (the GUI can only change it between two passes of the loop, where nothing is pending); whatever is still pending
+// is flushed by the next observation of the map anyway (Layermap::flush).
 #include "particle.h"
 
 using namespace glm;
@@ -31,7 +33,7 @@ struct WindParticle : public Particle {
   static void refresh(Layermap& map) {                                              // host mirror of wind.h:48 for the GUI texture
     if (frequency) smx_read_frequency(map.handle(), NULL, NULL, frequency);
   }
-  bool move(Layermap&, Vertexpool<Vertex>&) { return false; }                       // wind.h:54-92  (runs in the batch)
+  bool move(Layermap& map, Vertexpool<Vertex>& vertexpool) { map.present(vertexpool); return false; }   // wind.h:54-92 (runs in the batch; the call after the flush brings the pool up to date)
   bool interact(Layermap&, Vertexpool<Vertex>&) { return false; }                   // wind.h:94-136
 };
 

@@ -405,13 +405,22 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
           if (wind) batch_wind_reclaim(sim, bs, bs.live[i], epoch); else batch_water_reclaim(sim, bs, bs.live[i], epoch);
         }, shuffle ? shuffle + 5 : 0);
       }
+      static FILE* estats = getenv("HS_EPOCH_STATS") ? fopen(getenv("HS_EPOCH_STATS"), "w") : nullptr;   // analysis only
+      std::vector<uint32_t> pc, ps; std::vector<uint32_t> pst;
       for (int k = 0; k < B_CHUNK; k++, epoch++) {
+        if (estats && !wind) { pc.resize(nlive); ps.resize(nlive); pst.resize(nlive); for (uint32_t i = 0; i < nlive; i++) { const BWater& q = b.water[bs.live[i]]; pc[i] = q.c_casc; ps[i] = q.c_steps; pst[i] = q.state; } }
         parallel_for(nlive, nthreads, [&](uint32_t i) {
           BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
           Frame st[MAX_FRAMES];
           if (wind) batch_wind_epoch(sim, bs, bs.live[i], epoch); else batch_water_epoch(sim, bs, bs.live[i], epoch, st);
           sim.flush_counters(); pol.finish(s);
         }, shuffle ? shuffle + 11 + epoch : 0);
+        if (estats && !wind) {
+          uint32_t actors = 0, done = 0, maxc = 0, maxs = 0; unsigned long long sumc = 0, sums = 0;
+          for (uint32_t i = 0; i < nlive; i++) { const BWater& q = b.water[bs.live[i]]; const uint32_t dc = q.c_casc - pc[i], ds = q.c_steps - ps[i];
+            if (ds || dc || q.state != pst[i]) actors++; if (q.state == B_DONE && pst[i] != B_DONE) done++; if (dc > maxc) maxc = dc; if (ds > maxs) maxs = ds; sumc += dc; sums += ds; }
+          fprintf(estats, "%u %u %u %u %u %u %llu %llu %u\n", nslots, epoch, nlive, actors, done, maxc, sumc, sums, maxs);
+        }
       }
       batch_merge_freed(c, b);
       uint32_t m = 0;

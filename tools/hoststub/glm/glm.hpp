@@ -23,8 +23,8 @@ template <typename T> struct tvec3;
 template <typename T> struct tvec4;
 
 template <typename T> struct tvec2 {
-  T x, y;
-  tvec2() : x(0), y(0) {}
+  T x{}, y{};
+  constexpr tvec2() = default;
   template <typename S, typename = std::enable_if_t<std::is_arithmetic_v<S>>> tvec2(S s) : x(static_cast<T>(s)), y(static_cast<T>(s)) {}
   template <typename A, typename B> tvec2(A a, B b) : x(static_cast<T>(a)), y(static_cast<T>(b)) {}
   template <typename U> tvec2(const tvec2<U>& v) : x(static_cast<T>(v.x)), y(static_cast<T>(v.y)) {}
@@ -35,8 +35,8 @@ template <typename T> struct tvec2 {
 };
 
 template <typename T> struct tvec3 {
-  T x, y, z;
-  tvec3() : x(0), y(0), z(0) {}
+  T x{}, y{}, z{};
+  constexpr tvec3() = default;
   template <typename S, typename = std::enable_if_t<std::is_arithmetic_v<S>>> tvec3(S s) : x(static_cast<T>(s)), y(static_cast<T>(s)), z(static_cast<T>(s)) {}
   template <typename A, typename B, typename C>
   tvec3(A a, B b, C c) : x(static_cast<T>(a)), y(static_cast<T>(b)), z(static_cast<T>(c)) {}
@@ -50,8 +50,8 @@ template <typename T> struct tvec3 {
 };
 
 template <typename T> struct tvec4 {
-  T x, y, z, w;
-  tvec4() : x(0), y(0), z(0), w(0) {}
+  T x{}, y{}, z{}, w{};
+  constexpr tvec4() = default;   // (constexpr: `new vec4[N]{...}` of the host's lbmwind.h must not expand into N constructor calls)
   template <typename S, typename = std::enable_if_t<std::is_arithmetic_v<S>>> tvec4(S s)
       : x(static_cast<T>(s)), y(static_cast<T>(s)), z(static_cast<T>(s)), w(static_cast<T>(s)) {}
   template <typename A, typename B, typename C, typename D>
@@ -103,6 +103,9 @@ template <typename T> tvec3<T> operator-(const tvec3<T>& a) { return tvec3<T>(-a
 template <typename T> tvec4<T> operator+(const tvec4<T>& a, const tvec4<T>& b) { return tvec4<T>(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 template <typename T> tvec4<T> operator*(const tvec4<T>& a, T s) { return tvec4<T>(a.x * s, a.y * s, a.z * s, a.w * s); }
 template <typename T> tvec4<T> operator/(const tvec4<T>& a, T s) { return tvec4<T>(a.x / s, a.y / s, a.z / s, a.w / s); }
+template <typename T> tvec4<T> operator*(const tvec4<T>& a, const tvec4<T>& b) { return tvec4<T>(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+template <typename T> tvec4<T> operator/(const tvec4<T>& a, const tvec4<T>& b) { return tvec4<T>(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+template <typename T> tvec4<T> operator-(const tvec4<T>& a, const tvec4<T>& b) { return tvec4<T>(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 // ---- common ----
 inline vec2 floor(const vec2& v) { return vec2(std::floor(v.x), std::floor(v.y)); }
@@ -142,6 +145,14 @@ inline mat4 operator*(const mat4& a, const mat4& b) {
   for (int c = 0; c < 4; c++) for (int rr = 0; rr < 4; rr++) { float s = 0; for (int k = 0; k < 4; k++) s += a.m[k * 4 + rr] * b.m[c * 4 + k]; r.m[c * 4 + rr] = s; }
   return r;
 }
+
+// render-side matrix builders the host tree's own scene.h / lbmwind.h name (values are never looked at headless)
+template <typename T = float> mat4 ortho(T, T, T, T, T, T) { return mat4(1.0f); }
+template <typename A, typename B, typename C> mat4 lookAt(const A&, const B&, const C&) { return mat4(1.0f); }
+template <typename V> mat4 scale(const mat4& m, const V&) { return m; }
+template <typename V> mat4 translate(const mat4& m, const V&) { return m; }
+template <typename V> mat4 rotate(const mat4& m, float, const V&) { return m; }
+inline float radians(float d) { return d * 0.017453292519943295f; }
 
 template <typename T> bvec2 greaterThanEqual(const tvec2<T>& a, const tvec2<T>& b) { return bvec2(a.x >= b.x, a.y >= b.y); }
 template <typename T> bvec2 lessThan(const tvec2<T>& a, const tvec2<T>& b) { return bvec2(a.x < b.x, a.y < b.y); }
