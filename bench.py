@@ -344,6 +344,9 @@ def main():
             "ms_per_tick": 1e3 * tmax / args.steps, "phase_ms_per_tick": head["phase_ms_per_tick"],
             "steps_per_tick": head["steps_per_tick"], "engine_stats": head["engine_stats"], "digest": head["digest"],
             "roofline": roofline, "cpu_baseline": cpu, "lines": lines,
+            # nothing was dropped inside the timed region (nested particles that did not fit the children buffer, sediment
+            # that found no pool node): a line with work skipped would not be a measurement
+            "work_dropped": {"children_lost": int(head["engine_stats"].get("children_lost", 0)), "pool_overflow": int(head.get("pool_overflow") or 0)},
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -2,6 +2,7 @@
 more than one tick on the device, against digests produced by the reference itself (tests/golden/make_golden.py).
 Bit-exact: section count, type hash, sequential sum of heights, number of rand() draws."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -62,6 +63,15 @@ def test_8192_config4_init_one_tick_reference_digest_and_invariants():
     """BASELINE configs[4]: 8192^2 rockgravelpebbles_big -- terrain + one tick bit-exact, structural invariants."""
     sm = run_case("rgpbig8192_t1", capi.ENGINE_SPECULATIVE)
     column_invariants(sm.map.snapshot())
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("SMX_DEEP"), reason="opt-in (SMX_DEEP=1): several GPU-minutes; result of this round's run in profiles/r02_depth_256x300.log")
+@pytest.mark.parametrize("case", ["default256_t300", "default256_t1000"])
+def test_appendix_e_default256_deep(case):
+    """Appendix E, default 256^2 at 300 / 1000 ticks: the wet regime (lakes, ~2500 nested particles per tick) in exact order.
+    The exact engine runs it at 0.3 - 1.5 s per tick, so it is not part of the default suite."""
+    run_case(case, capi.ENGINE_SPECULATIVE)
 
 
 # ---------------------------------------------------------------- entry points that had no test in round 1
