@@ -327,7 +327,7 @@ def main():
                 ln["steps"], ln["warmup"] = k_, w_
                 lines.append(ln)
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:             # (rank 0 at N=1 only: the other ranks would wait at the barrier for it)
             # bounded sample: an eighth of the headline's particle counts for one tick (CPU steps/s does not depend on the count)
             cw, cd = (max(nwater // 8, 1000), max(nwind // 8, 250 if nwind else 0)) if nwater > 8000 else (nwater, nwind)
             cpu = cpu_baseline(soil, n, cw, cd, args.cpu_ticks, pool, all_cores=True)
