@@ -91,3 +91,55 @@ def test_unmodified_host_runs_and_matches_reference(tmp_path, soil, ticks):
     wantc = np.concatenate([col[top][:, [2, 1, 0]], np.ones((top.size, 1), np.float32)], axis=1)
     assert np.array_equal(rgba.view(np.uint32), wantc.view(np.uint32))
     assert len(np.unique(top)) > 1 or soil == "default.soil"
+
+
+PROBE = os.path.join(ROOT, "build", "host", "compat_probe")
+
+
+@pytest.mark.gpu
+def test_compat_queries_and_point_modifiers_through_the_class_api(tmp_path):
+    """The parts of the class API the reference's main() never calls (tools/compat_probe.cpp): Layermap::height(vec2),
+    normal(vec2) and the vertexpool variants (layermap.h:379-413), surface, top, add(pool.get(..)), remove, Particle::cascade --
+    after two ticks driven through the same classes. Expected values: the same operations through the C-ABI (each of which
+    is pinned to the oracle elsewhere) and, for normal(vec2), its float arithmetic restated on the per-cell normals."""
+    import ctypes as C
+    from soilmachine_amd.machine import SoilMachine
+    if not os.path.exists(PROBE):
+        pytest.skip("build/host/compat_probe not built (needs the reference tree at build time)")
+    soil = "rocksand.soil"
+    cfg = load_cfg(soil)
+    out = subprocess.run([PROBE, "-SEED", "4", "-soil", os.path.join(SOILS, soil), "-ticks", "2", "-o", "p.f64"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    got = np.fromfile(tmp_path / "p.f64", dtype=np.float64)
+    rest, rec = got[0], got[1:].reshape(-1, 17)
+    sm = SoilMachine(cfg, dimx=cfg.SIZEX, dimy=cfg.SIZEY, seed=4, nwater=cfg.NWATER, nwind=cfg.NWIND, pool=10_000_000)
+    sm.tick(2, sync=True)
+    m = sm.map
+    m.add(5, 7, 0.0125, 1)
+    assert m.remove(9, 3, 0.3) == rest
+    m._chk(m.L.smx_particle_cascade(m.h, C.c_float(20.4), C.c_float(11.6), 1))
+    nx, ny = cfg.SIZEX, cfg.SIZEY
+    pos = rec[:, 0:2].astype(np.float32)
+    k = np.arange(500, dtype=np.float32)
+    assert np.array_equal(pos[:, 0], np.fmod(k * np.float32(37.77), np.float32(nx - 2)) + np.float32(0.25))
+    assert np.array_equal(rec[:, 2], m.heights_bilinear(pos))                      # Layermap::height(vec2)
+    nrm = m.normals().reshape(nx, ny, 3)
+    ip = np.floor(pos).astype(np.int64)
+    w = (pos - np.floor(pos)).astype(np.float32)
+    one = np.float32(1.0)
+    want = np.zeros((500, 3), np.float32)
+    for wt, (dx, dy) in (((one - w[:, 0]) * (one - w[:, 1]), (0, 0)), ((one - w[:, 0]) * w[:, 1], (1, 0)),
+                         (w[:, 0] * (one - w[:, 1]), (0, 1)), (w[:, 0] * w[:, 1], (1, 1))):   # the reference's crossed weights (layermap.h:385-388)
+        want = (want + wt.astype(np.float32)[:, None] * nrm[ip[:, 0] + dx, ip[:, 1] + dy]).astype(np.float32)
+    assert np.array_equal(rec[:, 3:6].astype(np.float32).view(np.uint32), want.view(np.uint32))      # normal(vec2)
+    assert np.array_equal(rec[:, 6:9], rec[:, 3:6])                                # normal(vec2, vertexpool)
+    assert np.array_equal(rec[:, 9:12].astype(np.float32).view(np.uint32), nrm[ip[:, 0], ip[:, 1]].view(np.uint32))   # normal(ivec2, vertexpool)
+    s = m.snapshot()
+    end = np.cumsum(s.count.astype(np.int64))
+    c = ip[:, 0] * ny + ip[:, 1]
+    kk = end[c] - 1
+    assert (s.count[c] > 0).all()
+    assert np.array_equal(rec[:, 12], m.surface()[c].astype(np.float64))           # surface(ivec2)
+    assert np.array_equal(rec[:, 13], s.type[kk].astype(np.float64))               # top(ivec2)
+    assert np.array_equal(rec[:, 14], s.size[kk]) and np.array_equal(rec[:, 15], s.floor[kk]) and np.array_equal(rec[:, 16], s.sat[kk])

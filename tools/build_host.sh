@@ -25,3 +25,10 @@ g++ -std=c++20 -O2 -ffp-contract=off -Wfatal-errors -w \
     -o "$OUT/soilmachine_headless" "$OUT/SoilMachine.cpp" \
     -L"$ROOT/soilmachine_amd" -lsoilmx -Wl,-rpath,'$ORIGIN/../../soilmachine_amd'
 echo "built $OUT/soilmachine_headless"
+# a second host program on the same class API (queries / point modifiers main() never calls): tools/compat_probe.cpp
+ln -sfn "$ROOT/tools/compat_probe.cpp" "$OUT/compat_probe.cpp"
+g++ -std=c++20 -O2 -ffp-contract=off -Wfatal-errors -w \
+    -I"$ROOT/tools/hoststub" -I"$ROOT/include" \
+    -o "$OUT/compat_probe" "$OUT/compat_probe.cpp" \
+    -L"$ROOT/soilmachine_amd" -lsoilmx -Wl,-rpath,'$ORIGIN/../../soilmachine_amd'
+echo "built $OUT/compat_probe"
