@@ -1590,6 +1590,12 @@ int smx_d_unpack_columns(smx_ctx* ctx, const void* host_buf, uint64_t bytes) {
   uint32_t nrec, nb; memcpy(&nrec, hb, 4); memcpy(&nb, hb + 4, 4);
   if (nrec == 0) return 0;
   if (nrec > ctx->xoffs_cap || nb > ctx->xdata_cap || 8 + 4ull * nrec + nb > bytes) { ctx->err = "smx_d_unpack_columns: bad buffer"; return -2; }
+  for (uint32_t i = 0; i < nrec; i++) {                       // (the kernel follows these offsets and counts: they must stay inside the data)
+    uint32_t o, hd[2]; memcpy(&o, hb + 8 + 4ull * i, 4);
+    if ((uint64_t)o + 24 > nb) { ctx->err = "smx_d_unpack_columns: record offset outside the buffer"; return -2; }
+    memcpy(hd, hb + 8 + 4ull * nrec + o, 8);                  // {cell, section count}
+    if (hd[0] >= ctx->ncells || (uint64_t)o + 24 + 32ull * hd[1] > nb) { ctx->err = "smx_d_unpack_columns: bad record"; return -2; }
+  }
   HIPCHK(hipMemcpyAsync(ctx->d_xoffs, hb + 8, 4ull * nrec, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->d_xdata, hb + 8 + 4ull * nrec, nb, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_strip_unpack_columns, dim3((nrec + 63u) / 64u), dim3(64), 0, st, ctx->d, ctx->bs, ctx->d_xdata, ctx->d_xoffs, nrec);
