@@ -197,6 +197,34 @@ int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t tx_lo, int32_t tx_hi);
 int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost);
 void* smx_stream(smx_ctx* ctx);                          /* the hipStream_t all work is queued on */
 
+/* ---- LBM wind: the D3Q19 two-relaxation-time lattice Boltzmann solver the reference runs as OpenGL
+ * compute shaders (source/include/lbmwind/lbmwind.h:75-197; shader/LBM/{lbm,init,collide,stream}.cs; shader/move.cs). It is
+ * visual only in the reference (it never feeds WindParticle). A lattice is its own object; cell index (x*NY + y)*NZ + z and
+ * the distribution order F[cell*19 + q] at this boundary are the reference's (lbm.cs:8-26,60-80); on the device the
+ * distributions are stored direction-major and collide + stream are ONE kernel per step (csrc/soil_lbm.h).
+ *   smx_lbm_create / _destroy      lbmw::initialize's buffers (lbmwind.h:77-96) / lbmw::quit (:152-172)
+ *   smx_lbm_set_boundary           lbmw::b->fill(NX*NY*NZ, boundary) (lbmwind.h:89, SoilMachine.cpp:239): > 0 = solid
+ *   smx_lbm_boundary_from_map      SoilMachine.cpp:235-238 on the device: solid where map.height(ivec2(sx*x, sz*z)) > (sy*y)/SCALE
+ *   smx_lbm_initialize             init.cs (lbmwind.h:98-109)
+ *   smx_lbm_step(n)                n x { collide.cs; stream.cs } (lbmw::update, lbmwind.h:176-188); rho and v are those collide.cs
+ *                                  writes: the moments of the state the step started from
+ *   smx_lbm_read                   RHO (n floats), V (n vec4), F (n*19, reference order); any pointer may be NULL
+ *   smx_lbm_write_f                overwrite F (tests, restart)
+ *   smx_lbm_move                   move.cs on the caller's tracer array (n vec4, in place); the respawn of lbmwind.h:199-218 stays host code
+ *   smx_lbm_get_timing             HIP-event time of the step kernels since the last reset */
+typedef struct smx_lbm smx_lbm;
+int smx_lbm_create(int32_t nx, int32_t ny, int32_t nz, int32_t device, smx_lbm** out);
+void smx_lbm_destroy(smx_lbm* l);
+const char* smx_lbm_last_error(smx_lbm* l);
+int smx_lbm_set_boundary(smx_lbm* l, const float* boundary);
+int smx_lbm_boundary_from_map(smx_lbm* l, smx_ctx* map, float sx, float sy, float sz);
+int smx_lbm_initialize(smx_lbm* l);
+int smx_lbm_step(smx_lbm* l, int32_t n);
+int smx_lbm_read(smx_lbm* l, float* rho, float* v4, float* f);
+int smx_lbm_write_f(smx_lbm* l, const float* f);
+int smx_lbm_move(smx_lbm* l, float* pos4, int32_t n);
+int smx_lbm_get_timing(smx_lbm* l, double* ms_steps, uint64_t* steps, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

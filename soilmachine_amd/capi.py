@@ -58,6 +58,8 @@ SYMBOLS = [
     "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips",
     "smx_d_set_own", "smx_d_gen_begin", "smx_d_gen_spawn", "smx_d_next_phase", "smx_d_chunk", "smx_d_gen_end", "smx_d_pack_columns",
     "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep",
+    "smx_lbm_create", "smx_lbm_destroy", "smx_lbm_last_error", "smx_lbm_set_boundary", "smx_lbm_boundary_from_map", "smx_lbm_initialize",
+    "smx_lbm_step", "smx_lbm_read", "smx_lbm_write_f", "smx_lbm_move", "smx_lbm_get_timing",
 ]
 
 _lib = None
@@ -130,10 +132,21 @@ def load() -> C.CDLL:
     L.smx_d_grid_begin.argtypes = [vp]
     L.smx_d_grid_sweep.argtypes = [vp, i32, i32, i32]
     L.smx_get_batch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.smx_lbm_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+    L.smx_lbm_destroy.argtypes = [vp]; L.smx_lbm_destroy.restype = None
+    L.smx_lbm_last_error.argtypes = [vp]; L.smx_lbm_last_error.restype = C.c_char_p
+    L.smx_lbm_set_boundary.argtypes = [vp, vp]
+    L.smx_lbm_boundary_from_map.argtypes = [vp, vp, flt, flt, flt]
+    L.smx_lbm_initialize.argtypes = [vp]
+    L.smx_lbm_step.argtypes = [vp, i32]
+    L.smx_lbm_read.argtypes = [vp, vp, vp, vp]
+    L.smx_lbm_write_f.argtypes = [vp, vp]
+    L.smx_lbm_move.argtypes = [vp, vp, i32]
+    L.smx_lbm_get_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), i32]
     L.smx_stream.argtypes = [vp]; L.smx_stream.restype = vp
     for name in SYMBOLS:
         f = getattr(L, name)
-        if name not in ("smx_destroy", "smx_last_error", "smx_stream"):
+        if name not in ("smx_destroy", "smx_last_error", "smx_stream", "smx_lbm_destroy", "smx_lbm_last_error"):
             f.restype = C.c_int
     _lib = L
     return L

@@ -30,6 +30,7 @@
 #include "soil_coop.h"
 #include "soil_noise.h"
 #include "soil_batch.h"
+#include "soil_lbm.h"
 #include <algorithm>
 
 using namespace smx;
@@ -1829,4 +1830,130 @@ int smx_timing_reset(smx_ctx* ctx) {
   return 0;
 }
 
+}  // extern "C"
+
+// ---------------- LBM wind: lbmwind.h:75-197 + shader/LBM/*.cs, shader/move.cs -> soil_lbm.h ----------------
+#define LBMCHK(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess) { l->err = std::string(#call) + ": " + hipGetErrorString(e_); return -1; }  \
+  } while (0)
+extern "C" {
+void smx_lbm_destroy(smx_lbm* l) {
+  if (!l) return;
+  hipSetDevice(l->device);
+  if (l->stream) hipStreamSynchronize(l->stream);
+  hipFree(l->f[0]); hipFree(l->f[1]); hipFree(l->B); hipFree(l->rho); hipFree(l->v);
+  if (l->ev0) hipEventDestroy(l->ev0); if (l->ev1) hipEventDestroy(l->ev1);
+  if (l->stream) hipStreamDestroy(l->stream);
+  delete l;
+}
+const char* smx_lbm_last_error(smx_lbm* l) { return l ? l->err.c_str() : "null handle"; }
+int smx_lbm_create(int32_t nx, int32_t ny, int32_t nz, int32_t device, smx_lbm** out) {
+  if (!out) return -2;
+  smx_lbm* l = new smx_lbm;
+  *out = l;
+  if (nx < 2 || ny < 2 || nz < 2) { l->err = "smx_lbm_create: every dimension must be >= 2"; return -2; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { l->err = "no HIP device visible (soilmx has no CPU fallback)"; return -3; }
+  l->device = device; l->d.nx = nx; l->d.ny = ny; l->d.nz = nz; l->d.n = (unsigned long long)nx * ny * nz;
+  l->k = make_lbm_consts();
+  LBMCHK(hipSetDevice(device));
+  LBMCHK(hipStreamCreate(&l->stream));
+  LBMCHK(hipEventCreate(&l->ev0)); LBMCHK(hipEventCreate(&l->ev1));
+  const size_t n = (size_t)l->d.n;
+  LBMCHK(hipMalloc(&l->f[0], n * LQ * 4)); LBMCHK(hipMalloc(&l->f[1], n * LQ * 4));
+  LBMCHK(hipMalloc(&l->B, n * 4)); LBMCHK(hipMalloc(&l->rho, n * 4)); LBMCHK(hipMalloc(&l->v, n * 16));
+  LBMCHK(hipMemsetAsync(l->f[0], 0, n * LQ * 4, l->stream)); LBMCHK(hipMemsetAsync(l->f[1], 0, n * LQ * 4, l->stream));
+  LBMCHK(hipMemsetAsync(l->B, 0, n * 4, l->stream)); LBMCHK(hipMemsetAsync(l->rho, 0, n * 4, l->stream)); LBMCHK(hipMemsetAsync(l->v, 0, n * 16, l->stream));
+  LBMCHK(hipStreamSynchronize(l->stream));
+  return 0;
+}
+static unsigned lbm_grid(const smx_lbm* l) { const unsigned long long nb = (l->d.n + 255ull) / 256ull; return (unsigned)((nb + 7ull) / 8ull * 8ull); }
+int smx_lbm_set_boundary(smx_lbm* l, const float* b) {
+  LBMCHK(hipSetDevice(l->device));
+  LBMCHK(hipMemcpyAsync(l->B, b, (size_t)l->d.n * 4, hipMemcpyHostToDevice, l->stream));
+  LBMCHK(hipStreamSynchronize(l->stream));
+  return 0;
+}
+int smx_lbm_boundary_from_map(smx_lbm* l, smx_ctx* ctx, float sx, float sy, float sz) {
+  if (!ctx) { l->err = "smx_lbm_boundary_from_map: no map"; return -2; }
+  if (ctx->cfg.device != l->device) { l->err = "smx_lbm_boundary_from_map: map and lattice live on different devices"; return -2; }
+  if ((int)(sx * (float)(l->d.nx - 1)) >= ctx->cfg.dimx || (int)(sz * (float)(l->d.nz - 1)) >= ctx->cfg.dimy || sx < 0.f || sz < 0.f) {
+    l->err = "smx_lbm_boundary_from_map: the scaled lattice does not fit the map"; return -2;
+  }
+  if (ctx->plane_cap < ctx->ncells * 8) { hipFree(ctx->d_plane); ctx->d_plane = nullptr; ctx->plane_cap = 0; HIPCHK(hipMalloc(&ctx->d_plane, ctx->ncells * 8)); ctx->plane_cap = ctx->ncells * 8; }
+  hipLaunchKernelGGL(k_heights, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d, (double*)ctx->d_plane);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hipLaunchKernelGGL(k_lbm_boundary_from_heights, dim3((unsigned)((l->d.n + 255ull) / 256ull)), dim3(256), 0, l->stream, l->d, (const double*)ctx->d_plane,
+                     ctx->cfg.dimy, sx, sy, sz, ctx->cfg.scale, l->B);
+  LBMCHK(hipStreamSynchronize(l->stream));
+  return 0;
+}
+int smx_lbm_initialize(smx_lbm* l) {
+  LBMCHK(hipSetDevice(l->device));
+  l->cur = 0;
+  hipLaunchKernelGGL(k_lbm_init, dim3(lbm_grid(l)), dim3(256), 0, l->stream, l->d, l->k, l->B, l->f[0], l->rho, l->v);
+  LBMCHK(hipGetLastError());
+  return 0;
+}
+int smx_lbm_step(smx_lbm* l, int32_t n) {
+  LBMCHK(hipSetDevice(l->device));
+  if (n <= 0) return 0;
+  LBMCHK(hipEventRecord(l->ev0, l->stream));
+  for (int s = 0; s < n; s++) {
+    hipLaunchKernelGGL(k_lbm_step, dim3(lbm_grid(l)), dim3(256), 0, l->stream, l->d, l->k, l->B, l->f[l->cur], l->f[l->cur ^ 1], l->rho, l->v);
+    l->cur ^= 1;
+  }
+  LBMCHK(hipEventRecord(l->ev1, l->stream));
+  LBMCHK(hipGetLastError());
+  LBMCHK(hipEventSynchronize(l->ev1));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, l->ev0, l->ev1) == hipSuccess) { l->ms_steps += ms; l->steps += (unsigned long long)n; }
+  return 0;
+}
+int smx_lbm_get_timing(smx_lbm* l, double* ms_steps, uint64_t* steps, int32_t reset) {
+  if (ms_steps) *ms_steps = l->ms_steps;
+  if (steps) *steps = l->steps;
+  if (reset) { l->ms_steps = 0.0; l->steps = 0; }
+  return 0;
+}
+int smx_lbm_read(smx_lbm* l, float* rho, float* v4, float* f_aos) {
+  LBMCHK(hipSetDevice(l->device));
+  const size_t n = (size_t)l->d.n;
+  if (rho) LBMCHK(hipMemcpyAsync(rho, l->rho, n * 4, hipMemcpyDeviceToHost, l->stream));
+  if (v4) LBMCHK(hipMemcpyAsync(v4, l->v, n * 16, hipMemcpyDeviceToHost, l->stream));
+  if (f_aos) {                                                // the spare lattice is scratch between steps (a step writes every slot of it)
+    float* tmp = l->f[l->cur ^ 1];
+    hipLaunchKernelGGL(k_lbm_to_aos, dim3((unsigned)((n * LQ + 255) / 256)), dim3(256), 0, l->stream, l->d, l->f[l->cur], tmp);
+    LBMCHK(hipMemcpyAsync(f_aos, tmp, n * LQ * 4, hipMemcpyDeviceToHost, l->stream));
+  }
+  LBMCHK(hipStreamSynchronize(l->stream));
+  return 0;
+}
+int smx_lbm_write_f(smx_lbm* l, const float* f_aos) {
+  LBMCHK(hipSetDevice(l->device));
+  const size_t n = (size_t)l->d.n;
+  float* stage = nullptr;
+  LBMCHK(hipMalloc(&stage, n * LQ * 4));
+  hipError_t e = hipMemcpyAsync(stage, f_aos, n * LQ * 4, hipMemcpyHostToDevice, l->stream);
+  hipLaunchKernelGGL(k_lbm_from_aos, dim3((unsigned)((n * LQ + 255) / 256)), dim3(256), 0, l->stream, l->d, stage, l->f[l->cur]);
+  if (e == hipSuccess) e = hipStreamSynchronize(l->stream);
+  hipFree(stage);
+  if (e != hipSuccess) { l->err = hipGetErrorString(e); return -1; }
+  return 0;
+}
+int smx_lbm_move(smx_lbm* l, float* pos4, int32_t n) {
+  LBMCHK(hipSetDevice(l->device));
+  if (n <= 0) return 0;
+  float4* d = nullptr;
+  LBMCHK(hipMalloc(&d, (size_t)n * 16));
+  hipError_t e = hipMemcpyAsync(d, pos4, (size_t)n * 16, hipMemcpyHostToDevice, l->stream);
+  hipLaunchKernelGGL(k_lbm_move, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, l->stream, l->d, l->v, d, n);
+  if (e == hipSuccess) e = hipMemcpyAsync(pos4, d, (size_t)n * 16, hipMemcpyDeviceToHost, l->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(l->stream);
+  hipFree(d);
+  if (e != hipSuccess) { l->err = hipGetErrorString(e); return -1; }
+  return 0;
+}
 }  // extern "C"

@@ -86,6 +86,12 @@ def lib():
         L.so_batched_stats.argtypes = [vp, vp]
         L.so_noise_fbm.argtypes = [C.c_float] * 3 + [C.c_int] + [C.c_float] * 3
         L.so_noise_fbm.restype = C.c_float
+        L.lo_create.argtypes = [C.c_int] * 3; L.lo_create.restype = vp        # oracle/lbm_oracle.cpp
+        L.lo_destroy.argtypes = [vp]; L.lo_destroy.restype = None
+        L.lo_set_boundary.argtypes = [vp, vp]; L.lo_initialize.argtypes = [vp]; L.lo_step.argtypes = [vp, C.c_int]
+        L.lo_read.argtypes = [vp, vp, vp, vp]; L.lo_write_f.argtypes = [vp, vp]; L.lo_move.argtypes = [vp, vp, C.c_int]
+        for f in ("lo_set_boundary", "lo_initialize", "lo_step", "lo_read", "lo_write_f", "lo_move"):
+            getattr(L, f).restype = None
         _lib = L
     return _lib
 
@@ -194,3 +200,40 @@ def run_ref(soil: str, seed: int = 0, size: int = 0, ticks: int = 1, nwater: int
         if line.startswith("JSON "):
             return json.loads(line[5:])
     raise RuntimeError("soil_ref produced no JSON line:\n" + out)
+
+
+class LbmOracle:
+    """oracle/lbm_oracle.cpp: the reference's LBM shaders restated on the CPU (parity unpinned: see its header)."""
+    Q = 19
+
+    def __init__(self, nx, ny, nz):
+        self.L = lib()
+        self.nx, self.ny, self.nz, self.n = nx, ny, nz, nx * ny * nz
+        self.h = self.L.lo_create(nx, ny, nz)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.lo_destroy(self.h)
+            self.h = None
+
+    def set_boundary(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1)
+        assert b.size == self.n
+        self.L.lo_set_boundary(self.h, _p(b))
+
+    def initialize(self): self.L.lo_initialize(self.h)
+    def step(self, n=1): self.L.lo_step(self.h, n)
+
+    def read(self):
+        r, v, f = np.zeros(self.n, np.float32), np.zeros((self.n, 4), np.float32), np.zeros((self.n, 19), np.float32)
+        self.L.lo_read(self.h, _p(r), _p(v), _p(f))
+        return r, v, f
+
+    def write_f(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float32).reshape(-1)
+        self.L.lo_write_f(self.h, _p(f))
+
+    def move(self, pos4):
+        p = np.ascontiguousarray(pos4, dtype=np.float32).copy()
+        self.L.lo_move(self.h, _p(p), p.shape[0])
+        return p
