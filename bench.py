@@ -188,6 +188,27 @@ def measure_strips(cfg, n, nwater, nwind, pool, device, steps, warmup, dist, bar
     return r
 
 
+def measure_lbm(device, dims=(512, 320, 512), steps=40):
+    """Row f4 (LBM wind, csrc/soil_lbm.h): cell updates/s of the fused collide+stream kernel on a lattice that does not fit the
+    caches, HIP events around the step kernels; 176 algorithmic bytes per cell and step (19 + 19 distributions, mask, rho, v)."""
+    import numpy as np
+    from soilmachine_amd.lbm import LbmWind
+    nx, ny, nz = dims
+    g = LbmWind(nx, ny, nz, device=device)
+    b = np.zeros((nx, ny, nz), np.float32)
+    b[:, :ny // 8, :] = 1.0
+    g.set_boundary(b); g.initialize(); g.step(5); g.timing(reset=True)
+    g.step(steps)
+    tm = g.timing()
+    g.close()
+    us = 1e3 * tm["ms_steps"] / max(tm["steps"], 1)
+    gbs = nx * ny * nz * 176 / (us * 1e-6) / 1e9
+    return {"kernel": "k_lbm_step (D3Q19 TRT collide+stream fused; reference: lbmwind.h:174-188, shader/LBM/*.cs)", "lattice": f"{nx}x{ny}x{nz}",
+            "steps": int(tm["steps"]), "us_per_step": us, "cell_updates_per_s": nx * ny * nz / (us * 1e-6),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_cell_step": 176}}
+
+
 def line_of(r, name, workload, engine_name, steps):
     dt, tm = r["dt"], r["tm"]
     tot = r["steps_w"] + r["steps_d"]
@@ -326,6 +347,12 @@ def main():
                 ln = line_of(rr, nm, wl_, "exact (speculative)" if e_ == "spec" else "batched", k_)
                 ln["steps"], ln["warmup"] = k_, w_
                 lines.append(ln)
+        lbm = None
+        if not args.no_lines and world == 1:
+            try:
+                lbm = measure_lbm(local_rank)
+            except Exception as e:                                  # (an extra line must not take the headline down with it)
+                lbm = {"error": str(e)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:             # (rank 0 at N=1 only: the other ranks would wait at the barrier for it)
             # bounded sample: an eighth of the headline's particle counts for one tick (CPU steps/s does not depend on the count)
@@ -343,7 +370,7 @@ def main():
                                 "(what cpu_baseline can count)",
             "ms_per_tick": 1e3 * tmax / args.steps, "phase_ms_per_tick": head["phase_ms_per_tick"],
             "steps_per_tick": head["steps_per_tick"], "engine_stats": head["engine_stats"], "digest": head["digest"],
-            "roofline": roofline, "cpu_baseline": cpu, "lines": lines,
+            "roofline": roofline, "cpu_baseline": cpu, "lines": lines, "lbm_wind": lbm,
             # nothing was dropped inside the timed region (nested particles that did not fit the children buffer, sediment
             # that found no pool node): a line with work skipped would not be a measurement
             "work_dropped": {"children_lost": int(head["engine_stats"].get("children_lost", 0)), "pool_overflow": int(head.get("pool_overflow") or 0)},

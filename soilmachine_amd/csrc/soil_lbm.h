@@ -16,8 +16,9 @@
 //     value (the cell copies it across itself), the five driven faces are overwritten with the forcing equilibrium AFTER
 //     streaming (neighbours do not push into them, the face cell writes all 19 itself) -- the order the shader's race
 //     (stream.cs:9-36) is meant to have and the one oracle/lbm_oracle.cpp restates;
-//   * blockIdx is remapped so that each of the 8 XCDs sweeps one contiguous eighth of the lattice: the +-1-row / +-1-plane
-//     pushes of neighbouring workgroups then meet in the same L2.
+//   * two launch variants were measured and are OFF by default (profiles/r02_lbm_bench.log): blockIdx remapped so that each of
+//     the 8 XCDs sweeps one contiguous eighth of the lattice (SMX_LBM_XCD=1: no reuse to win in a pure stream -- equal or
+//     slower), and non-temporal hints on the 38 lattice accesses (SMX_LBM_NT=1: equal or slower).
 // Arithmetic: float32, the shader's statement order, no contraction; constants that involve sqrt/div are computed on the
 // host once (make_lbm_consts) so that device and oracle use identical bit patterns.
 #pragma once
@@ -102,14 +103,18 @@ __global__ void __launch_bounds__(256) k_lbm_init(LbmDims d, LbmConsts k, const 
   v[i] = make_float4(vx / r, vy / r, vz / r, 1.0f);
 }
 
-// collide.cs + stream.cs fused: lattice `a` (F) -> lattice `b`
+// collide.cs + stream.cs fused: lattice `a` (F) -> lattice `b`. NT: the 38 lattice accesses carry the non-temporal hint (each
+// byte is touched once per step); XCD: the blockIdx remap above. Both are measured switches (SMX_LBM_NT / SMX_LBM_XCD), off.
+template <bool NT> __device__ __forceinline__ float lbm_ld(const float* p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
+template <bool NT> __device__ __forceinline__ void lbm_st(float* p, float x) { if constexpr (NT) __builtin_nontemporal_store(x, p); else *p = x; }
+template <bool NT, bool XCD>
 __global__ void __launch_bounds__(256) k_lbm_step(LbmDims d, LbmConsts k, const float* __restrict__ B, const float* __restrict__ a, float* __restrict__ b,
                                                   float* __restrict__ rho, float4* __restrict__ v) {
-  const unsigned long long i = lbm_block() * 256ull + threadIdx.x;
+  const unsigned long long i = (XCD ? lbm_block() : (unsigned long long)blockIdx.x) * 256ull + threadIdx.x;
   if (i >= d.n) return;
   const int z = (int)(i % (unsigned)d.nz), y = (int)((i / (unsigned)d.nz) % (unsigned)d.ny), x = (int)(i / ((unsigned long long)d.nz * d.ny));
   float F[LQ];
-  LbmUnroll<LQ - 1>::run([&](auto qc) { constexpr int q = decltype(qc)::value; F[q] = a[(unsigned long long)q * d.n + i]; });
+  LbmUnroll<LQ - 1>::run([&](auto qc) { constexpr int q = decltype(qc)::value; F[q] = lbm_ld<NT>(a + ((unsigned long long)q * d.n + i)); });
   const bool solid = B[i] > 0.0f;
   float r = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
   LbmUnroll<LQ - 1>::run([&](auto qc) { constexpr int q = decltype(qc)::value; r += F[q]; });                     // getRho lbm.cs:109-116
@@ -132,12 +137,12 @@ __global__ void __launch_bounds__(256) k_lbm_step(LbmDims d, LbmConsts k, const 
     const int ax = x + lcx(q), ay = y + lcy(q), az = z + lcz(q);
     const bool inside = !(ax < 0 || ax >= d.nx || ay < 0 || ay >= d.ny || az < 0 || az >= d.nz);
     if (inside && !lbm_driven(d, ax, ay, az))
-      b[(unsigned long long)q * d.n + (unsigned long long)((long long)i + ((long long)lcx(q) * d.ny + lcy(q)) * d.nz + lcz(q))] = out;
+      lbm_st<NT>(b + ((unsigned long long)q * d.n + (unsigned long long)((long long)i + ((long long)lcx(q) * d.ny + lcy(q)) * d.nz + lcz(q))), out);
     // my own slot q: driven face -> forcing equilibrium (stream.cs:33-34); no source for direction q -> the old value stays
     const int sx = x - lcx(q), sy = y - lcy(q), sz = z - lcz(q);
     const bool has_source = !(sx < 0 || sx >= d.nx || sy < 0 || sy >= d.ny || sz < 0 || sz >= d.nz);
-    if (me_driven) b[(unsigned long long)q * d.n + i] = l_equilibrium<q>(k, 1.0f, k.force[0], k.force[1], k.force[2]);
-    else if (!has_source) b[(unsigned long long)q * d.n + i] = F[q];
+    if (me_driven) lbm_st<NT>(b + ((unsigned long long)q * d.n + i), l_equilibrium<q>(k, 1.0f, k.force[0], k.force[1], k.force[2]));
+    else if (!has_source) lbm_st<NT>(b + ((unsigned long long)q * d.n + i), F[q]);
   });
 }
 

@@ -1901,8 +1901,19 @@ int smx_lbm_step(smx_lbm* l, int32_t n) {
   LBMCHK(hipSetDevice(l->device));
   if (n <= 0) return 0;
   LBMCHK(hipEventRecord(l->ev0, l->stream));
+  static const int variant = [] {                             // measured switches (profiles/r02_lbm_bench.log); results do not depend on them
+    const char* a = getenv("SMX_LBM_NT"); const char* b = getenv("SMX_LBM_XCD");
+    return ((a ? atoi(a) != 0 : false) ? 1 : 0) | ((b ? atoi(b) != 0 : false) ? 2 : 0);
+  }();
   for (int s = 0; s < n; s++) {
-    hipLaunchKernelGGL(k_lbm_step, dim3(lbm_grid(l)), dim3(256), 0, l->stream, l->d, l->k, l->B, l->f[l->cur], l->f[l->cur ^ 1], l->rho, l->v);
+    const dim3 g(lbm_grid(l)), t(256);
+    float *fa = l->f[l->cur], *fb = l->f[l->cur ^ 1];
+    switch (variant) {
+      case 0: hipLaunchKernelGGL((k_lbm_step<false, false>), g, t, 0, l->stream, l->d, l->k, l->B, fa, fb, l->rho, l->v); break;
+      case 1: hipLaunchKernelGGL((k_lbm_step<true, false>), g, t, 0, l->stream, l->d, l->k, l->B, fa, fb, l->rho, l->v); break;
+      case 2: hipLaunchKernelGGL((k_lbm_step<false, true>), g, t, 0, l->stream, l->d, l->k, l->B, fa, fb, l->rho, l->v); break;
+      default: hipLaunchKernelGGL((k_lbm_step<true, true>), g, t, 0, l->stream, l->d, l->k, l->B, fa, fb, l->rho, l->v); break;
+    }
     l->cur ^= 1;
   }
   LBMCHK(hipEventRecord(l->ev1, l->stream));
