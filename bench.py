@@ -22,10 +22,11 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
   * "cpu_baseline": the reference's own CPU loop (oracle/_ref/soil_ref_lean = the unmodified reference headers,
     render-only Layermap::update elided) timed on this box's host: 1 core on a bounded sample of the headline
     workload, and an all-cores line (independent processes, different SEEDs -- the reference has no threads).
-  * N > 1: one process per GPU. The batched engine (default) shards the ONE map into N column strips
-    (soilmachine_amd/strips.py: halo columns + migrating particles point to point over RCCL, live count by all-reduce;
-    same total work at every N: "scaling": "strong"). The exact engines do not shard (sequential semantics): with
-    --engine spec/serial the ranks run independent replicas (SEED = rank, "weak").
+  * N > 1: one process per GPU. The batched engine (default) runs ONE map in N column strips (soilmachine_amd/strips.py: halo
+    columns + migrating particles point to point over RCCL, live count by all-reduce). Default "scaling": "weak" -- the map is
+    (N*size) x size, every GPU owns a size x size strip and its share of N x the particles, so per-GPU work is the N=1 line's;
+    --strong splits the N=1 map instead ("strong"). The exact engines do not shard (sequential semantics): with --engine
+    spec/serial the ranks run independent replicas (SEED = rank, "weak").
 """
 from __future__ import annotations
 
@@ -156,7 +157,7 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
     return r
 
 
-def measure_strips(cfg, n, nwater, nwind, pool, device, steps, warmup, dist, barrier, torch):
+def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dist, barrier, torch):
     """ONE map sharded into world-size column strips (soilmachine_amd/strips.py): every rank holds a context with the
     full-size map, initialises the terrain itself and keeps its strip + halo current; halo columns and migrating
     particles travel point to point over RCCL (backend nccl), the live-particle count by all-reduce."""
@@ -164,9 +165,9 @@ def measure_strips(cfg, n, nwater, nwind, pool, device, steps, warmup, dist, bar
     from soilmachine_amd.machine import Layermap
     from soilmachine_amd.strips import DeviceStripBackend, StripGeometry, StripRank, TorchComm
     world = dist.get_world_size()
-    m = Layermap(cfg, n, n, seed=0, pool=pool, device=device, engine=capi.ENGINE_BATCHED)
+    m = Layermap(cfg, dimx, n, seed=0, pool=pool, device=device, engine=capi.ENGINE_BATCHED)
     dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
-    rk = StripRank(DeviceStripBackend(m, buf_mb=256), TorchComm(dist, dev if dist.get_backend() == "nccl" else None), StripGeometry(n, world))
+    rk = StripRank(DeviceStripBackend(m, buf_mb=256), TorchComm(dist, dev if dist.get_backend() == "nccl" else None), StripGeometry(dimx, world))
     for _ in range(warmup):
         rk.tick(nwater, nwind, True, nwind > 0)
     m.sync()
@@ -239,6 +240,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lines", action="store_true", help="only the headline measurement")
     ap.add_argument("--cpu-ticks", type=int, default=1)
+    ap.add_argument("--strong", action="store_true", help="N > 1: keep the map at --size^2 and split it (default: the map grows with N)")
     args = ap.parse_args()
 
     import torch
@@ -274,8 +276,15 @@ def main():
         torch.cuda.synchronize()
 
     strips = world > 1 and eng_name == "batched"
+    dimx = n
     if strips:
-        r = measure_strips(cfg, n, nwater, nwind, pool, local_rank, args.steps, args.warmup, dist, barrier, torch)
+        # ONE map in `world` column strips. Default (weak scaling): the map grows with N -- every GPU owns a size x size strip of
+        # a (N*size) x size map and its share of N x the particles, i.e. per-GPU work is what the N=1 line measures. --strong
+        # keeps the N=1 map and splits it: the phases are latency chains, which a smaller strip does not shorten.
+        if not args.strong:
+            dimx, nwater, nwind = n * world, nwater * world, nwind * world
+            pool = max(10_000_000, 3 * dimx * n)
+        r = measure_strips(cfg, dimx, n, nwater, nwind, pool, local_rank, args.steps, args.warmup, dist, barrier, torch)
     else:
         r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier)
     steps = r["steps_w"] + r["steps_d"]
@@ -323,7 +332,7 @@ def main():
                             "phase is particles excluding each other where they drain together (pits, lake shores) and the longest single "
                             "particle, not bandwidth (DESIGN.md). The O(cells) kernels are the HBM-streaming ones (phases)."}
 
-        workload = (f"{n}x{n} layermap, soil/{soil}, SEED 0, nwater={nwater}, nwind={nwind} per tick"
+        workload = (f"{dimx}x{n} layermap{f' (one map, {world} column strips of {dimx // world}x{n})' if strips else ''}, soil/{soil}, SEED 0, nwater={nwater}, nwind={nwind} per tick"
                     f"{' (area-scaled, SURVEY 8d)' if eng_name == 'batched' and args.nwater is None else ''}, "
                     f"tick = water + grid pass + wind + frequency")
         head = line_of(r, "headline", workload, eng_name, args.steps)
@@ -361,7 +370,7 @@ def main():
         out = {
             "metric": "particle-steps/s", "value": total_steps / tmax, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True,
-            "scaling": "strong" if strips else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if (strips and args.strong) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "engine": eng_name,
                        "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
                        "parity": head["parity"]},
