@@ -222,6 +222,13 @@ def line_of(r, name, workload, engine_name, steps):
         "steps_per_tick": {"water": r["steps_w"] / steps, "wind": r["steps_d"] / steps, "nested_particles": r["nested"] / steps,
                            "floods": r["floods"] / steps},
         "engine_stats": r["engine_stats"], "digest": r["digest"], "pool_overflow": r["pool_overflow"],
+        # particle kernels of this line against the HBM roofline: algorithmic bytes (192 B per water step, 256 B per wind step,
+        # SURVEY 8d) over the HIP-event time of nothing but those kernels
+        "roofline_particles": {
+            k: ({"achieved": nb / (ms * 1e-3) / 1e9, "unit": "GB/s", "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": ln}
+                if ms > 0 else None)
+            for k, nb, ms, ln in (("water", r["steps_w"] * B_WATER_STEP, tm["ms_kernel_water"], tm["launches_kernel_water"]),
+                                  ("wind", r["steps_d"] * B_WIND_STEP, tm["ms_kernel_wind"], tm["launches_kernel_wind"]))},
         "parity": "bit-exact vs the reference (tests/golden)" if engine_name != "batched" else
                   "P2: deterministic, bit-exact vs its CPU restatement, statistical vs the reference",
     }
@@ -350,6 +357,16 @@ def main():
                 for e in ("spec", "batched"):
                     extra.append((f"{nm}_{'exact' if e == 'spec' else e}", dcfg, "default.soil", 1024, 250, wind, e, 10_000_000, k3, w3,
                                   f"1024x1024, soil/default.soil, NWATER=250, NWIND={wind} (BASELINE {nm.split('_')[0]})"))
+            if eng_name == "batched":
+                # the same density on larger maps: the phases are latency chains of about constant length, so the
+                # rate grows with the area. configs[4]'s map size with its own soil file and with the headline's.
+                bcfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", "rockgravelpebbles_big.soil"))
+                for nm, c_, s_, n_ in (("configs4_8192_rockgravelpebbles_big_batched", bcfg, "rockgravelpebbles_big.soil", 8192),
+                                       ("area_8192_batched", cfg, soil, 8192), ("area_16384_batched", cfg, soil, 16384)):
+                    a_ = (n_ / 256.0) ** 2
+                    nw_, nd_ = int(250 * a_), int(250 * a_ * c_.NWIND / max(c_.NWATER, 1))
+                    extra.append((nm, c_, s_, n_, nw_, nd_, "batched", max(10_000_000, 3 * n_ * n_), 2, 1,
+                                  f"{n_}x{n_}, soil/{s_}, area-scaled NWATER={nw_} / NWIND={nd_}"))
             for (nm, c_, s_, n_, nw_, nd_, e_, pool_, k_, w_, wl_) in extra:
                 eng_ = {"spec": capi.ENGINE_SPECULATIVE, "batched": capi.ENGINE_BATCHED}[e_]
                 rr = measure(c_, s_, n_, 0, nw_, nd_, nd_ > 0, eng_, pool_, local_rank, k_, w_)
@@ -373,6 +390,10 @@ def main():
             "scaling": "strong" if (strips and args.strong) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "engine": eng_name,
                        "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
+                       "scaling_note": (None if world == 1 else ("--strong: the N=1 map split into N strips" if (strips and args.strong) else
+                                        "weak: one (N*size) x size map, every GPU owns a size x size strip and 1/N of N x the particles "
+                                        "(per-GPU work = the N=1 line); the particle phases are latency chains, so splitting the N=1 map "
+                                        "(--strong) cannot shorten a tick (DESIGN.md 7)") if strips else "independent replicas (exact engines do not shard)"),
                        "parity": head["parity"]},
             "value_top_level": head["value_top_level"] if world == 1 else None,
             "steps_definition": "value: move()==true + interact(), top-level AND nested particles; value_top_level: top-level only "
