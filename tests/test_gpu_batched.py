@@ -111,3 +111,25 @@ def test_4096_batched_determinism_invariants_and_statistics():
     assert abs(ca["steps_wind"] - ce["steps_wind"]) < 0.05 * ce["steps_wind"]
     assert abs(da["sumh"] - de["sumh"]) < 1e-5 * de["sumh"]
     assert abs(da["nsec"] - de["nsec"]) < 0.01 * de["nsec"]
+
+
+@pytest.mark.slow
+def test_256_default_1000_ticks_in_the_wet_regime_equal_restated_schedule():
+    """Depth: 1000 ticks of BASELINE configs[0]'s map (256^2 default.soil, 250 particles per tick, hydraulic only) -- lakes from
+    tick ~60 on, > 10^6 nested particles, > 10^6 epochs -- device == restated schedule on the full state, every 250 ticks."""
+    cfg = load_cfg("default.soil")
+    n, nw = 256, 250
+    sm = SoilMachine(cfg, n, seed=0, nwater=nw, nwind=0, dowind=False, engine=capi.ENGINE_BATCHED)
+    o = Oracle(cfg, n, n, seed=0)
+    o.initialize()
+    for block in range(4):
+        sm.tick(250, sync=True)
+        for _ in range(250):
+            o.batched_tick(nw, 0, True, False)
+        bad = compare(sm.map.snapshot(), o.snapshot())
+        assert not bad, f"after {250 * (block + 1)} ticks: {bad}"
+    cd, co = sm.map.counters(), o.counters()
+    assert {k: cd[k] for k in KEYS} == {k: co[k] for k in KEYS}
+    st, bs = o.batched_stats(), sm.map.batch_stats()
+    assert st["guard_violations"] == 0 and (bs["epochs"], bs["generations"], bs["children_lost"]) == (st["epochs"], st["generations"], 0)
+    assert co["nested_particles"] > 10**6 and cd["pool_overflow"] == 0
