@@ -46,6 +46,7 @@ def pair(soil, case, tick0, dilate=0):
     set_dilate(dilate)
     h = HostSim(cfg, g.dimx, g.dimy, seed=0)
     h.load(g, advance_rand=True)
+    h.batch_stats()                                           # (the host-sim's counters are process-global: read = reset)
     o = Oracle(cfg, g.dimx, g.dimy, seed=0)
     o.load(g)
     o.batched_set_dilate(dilate)
@@ -178,7 +179,7 @@ def test_batched_statistics_against_the_exact_engine():
 
 
 def test_300_ticks_into_the_wet_regime_equal_restated_schedule():
-    """Depth on the CPU: 128^2 default.soil, 250 particles per tick for 300 ticks -- lakes, > 5 * 10^5 nested particles,
+    """Depth on the CPU: 128^2 default.soil, 250 particles per tick for 300 ticks -- lakes, > 4 * 10^5 nested particles,
     ~4 * 10^5 epochs; the device sources on host threads == the restated schedule on the full state every 100 ticks."""
     cfg = load_cfg("default.soil")
     n = 128
@@ -194,4 +195,31 @@ def test_300_ticks_into_the_wet_regime_equal_restated_schedule():
         assert not bad, f"after {100 * (block + 1)} ticks: {bad}"
     ch, co = h.counters(), o.counters()
     assert {k: ch[k] for k in KEYS} == {k: co[k] for k in KEYS}
-    assert co["nested_particles"] > 5 * 10**5 and o.batched_stats()["guard_violations"] == 0
+    assert co["nested_particles"] > 4 * 10**5 and o.batched_stats()["guard_violations"] == 0
+
+
+def test_statistics_in_the_wet_regime_track_the_reference():
+    """Tier P2 where it is hardest: 256^2 default.soil, 150 ticks (lakes, ~2 * 10^5 nested particles). The batched schedule
+    must reproduce the reference's AMOUNTS -- floods, nested particles, standing water, total height -- not just look
+    plausible. (Round 2 tried running floods as a sub-phase after every 32-epoch chunk: 18 % faster on the device, but a
+    flood is a feedback -- the puddle it leaves ends the particles that arrive next -- and delaying it cost 17 % of the
+    floods and 25 % of the nested particles, +21 % standing water. tools/experiments/r02_flood_subphase.patch; this test is
+    what such a change has to pass.)"""
+    cfg = load_cfg("default.soil")
+    n = 256
+    a = Oracle(cfg, n, n, seed=0); a.initialize()
+    b = Oracle(cfg, n, n, seed=0); b.initialize()
+    for _ in range(150):
+        a.tick(250, 0, True, False)
+        b.batched_tick(250, 0, True, False)
+    ca, cb = a.counters(), b.counters()
+    sa, sb = a.snapshot(), b.snapshot()
+    water_a, water_b = float(sa.size[sa.type == 0].sum()), float(sb.size[sb.type == 0].sum())
+    ha, hb = np.asarray(a.heights()), np.asarray(b.heights())
+    assert ca["floods"] > 50000 and ca["nested_particles"] > 250000
+    assert abs(cb["floods"] / ca["floods"] - 1) < 0.03
+    assert abs(cb["nested_particles"] / ca["nested_particles"] - 1) < 0.05
+    assert abs(water_b / water_a - 1) < 0.12
+    assert abs(hb.sum() - ha.sum()) < 5.0 and abs(float((hb - ha).mean())) < 1e-4
+    assert float(np.sqrt(((ha - hb) ** 2).mean())) < 3e-3
+    assert abs(int(sb.count.sum()) / int(sa.count.sum()) - 1) < 0.01
