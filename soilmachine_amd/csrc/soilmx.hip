@@ -282,6 +282,20 @@ __global__ void __launch_bounds__(64) k_batch_epoch(DevState s, BatchShared bs, 
   else { Frame st[MAX_FRAMES]; batch_water_epoch(sim, bs, bs.live[i], epoch, st); }
   sim.flush_counters(); pol.finish(s);
 }
+// the same kernel held to 256 registers (a few spilled) = two wavefronts per SIMD: for phases with more wavefronts than SIMDs
+template <bool WIND>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_batch_epoch2(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch, uint32_t lpw) {
+  SMX_LOAD_SOILS(sh)
+  // `lpw` particles per wavefront (batch_lanes_per_wave): a wavefront costs the UNION of its lanes' paths, and the chip has
+  // 1024 SIMDs -- a phase that is down to a few thousand particles runs them one per wavefront instead of 64.
+  const uint32_t i = blockIdx.x * lpw + threadIdx.x;
+  if (threadIdx.x >= lpw || i >= nlive) return;
+  BatchPolicy pol(s, bs);
+  Sim<BatchPolicy> sim(s, sh, pol);
+  if constexpr (WIND) batch_wind_epoch(sim, bs, bs.live[i], epoch);
+  else { Frame st[MAX_FRAMES]; batch_water_epoch(sim, bs, bs.live[i], epoch, st); }
+  sim.flush_counters(); pol.finish(s);
+}
 // how many particles share a wavefront: as few as fill `SMX_BATCH_WAVES` wavefronts (default 256 = one per CU; 0 = always 64;
 // measured in profiles/r02_batched_schedules.md, sweep 5). Which lane runs a slot has no influence on results.
 static uint32_t batch_lanes_per_wave(uint32_t nlive) {
@@ -1363,8 +1377,15 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
         PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)CHUNK);   // CHUNK back-to-back launches of the epoch kernel, nothing else
         const uint32_t lpw = batch_lanes_per_wave(nlive);
         const unsigned nbl = (nlive + lpw - 1u) / lpw;
+        // more wavefronts than SIMDs (> 65 536 running particles): the 256-register build, two wavefronts per SIMD -- +5 % at 16384^2,
+        // nothing below (profiles/r02_batched_schedules.md); results do not depend on it
+        static const uint32_t occ2_above = [] { const char* e = getenv("SMX_BATCH_OCC2_ABOVE"); return e ? (uint32_t)atoll(e) : 65536u; }();
+        const bool occ2 = nlive > occ2_above;
         for (int k = 0; k < CHUNK; k++, epoch++) {
-          if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+          if (occ2) {
+            if (wind) hipLaunchKernelGGL(k_batch_epoch2<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+            else hipLaunchKernelGGL(k_batch_epoch2<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+          } else if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
           else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
         }
       }
