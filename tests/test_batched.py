@@ -178,16 +178,16 @@ def test_batched_statistics_against_the_exact_engine():
     assert ba.batched_stats()["guard_violations"] == 0
 
 
-def test_300_ticks_into_the_wet_regime_equal_restated_schedule():
-    """Depth on the CPU: 128^2 default.soil, 250 particles per tick for 300 ticks -- lakes, > 4 * 10^5 nested particles,
-    ~4 * 10^5 epochs; the device sources on host threads == the restated schedule on the full state every 100 ticks."""
+def test_200_ticks_into_the_wet_regime_equal_restated_schedule():
+    """Depth on the CPU: 128^2 default.soil, 250 particles per tick for 200 ticks -- lakes, > 2.5 * 10^5 nested particles,
+    ~2.5 * 10^5 epochs; the device sources on host threads == the restated schedule on the full state every 100 ticks."""
     cfg = load_cfg("default.soil")
     n = 128
     o = Oracle(cfg, n, n, seed=0)
     o.initialize()
     h = HostSim(cfg, n, n, seed=0)
     h.load(o.snapshot())
-    for block in range(3):
+    for block in range(2):
         for _ in range(100):
             h.batched_tick(250, 0, True, False, nthreads=4, shuffle=block + 1)
             o.batched_tick(250, 0, True, False)
@@ -195,7 +195,7 @@ def test_300_ticks_into_the_wet_regime_equal_restated_schedule():
         assert not bad, f"after {100 * (block + 1)} ticks: {bad}"
     ch, co = h.counters(), o.counters()
     assert {k: ch[k] for k in KEYS} == {k: co[k] for k in KEYS}
-    assert co["nested_particles"] > 4 * 10**5 and o.batched_stats()["guard_violations"] == 0
+    assert co["nested_particles"] > 2.5 * 10**5 and o.batched_stats()["guard_violations"] == 0
 
 
 def test_statistics_in_the_wet_regime_track_the_reference():
