@@ -734,6 +734,10 @@ struct so_ctx {
       for (int g = 0; g < bs_n; g++) { const int lo = bs_x(g) + (g ? bs_a : 0), hi = bs_x(g + 1) - (g < bs_n - 1 ? bs_a : 0); if (cx0 >= lo && cx1 < hi) return true; }
     } else {
       for (int g = 0; g + 1 < bs_n; g++) if (cx0 >= bs_x(g + 1) - bs_b && cx1 < bs_x(g + 1) + bs_b) return true;
+      for (int g = 0; g < bs_n; g++) {                        // deep inside a strip: out of reach of every seam zone -> goes on in SEAM chunks too
+        const int lo = bs_x(g) + (g ? bs_b : 0), hi = bs_x(g + 1) - (g < bs_n - 1 ? bs_b : 0);
+        if (cx0 >= lo && cx1 < hi) return true;
+      }
     }
     return false;
   }

@@ -51,11 +51,13 @@ struct BChild {                               // a nested WaterParticle waiting 
 
 // Column strips (DESIGN.md "Multi-GPU"): the map is cut into x-strips [x[g], x[g+1]); chunks of epochs alternate between
 //   INTERIOR  a particle may act iff its whole reservation lies at least `a` cells inside ONE strip (map edges excepted), and
-//   SEAM      iff it lies inside ONE seam zone [x[g+1]-b, x[g+1]+b).
+//   SEAM      iff it lies inside ONE seam zone [x[g+1]-b, x[g+1]+b) -- or at least `b` cells inside one strip, where no
+//             seam zone reaches (so that a SEAM chunk does not idle the particles that are nowhere near a seam).
 // b - a is at least the widest reservation (32 cells), so every reservation fits one of the two. In an INTERIOR chunk the
-// strips touch disjoint cells -- one device each, nothing to exchange; a SEAM chunk is run by the device left of the
-// seam, on a halo that is refreshed before and handed back after. Ineligible particles do not reserve anything (they
-// are dormant until the other kind of chunk). With n == 1 everything is interior: the single-device schedule.
+// strips touch disjoint cells -- one device each, nothing to exchange; a SEAM zone is run by the device left of the
+// seam, on a halo that is refreshed before and handed back after, while every device goes on deep inside its own strip.
+// Ineligible particles do not reserve anything (they are dormant until the other kind of chunk). With n == 1 everything is
+// interior: the single-device schedule.
 struct BStrips { int n; int x[9]; int a, b; };
 constexpr int STRIP_INTERIOR = 0, STRIP_SEAM = 1;
 
@@ -116,6 +118,12 @@ SMX_D bool beligible(const DevState& s, const BatchShared& bs, const BRect& r) {
   } else {
     for (int g = 0; g + 1 < st.n; g++)
       if (cx0 >= st.x[g + 1] - st.b && cx1 < st.x[g + 1] + st.b) return true;
+    // ... and whoever is so deep inside a strip (b cells from its boundaries) that no seam zone can touch what it touches
+    // goes on: a SEAM chunk must not idle the 97 % of the particles that are nowhere near a seam
+    for (int g = 0; g < st.n; g++) {
+      const int lo = st.x[g] + (g ? st.b : 0), hi = st.x[g + 1] - (g < st.n - 1 ? st.b : 0);
+      if (cx0 >= lo && cx1 < hi) return true;
+    }
   }
   return false;
 }
