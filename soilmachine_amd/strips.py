@@ -6,11 +6,12 @@ batched engine's schedule alternates two kinds of 32-epoch chunks (csrc/soil_bat
   INTERIOR  a particle acts iff its whole reservation lies `a` cells inside one strip  -> strips touch disjoint cells,
             every rank runs its own, nothing is exchanged;
   SEAM      a particle acts iff its reservation lies inside one seam zone [x_b - b, x_b + b) around a strip boundary
-            -> the rank LEFT of the boundary runs the seam on a halo of b columns.
+            -> the rank LEFT of the boundary runs the seam on a halo of b columns -- or b cells inside a strip, out of
+            every seam zone's reach (the particles that are nowhere near a seam do not idle).
 
 Per chunk the ranks agree on the number of running particles (one all-reduce of 4 bytes: the schedule depends on it);
 around every SEAM chunk neighbours exchange, point to point, (i) the halo columns that changed (dirty 4x4 tiles only)
-and (ii) the particles that sit in the halo. Nested particles are all-gathered once per generation (they are sorted by
+and (ii) the particles that sit in the halo -- one message per direction. Nested particles are all-gathered once per generation (they are sorted by
 key: slot numbers = priorities must be global). The result is a function of (nstrips, a, b) only: running the strips on
 one device with smx_set_batch_strips() gives the same bits (tests/test_strips.py, loop-back), as does any transport.
 
@@ -218,35 +219,40 @@ class StripRank:
         self.stats = {"chunks": 0, "seam_chunks": 0, "generations": 0}
 
     # -- halo traffic (nearest neighbours only). A rank holds, besides its strip, the b columns right of its right boundary.
+    # one message per direction: [u64 length of the column part][columns][particles]
+    @staticmethod
+    def _bundle(cols: bytes, parts: bytes) -> bytes:
+        return len(cols).to_bytes(8, "little") + cols + parts
+
+    def _apply_bundle(self, b: bytes, particles: bool):
+        n = int.from_bytes(b[:8], "little")
+        self.be.unpack_columns(b[8:8 + n])
+        if particles:
+            self.be.unpack_particles(b[8 + n:])
+
     def _send_band_left(self, particles: bool):
         """band [x0, x0 + b) of this strip -> the rank on the left (which runs that seam)"""
         r, g = self.comm.rank, self.g
         if r > 0:
-            self.comm.send(r - 1, self.be.pack_columns(self.x0, self.x0 + g.b))
-            if particles:
-                self.comm.send(r - 1, self.be.pack_particles(self.x0, self.x0 + g.b))
+            self.comm.send(r - 1, self._bundle(self.be.pack_columns(self.x0, self.x0 + g.b),
+                                               self.be.pack_particles(self.x0, self.x0 + g.b) if particles else b""))
 
     def _recv_band_from_right(self, particles: bool):
         r, g = self.comm.rank, self.g
         if r < g.n - 1:
-            self.be.unpack_columns(self.comm.recv(r + 1))
-            if particles:
-                self.be.unpack_particles(self.comm.recv(r + 1))
+            self._apply_bundle(self.comm.recv(r + 1), particles)
 
     def _send_band_right(self, particles: bool):
         """the halo [x1, x1 + b) goes home to the rank on the right, with every particle that sits beyond x1"""
         r, g = self.comm.rank, self.g
         if r < g.n - 1:
-            self.comm.send(r + 1, self.be.pack_columns(self.x1, self.x1 + g.b))
-            if particles:
-                self.comm.send(r + 1, self.be.pack_particles(self.x1, g.dimx))
+            self.comm.send(r + 1, self._bundle(self.be.pack_columns(self.x1, self.x1 + g.b),
+                                               self.be.pack_particles(self.x1, g.dimx) if particles else b""))
 
     def _recv_band_from_left(self, particles: bool):
         r = self.comm.rank
         if r > 0:
-            self.be.unpack_columns(self.comm.recv(r - 1))
-            if particles:
-                self.be.unpack_particles(self.comm.recv(r - 1))
+            self._apply_bundle(self.comm.recv(r - 1), particles)
 
     def sync_halos(self):
         self._send_band_left(False)
