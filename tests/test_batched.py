@@ -223,3 +223,41 @@ def test_statistics_in_the_wet_regime_track_the_reference():
     assert abs(hb.sum() - ha.sum()) < 5.0 and abs(float((hb - ha).mean())) < 1e-4
     assert float(np.sqrt(((ha - hb) ** 2).mean())) < 3e-3
     assert abs(int(sb.count.sum()) / int(sa.count.sum()) - 1) < 0.01
+
+
+def test_random_configurations_host_sim_equals_restatement():
+    """A seeded sweep over what the fixed cases do not vary together: map shapes that are not multiples of any tile (17x19 ...
+    130x96), six soil files, particle counts from 1 up, margins, single-cell reservations, 1-3 column strips, thread counts and
+    execution orders. (The same loop ran ~10^3 cases while the engine was written; here 30 of them.)"""
+    import random
+    from oracle_lib import lib as olib
+    L = lib()
+    L.hs_set_batch_strips.argtypes = [ctypes.c_int] * 3
+    OL = olib()
+    OL.so_batched_set_strips.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
+    soils = ["default.soil", "rockgravelpebblessand.soil", "painted.soil", "rocksand.soil", "sand.soil", "bigbutte.soil"]
+    rng = random.Random(20260926)
+    try:
+        for case in range(30):
+            cfg = load_cfg(rng.choice(soils))
+            dx, dy = rng.choice([17, 33, 48, 64, 80, 97, 130, 224]), rng.choice([19, 32, 50, 64, 96])
+            seed, nw, nd = rng.randrange(1000), rng.choice([1, 7, 60, 250]), rng.choice([0, 5, 40, 120])
+            ticks, dil, fine = rng.choice([1, 2, 3]), rng.choice([0, 0, 1, 2]), rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 30])
+            strips = rng.choice([1, 2, 3]) if dx >= 130 else 1
+            if strips > 1 and dx // strips < 2 * 48 + 16:
+                strips = 1
+            o = Oracle(cfg, dx, dy, seed=seed)
+            o.initialize()
+            h = HostSim(cfg, dx, dy, seed=seed)
+            h.load(o.snapshot())
+            set_dilate(dil); o.batched_set_dilate(dil)
+            set_fine_above(fine, o)
+            L.hs_set_batch_strips(strips, 16, 48); OL.so_batched_set_strips(o.h, strips, 16, 48)
+            for t in range(ticks):
+                h.batched_tick(nw, nd, True, nd > 0, nthreads=rng.choice([1, 3]), shuffle=rng.randrange(5))
+                o.batched_tick(nw, nd, True, nd > 0)
+                bad = compare(h.snapshot(), o.snapshot())
+                assert not bad, f"case {case} ({dx}x{dy}, seed {seed}, {nw}+{nd}, margin {dil}, strips {strips}) tick {t}: {bad}"
+            assert o.batched_stats()["guard_violations"] == 0
+    finally:
+        set_dilate(0); set_fine_above(0xFFFFFFFF); L.hs_set_batch_strips(1, 16, 48)
