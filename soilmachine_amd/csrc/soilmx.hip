@@ -845,10 +845,28 @@ int smx_set_soils(smx_ctx* ctx, const smx_soil* soils, int32_t n) {
 }
 int smx_set_scale(smx_ctx* ctx, int32_t scale) { ctx->d.scale = scale; ctx->cfg.scale = scale; return 0; }
 int smx_set_engine(smx_ctx* ctx, int32_t engine) { ctx->cfg.engine = engine; return 0; }
-int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) { ctx->batch_dilate = tiles < 0 ? 0 : tiles; return 0; }
+// Column strips need every reservation to fit between the inset and the seam half-width (soil_batch.h BStrips), or a particle
+// near a boundary is eligible in neither kind of chunk and the phase never ends. Widest reservations of batch_schedule:
+// water 3 tiles of 4 cells, wind 3 tiles of 4 / 2 tiles of 8, each plus the margin on both sides.
+static bool batch_strips_fit(int dilate, int inset, int seam_halfwidth) {
+  const int dw = dilate > 0 ? dilate : 0, dd = dilate > 1 ? dilate : 1;
+  const int w_water = (3 + 2 * dw) * 4, w_wind = (3 + 2 * dd) * 4, w_tail = (2 + 2 * dd) * 8;
+  return std::max(w_water, std::max(w_wind, w_tail)) <= seam_halfwidth - inset;
+}
+int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) {
+  if (tiles < 0) tiles = 0;
+  if (ctx->strips_n > 1 && !batch_strips_fit(tiles, ctx->strips_a, ctx->strips_b)) {
+    ctx->err = "smx_set_batch_dilate: reservations with this margin do not fit the seam zones of the column strips"; return -2;
+  }
+  ctx->batch_dilate = tiles;
+  return 0;
+}
 int smx_set_batch_strips(smx_ctx* ctx, int32_t nstrips, int32_t inset, int32_t seam_halfwidth) {
   if (nstrips < 1 || nstrips > 8 || inset < 0 || seam_halfwidth - inset < 32) { ctx->err = "smx_set_batch_strips: 1..8 strips, seam_halfwidth - inset >= 32"; return -2; }
   if (nstrips > 1 && ctx->cfg.dimx / nstrips < 2 * seam_halfwidth + 16) { ctx->err = "smx_set_batch_strips: strips narrower than two seam zones"; return -2; }
+  if (nstrips > 1 && !batch_strips_fit(ctx->batch_dilate, inset, seam_halfwidth)) {
+    ctx->err = "smx_set_batch_strips: the reservations of the current margin (smx_set_batch_dilate) do not fit seam_halfwidth - inset"; return -2;
+  }
   ctx->strips_n = nstrips; ctx->strips_a = inset; ctx->strips_b = seam_halfwidth;
   return 0;
 }

@@ -133,3 +133,4 @@ def test_256_default_1000_ticks_in_the_wet_regime_equal_restated_schedule():
     st, bs = o.batched_stats(), sm.map.batch_stats()
     assert st["guard_violations"] == 0 and (bs["epochs"], bs["generations"], bs["children_lost"]) == (st["epochs"], st["generations"], 0)
     assert co["nested_particles"] > 10**6 and cd["pool_overflow"] == 0
+
