@@ -19,11 +19,12 @@ t_end = time.time() + float(sys.argv[2]) if len(sys.argv)>2 else time.time()+120
 n=0
 while time.time() < t_end:
     soil = rng.choice(soils); cfg = load_cfg(soil)
-    dx = rng.choice([17, 33, 48, 64, 80, 97, 130]); dy = rng.choice([19, 32, 50, 64, 96])
+    dx = rng.choice([17, 33, 48, 64, 80, 97, 130, 224, 260, 352]); dy = rng.choice([19, 32, 50, 64, 96])
     seed = rng.randrange(1000); nw = rng.choice([1, 7, 60, 250]); nd = rng.choice([0, 5, 40, 120])
     ticks = rng.choice([1, 2, 4]); dil = rng.choice([0, 0, 1, 2]); cell_above = rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 30])
-    strips = rng.choice([1, 1, 2, 3]) if dx >= 130 or (dx>=97 and rng.random()<0.3) else 1
+    strips = rng.choice([1, 2, 3]) if dx >= 224 else 1
     if strips > 1 and dx // strips < 2*48+16: strips = 1
+    if strips > 1 and dil > 1: dil = 1                          # (wider margins do not fit the seam zones: rejected at the C-ABI)
     o = Oracle(cfg, dx, dy, seed=seed); o.initialize()
     h = HostSim(cfg, dx, dy, seed=seed); h.load(o.snapshot())
     L.hs_set_batch_dilate(dil); o.batched_set_dilate(dil)
