@@ -210,7 +210,9 @@ void* smx_stream(smx_ctx* ctx);                          /* the hipStream_t all 
  *                                  writes: the moments of the state the step started from
  *   smx_lbm_read                   RHO (n floats), V (n vec4), F (n*19, reference order); any pointer may be NULL
  *   smx_lbm_write_f                overwrite F (tests, restart)
- *   smx_lbm_move                   move.cs on the caller's tracer array (n vec4, in place); the respawn of lbmwind.h:199-218 stays host code
+ *   smx_lbm_move                   move.cs on the caller's tracer array (n vec4, in place); the respawn of lbmwind.h:199-218 stays host code.
+ *                                  Tracers whose cell or cell+1 lies outside the lattice (the reference moves BEFORE its range check,
+ *                                  lbmwind.h:193-215) sample the nearest lattice cell: indices are clamped, never out of bounds
  *   smx_lbm_get_timing             HIP-event time of the step kernels since the last reset */
 typedef struct smx_lbm smx_lbm;
 int smx_lbm_create(int32_t nx, int32_t ny, int32_t nz, int32_t device, smx_lbm** out);

@@ -5,11 +5,14 @@
 // (shader/move.cs). This file follows the shaders statement by statement in float32, one fixed evaluation order:
 //   dot(a, b) = (a.x*b.x + a.y*b.y) + a.z*b.z, products left to right, no contraction (-ffp-contract=off).
 //
-// PARITY UNPINNED: GLSL cannot run in this container (no GL), the reference has no test or golden vector for this path, and
-// a GLSL compiler is free to contract and reassociate -- so this restatement is checked against nothing but the shader
-// text. Where the reference's stream.cs races with itself (a face cell's distributions are written by its neighbours' push
+// PARITY PINNED (round 3): the reference's own shader text, compiled as C++ (oracle/lbm_ref.cpp + oracle/glsl2cpp.py +
+// oracle/shim/glsl_cs.h -> oracle/_ref/liblbm_ref.so), reproduces this restatement bit for bit on every buffer after every step
+// (tests/test_lbm.py, live where /root/reference exists; against tests/golden/lbm_ref.npz -- the shaders' own outputs --
+// everywhere). What no CPU build can pin: a GLSL compiler may contract or reassociate float arithmetic and fold constants
+// at another precision; both builds evaluate every expression as written, in float, no contraction.
+// Where the reference's stream.cs races with itself (a face cell's distributions are written by its neighbours' push
 // AND by its own driving-force overwrite in the same dispatch, stream.cs:9-34), the overwrite wins here: that is the wet-node
-// boundary the shader's comment states.
+// boundary the shader's comment states (the shim's FBUF takes the same decision for the compiled shaders).
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -142,7 +145,8 @@ void lo_move(lo_ctx* c, float* pos4, int n) {
     float* P = pos4 + 4 * (size_t)i;
     int p[4], nn[4]; float w[4];
     for (int d = 0; d < 4; d++) { p[d] = (int)P[d]; nn[d] = p[d] + 1; w[d] = P[d] - (float)p[d]; }
-    auto V = [&](int x, int y, int z) { return &c->V[4 * (((size_t)x * NY + y) * NZ + z)]; };
+    auto cl = [](int a, int n) { return a < 0 ? 0 : (a > n - 1 ? n - 1 : a); };   // out-of-lattice samples: nearest cell (soilmx.h smx_lbm_move)
+    auto V = [&](int x, int y, int z) { return &c->V[4 * (((size_t)cl(x, c->nx) * NY + cl(y, NY)) * NZ + cl(z, NZ))]; };
     const float *v000 = V(p[0], p[1], p[2]), *v100 = V(nn[0], p[1], p[2]), *v010 = V(p[0], nn[1], p[2]), *v001 = V(p[0], p[1], nn[2]),
                 *v110 = V(nn[0], nn[1], p[2]), *v101 = V(nn[0], p[1], nn[2]), *v011 = V(p[0], nn[1], nn[2]), *v111 = V(nn[0], nn[1], nn[2]);
     for (int d = 0; d < 4; d++) {

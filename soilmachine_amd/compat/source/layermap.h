@@ -65,7 +65,8 @@ class Layermap {
   smx_ctx* ctx = nullptr;
   std::vector<double> hmirror;                // Layermap::height(ivec2) for every cell (cell order x*dim.y+y)
   std::vector<uint32_t> smirror;              // Layermap::surface(ivec2)
-  bool dirty = true;
+  std::vector<float> nmirror;                 // Layermap::normal(ivec2), xyz per cell (filled on first use after a change)
+  bool dirty = true, nstale = true;
   sec topview;                                // what top() hands out
 
   void check(int rc, const char* what) {
@@ -77,7 +78,7 @@ class Layermap {
     hmirror.resize((size_t)dim.x * dim.y); smirror.resize((size_t)dim.x * dim.y);
     check(smx_read_heights(ctx, hmirror.data()), "smx_read_heights");
     check(smx_read_surface(ctx, smirror.data()), "smx_read_surface");
-    dirty = false;
+    dirty = false; nstale = true;
   }
 
  public:
@@ -119,52 +120,32 @@ class Layermap {
 
   // ---- queries
   double height(ivec2 pos) { refresh(); return hmirror[(size_t)pos.x * dim.y + pos.y]; }          // layermap.h:422-425
-  double height(vec2 pos) {                                                                         // layermap.h:427-439
-    double h = 0.0f;
-    ivec2 p = floor(pos);
-    vec2 w = fract(pos);
-    h += (1.0 - w.x) * (1.0 - w.y) * height(p);
-    h += (1.0 - w.x) * w.y * height(p + ivec2(1, 0));
-    h += w.x * (1.0 - w.y) * height(p + ivec2(0, 1));
-    h += w.x * w.y * height(p + ivec2(1, 1));
+  double height(vec2 pos) {                                       // layermap.h:427-439: evaluated on the device (k_bilinear), bit-identical
+    flush();
+    const float xy[2] = {pos.x, pos.y};
+    double h = 0.0;
+    check(smx_heights_bilinear(ctx, xy, 1, &h), "smx_heights_bilinear");
     return h;
   }
   SurfType surface(ivec2 pos) { refresh(); return smirror[(size_t)pos.x * dim.y + pos.y]; }        // layermap.h:417-420
-  vec3 normal(ivec2 pos) {                                                                          // layermap.h:341-377
-    vec3 n = vec3(0);
-    vec3 p = vec3(pos.x, SCALE * height(pos), pos.y);
-    int k = 0;
-    if (pos.x > 0 && pos.y > 0) {
-      vec3 b = vec3(pos.x - 1, SCALE * height(pos - ivec2(1, 0)), pos.y);
-      vec3 c = vec3(pos.x, SCALE * height(pos - ivec2(0, 1)), pos.y - 1);
-      n += cross(c - p, b - p); k++;
-    }
-    if (pos.x > 0 && pos.y < dim.y - 1) {
-      vec3 b = vec3(pos.x - 1, SCALE * height(pos - ivec2(1, 0)), pos.y);
-      vec3 c = vec3(pos.x, SCALE * height(pos + ivec2(0, 1)), pos.y + 1);
-      n -= cross(c - p, b - p); k++;
-    }
-    if (pos.x < dim.x - 1 && pos.y > 0) {
-      vec3 b = vec3(pos.x + 1, SCALE * height(pos + ivec2(1, 0)), pos.y);
-      vec3 c = vec3(pos.x, SCALE * height(pos - ivec2(0, 1)), pos.y - 1);
-      n -= cross(c - p, b - p); k++;
-    }
-    if (pos.x < dim.x - 1 && pos.y < dim.y - 1) {
-      vec3 b = vec3(pos.x + 1, SCALE * height(pos + ivec2(1, 0)), pos.y);
-      vec3 c = vec3(pos.x, SCALE * height(pos + ivec2(0, 1)), pos.y + 1);
-      n += cross(c - p, b - p); k++;
-    }
-    return normalize(n / (float)k);
+  // Layermap::normal(ivec2) (layermap.h:341-377) is a device kernel (k_normals behind smx_normals: the same code the particles
+  // use); the host serves point queries from a mirror of that plane, refreshed after device work like the height mirror
+  vec3 normal(ivec2 pos) {
+    refresh();
+    if (nstale) { nmirror.resize(3 * (size_t)dim.x * dim.y); check(smx_normals(ctx, nmirror.data()), "smx_normals"); nstale = false; }
+    const float* q = &nmirror[3 * ((size_t)pos.x * dim.y + pos.y)];
+    return vec3(q[0], q[1], q[2]);
   }
-  vec3 normal(vec2 pos) {                                                                           // layermap.h:379-392
-    vec3 n = vec3(0);
-    ivec2 p = floor(pos);
-    vec2 w = fract(pos);
-    n += (1.0f - w.x) * (1.0f - w.y) * normal(p);
-    n += (1.0f - w.x) * w.y * normal(p + ivec2(1, 0));
-    n += w.x * (1.0f - w.y) * normal(p + ivec2(0, 1));
-    n += w.x * w.y * normal(p + ivec2(1, 1));
-    return n;
+  // layermap.h:379-392: the four corner normals blended with the bilinear weights (float; corner order (0,0) (1,0) (0,1) (1,1)
+  // with the weight pairing of the reference, i.e. crossed like height(vec2))
+  vec3 normal(vec2 pos) {
+    const ivec2 cell = floor(pos);
+    const vec2 f = fract(pos);
+    const float wx[2] = {1.0f - f.x, f.x}, wy[2] = {1.0f - f.y, f.y};
+    const int corner[4][4] = {{0, 0, 0, 0}, {1, 0, 0, 1}, {0, 1, 1, 0}, {1, 1, 1, 1}};   // {dx, dy, index into wx, index into wy}
+    vec3 acc = vec3(0);
+    for (int k = 0; k < 4; k++) acc += wx[corner[k][2]] * wy[corner[k][3]] * normal(cell + ivec2(corner[k][0], corner[k][1]));
+    return acc;
   }
   vec3 normal(ivec2 pos, Vertexpool<Vertex>&) { return normal(pos); }                               // layermap.h:394-398
   vec3 normal(vec2 pos, Vertexpool<Vertex>&) { return normal(pos); }                                // layermap.h:400-413
@@ -198,15 +179,13 @@ class Layermap {
     if (section != NULL) { vertexpool.unsection(section); vertexpool.indices.clear(); }
     section = vertexpool.section(dim.x * dim.y, 0, glm::vec3(0));
     update(vertexpool);
-    for (int i = 0; i < dim.x - 1; i++)
-      for (int j = 0; j < dim.y - 1; j++) {
-        vertexpool.indices.push_back(i * dim.y + j);
-        vertexpool.indices.push_back(i * dim.y + (j + 1));
-        vertexpool.indices.push_back((i + 1) * dim.y + j);
-        vertexpool.indices.push_back((i + 1) * dim.y + j);
-        vertexpool.indices.push_back(i * dim.y + (j + 1));
-        vertexpool.indices.push_back((i + 1) * dim.y + (j + 1));
-      }
+    // two triangles per grid quad, vertices numbered in cell order (layermap.h:458-469): (q, q+1, q+dim.y) and (q+dim.y, q+1, q+dim.y+1)
+    vertexpool.indices.reserve((size_t)6 * (dim.x - 1) * (dim.y - 1));
+    const int tri[6] = {0, 1, dim.y, dim.y, 1, dim.y + 1};
+    for (int q = 0; q < (dim.x - 1) * dim.y; q++) {
+      if (q % dim.y == dim.y - 1) continue;                    // last cell of a row: no quad to its right
+      for (int t = 0; t < 6; t++) vertexpool.indices.push_back(q + tri[t]);
+    }
     vertexpool.resize(section, vertexpool.indices.size());
     vertexpool.index();
     vertexpool.update();
@@ -268,7 +247,7 @@ class Layermap {
       smx_destroy(ctx); ctx = nullptr;
       create_context(_dim);
       check(smx_set_rand_state(ctx, ring, idx, calls), "smx_set_rand_state");
-      hmirror.clear(); smirror.clear();
+      hmirror.clear(); smirror.clear(); nmirror.clear();
     }
     dim = _dim;
     std::vector<smx_layer> L(layers.size());

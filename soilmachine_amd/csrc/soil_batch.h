@@ -184,11 +184,18 @@ struct BatchPolicy {
     if (k < bs.freed_cap) bs.freed[k] = e; else SMX_A_ADD(&bs.ctrl[BC_FREED_LOST], 1u);
   }
   SMX_D void rand2(const DevState&, int& a, int& b) { a = 0; b = 0; }   // (nested particles draw when their generation starts)
-  SMX_D bool child_room() const { return nchild < (uint32_t)B_MAXCHILD; }
+  // Reserve the child's record BEFORE the water leaves its column (soil_core.h water_drive): when the per-thread limit or the
+  // generation's buffer is exhausted the spawn is refused and the water stays where it is -- nothing leaves the simulation.
+  uint32_t child_slot = 0;
+  SMX_D bool child_room() {
+    if (nchild >= (uint32_t)B_MAXCHILD) return false;
+    const uint32_t k = SMX_A_ADD(&bs.ctrl[BC_NCHILD], 1u);   // (may overshoot child_cap: the host clamps; records [0, cap) are all valid)
+    if (k >= bs.child_cap) { SMX_A_ADD(&bs.ctrl[BC_CHILD_LOST], 1u); return false; }
+    child_slot = k;
+    return true;
+  }
   SMX_D void emit_child(int tx, int ty, int bx, int by, int spill, double volume) {
-    const uint32_t k = SMX_A_ADD(&bs.ctrl[BC_NCHILD], 1u);
-    if (k >= bs.child_cap) { SMX_A_ADD(&bs.ctrl[BC_CHILD_LOST], 1u); nchild++; return; }
-    BChild& c = bs.children[k];
+    BChild& c = bs.children[child_slot];
     c.key = (parent << 8) | (unsigned long long)nchild; nchild++;
     c.tx = tx; c.ty = ty; c.bx = bx; c.by = by; c.spill = spill; c.pad = 0; c.volume = volume;
   }

@@ -29,6 +29,20 @@
 #ifndef SMX_D
 #define SMX_D __device__ __forceinline__
 #endif
+// Fire-and-forget read-modify-writes (no return value -> the lane never waits for the memory round trip) and the
+// coherent load that goes with them. The exact engines are chains of DEPENDENT accesses on one lane: a plain
+// `word |= bit` costs a full round trip each (load, wait, or, store); the grid pass did 27 of them per water transfer.
+#ifdef SMX_HOSTSIM
+#define SMX_OR64_ASYNC(p, v) (void)(*(p) |= (v))
+#define SMX_OR32_ASYNC(p, v) (void)(*(p) |= (v))
+#define SMX_AND32_ASYNC(p, v) (void)(*(p) &= (v))
+#define SMX_LD64_COHERENT(p) (*(p))
+#else
+#define SMX_OR64_ASYNC(p, v) (void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SMX_OR32_ASYNC(p, v) (void)__hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SMX_AND32_ASYNC(p, v) (void)__hip_atomic_fetch_and((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SMX_LD64_COHERENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
 
 namespace smx {
 
@@ -136,6 +150,9 @@ template <class P> struct RecRes { P pol; Blk b; bool ab, moved; };
 #define SMX_NOINLINE __device__ __attribute__((noinline))
 #endif
 template <class P> SMX_NOINLINE RecRes<P> wind_recurse(DevState s, const SoilP* soils, P pol, float cx, float cy, int ix, int iy);
+// P::WINDOWED: the policy keeps a window of the map's cell records somewhere faster (LDS) and redirects accesses: cref()
+template <class P, class = void> struct has_window { static constexpr bool value = false; };
+template <class P> struct has_window<P, decltype((void)P::WINDOWED)> { static constexpr bool value = P::WINDOWED; };
 template <class P, class = void> struct outline_recursion { static constexpr bool value = false; };
 template <class P> struct outline_recursion<P, decltype((void)P::OUTLINE_RECURSION)> { static constexpr bool value = P::OUTLINE_RECURSION; };
 
@@ -167,10 +184,13 @@ struct Sim {
   }
 
   // ---------------- cell access (every access announces itself to the policy first) ----------------
+  SMX_D Sec& cs(size_t c) const {                           // the record of cell c, wherever the policy keeps it
+    if constexpr (has_window<P>::value) return pol.cref(s, c); else return s.cells[c];
+  }
   SMX_D Sec& cell(int x, int y) {
     const size_t c = cidx(x, y);
     if (!pol.touch(s, c, fidx(x, y))) ab = true;
-    return s.cells[c];
+    return cs(c);
   }
   SMX_D double height(int x, int y) {                       // Layermap::height(ivec2) layermap.h:422-425
     const Sec& c = cell(x, y);
@@ -188,7 +208,7 @@ struct Sim {
   SMX_D static double vh(const View& v) { return v.floor + v.size; }
   SMX_D static uint32_t vsurf(const View& v) { return v.type == EMPTY ? 0u : v.type; }
   SMX_D View load_view(size_t c) const {
-    const Sec& r = s.cells[c];
+    const Sec& r = cs(c);
     View v; v.size = r.size; v.floor = r.floor; v.type = r.type;
     return v;
   }
@@ -199,7 +219,7 @@ struct Sim {
     pol.template prefetch<N>(s, c, f, pf);                  // stamps, claims, undo words: loads only, no waiting
     Sec r[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) r[i] = s.cells[c[i]];       // whole 32-byte records: the views AND the undo snapshots
+    for (int i = 0; i < N; i++) r[i] = cs(c[i]);            // whole 32-byte records: the views AND the undo snapshots
     if (!pol.template acquire_log<N>(s, c, pf, r)) ab = true;
 #pragma unroll
     for (int i = 0; i < N; i++) { v[i].size = r[i].size; v[i].floor = r[i].floor; v[i].type = r[i].type; }
@@ -305,9 +325,9 @@ struct Sim {
 
   // ---------------- wet bookkeeping for the grid pass ----------------
   SMX_D void mark_active(size_t c) {
-    s.active[c >> 6] |= (1ull << (c & 63));
-    s.active1[c >> 12] |= (1ull << ((c >> 6) & 63));
-    s.active2[c >> 18] |= (1ull << ((c >> 12) & 63));
+    SMX_OR64_ASYNC(&s.active[c >> 6], 1ull << (c & 63));
+    SMX_OR64_ASYNC(&s.active1[c >> 12], 1ull << ((c >> 6) & 63));
+    SMX_OR64_ASYNC(&s.active2[c >> 18], 1ull << ((c >> 12) & 63));
   }
   // next set bit >= c in the 3-level bitmap, or ncells (summary levels are conservative)
   SMX_D size_t next_active(size_t c) const {
@@ -315,12 +335,12 @@ struct Sim {
     const size_t nw0 = (n + 63) >> 6, nw1 = (nw0 + 63) >> 6, nw2 = (nw1 + 63) >> 6;
     while (c < n) {
       const size_t w0 = c >> 6;
-      unsigned long long bits = s.active[w0] & (~0ull << (c & 63));
+      unsigned long long bits = SMX_LD64_COHERENT(&s.active[w0]) & (~0ull << (c & 63));
       if (bits) { size_t r = (w0 << 6) + (size_t)__builtin_ctzll(bits); return r < n ? r : n; }
       const size_t w = w0 + 1;
       if (w >= nw0) return n;
       const size_t w1 = w >> 6;
-      bits = s.active1[w1] & (~0ull << (w & 63));
+      bits = SMX_LD64_COHERENT(&s.active1[w1]) & (~0ull << (w & 63));
       if (bits) { c = ((w1 << 6) + (size_t)__builtin_ctzll(bits)) << 6; continue; }
       size_t v = w1 + 1;
       if (v >= nw1) return n;
@@ -328,7 +348,7 @@ struct Sim {
       unsigned long long mask = ~0ull << (v & 63);
       bool found = false;
       for (; w2 < nw2; w2++, mask = ~0ull) {
-        bits = s.active2[w2] & mask;
+        bits = SMX_LD64_COHERENT(&s.active2[w2]) & mask;
         if (bits) { found = true; break; }
       }
       if (!found) return n;
@@ -390,7 +410,7 @@ struct Sim {
   SMX_D void add(int x, int y, double size, uint32_t type, bool owned = false) {
     if (ab) return;
     if constexpr (P::READ_ONLY) { if (!owned) (void)cell(x, y); return; }   // scout: footprint only, never writes
-    Sec& c = owned ? s.cells[cidx(x, y)] : cell(x, y);
+    Sec& c = owned ? cs(cidx(x, y)) : cell(x, y);
     if (ab) return;
     // pool.get(): the reference takes a node for EVERY get (even if add() merges and returns it at once),
     // so get() fails exactly when live sections == capacity; add(NULL) is ignored (:233)
@@ -414,7 +434,7 @@ struct Sim {
     if (popped) *popped = false;
     if (ab) return 0.0;
     if constexpr (P::READ_ONLY) { if (!owned) (void)cell(x, y); return 0.0; }
-    Sec& c = owned ? s.cells[cidx(x, y)] : cell(x, y);
+    Sec& c = owned ? cs(cidx(x, y)) : cell(x, y);
     if (ab) return 0.0;
     if (c.type == EMPTY) return 0.0;
     if (c.size <= 0.0) { pop_top(c); sync_air_flag(x, y, c.type); if (popped) *popped = true; return 0.0; }
@@ -436,7 +456,7 @@ struct Sim {
       if (h <= 0.0) return 0.0;                             // layermap.h:325
       if (h < v.size) {                                     // :328-337 with diff < 0: shrink, nothing pops
         v.size -= h;
-        s.cells[c].size = v.size;
+        cs(c).size = v.size;
         return 0.0;
       }
     }
@@ -450,7 +470,7 @@ struct Sim {
     if (size <= 0) { if (!pol.can_get(s)) n_overflow++; return; }   // pool.get + unget of an empty section (layermap.h:237-240)
     if (v.type == type && v.type != EMPTY && size > 0 && pol.can_get(s)) {   // layermap.h:249-253 elongate (pool.get + unget: net 0)
       v.size += size;
-      s.cells[c].size = v.size;
+      cs(c).size = v.size;
       return;
     }
     add(x, y, size, type, true);

@@ -154,7 +154,11 @@ __global__ void __launch_bounds__(256) k_lbm_move(LbmDims d, const float4* __res
   const float Pa[4] = {pp.x, pp.y, pp.z, pp.w};
   int p[4], nn[4]; float w[4];
   for (int c = 0; c < 4; c++) { p[c] = (int)Pa[c]; nn[c] = p[c] + 1; w[c] = Pa[c] - (float)p[c]; }
-  auto V = [&](int x, int y, int z) { return v[((unsigned long long)x * d.ny + y) * d.nz + z]; };
+  // A tracer in [N-1, N) -- or below 0, or NaN -- has p or p+1 outside the lattice. The reference moves tracers BEFORE its
+  // range check (lbmwind.h:193-215) and GL's robust buffer access tolerates the stray read; here the index is clamped to
+  // the lattice (the nearest cell is sampled): in-range tracers are untouched, out-of-range ones cannot fault the context.
+  auto cl = [](int a, int n) { return a < 0 ? 0 : (a > n - 1 ? n - 1 : a); };
+  auto V = [&](int x, int y, int z) { return v[((unsigned long long)cl(x, d.nx) * d.ny + cl(y, d.ny)) * d.nz + cl(z, d.nz)]; };
   const float4 q000 = V(p[0], p[1], p[2]), q100 = V(nn[0], p[1], p[2]), q010 = V(p[0], nn[1], p[2]), q001 = V(p[0], p[1], nn[2]),
                q110 = V(nn[0], nn[1], p[2]), q101 = V(nn[0], p[1], nn[2]), q011 = V(p[0], nn[1], nn[2]), q111 = V(nn[0], nn[1], nn[2]);
   auto comp = [](const float4& t, int c) { return c == 0 ? t.x : (c == 1 ? t.y : (c == 2 ? t.z : t.w)); };

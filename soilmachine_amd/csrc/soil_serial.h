@@ -19,8 +19,14 @@ struct SerialPolicy {
   template <int N> SMX_D void prefetch(const DevState&, const size_t (&)[N], const size_t (&)[N], Pre<N>&) {}
   template <int N> SMX_D bool acquire_log(const DevState&, const size_t (&)[N], const Pre<N>&, const Sec (&)[N]) { return true; }
   SMX_D void pre_write_node(const DevState&, uint32_t) {}
-  SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (!(v & f)) s.flags[c] = v | f; }
-  SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (v & f) s.flags[c] = v & (uint8_t)~f; }
+  // fire-and-forget on the 32-bit word that holds the flag byte (the plane is allocated in whole words): a walker that first
+  // LOADS the byte to see whether it must change pays a memory round trip per call
+  SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) {
+    SMX_OR32_ASYNC(reinterpret_cast<uint32_t*>(s.flags + (c & ~(size_t)3)), (uint32_t)f << (8u * (uint32_t)(c & 3)));
+  }
+  SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) {
+    SMX_AND32_ASYNC(reinterpret_cast<uint32_t*>(s.flags + (c & ~(size_t)3)), ~((uint32_t)f << (8u * (uint32_t)(c & 3))));
+  }
   // secpool::get / unget (layermap.h:89-111): get() fails exactly when live sections == capacity
   SMX_D bool can_get(const DevState& s) const { return live < s.pool_capacity; }
   SMX_D void live_add(const DevState&, int d) { live += (long long)d; }

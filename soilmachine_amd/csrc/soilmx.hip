@@ -18,12 +18,14 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <sys/stat.h>
 #include <string>
 #include <vector>
 
 #include "../../include/soilmx.h"
 #include "soil_core.h"
 #include "soil_serial.h"
+#include "soil_grid.h"
 #include "soil_spec.h"
 #include <type_traits>
 #include <chrono>
@@ -179,6 +181,18 @@ __global__ void __launch_bounds__(64) k_grid_serial(DevState s) {
   sim.flush_counters();
   pol.add_counter(s, C_GRID_ACTIVE, visited);
   pol.finish(s);
+}
+
+// the same walk with its working set in LDS (soil_grid.h): lane 0 walks, the wavefront moves the 9 x 64-cell window
+__global__ void __launch_bounds__(64) k_grid_serial_win(DevState s) {
+  SMX_LOAD_SOILS(sh)
+  __shared__ Sec win[WIN_ROWS * WIN_WY];
+  if (blockIdx.x != 0) return;
+  grid_walk_windowed(s, sh, win, threadIdx.x, 64u, [] { __syncthreads(); },
+                     [](size_t v) {
+                       const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+                       return ((size_t)hi << 32) | (size_t)lo;
+                     });
 }
 
 // ---------------- speculative engine kernels (protocol: soil_spec.h) ----------------
@@ -779,7 +793,7 @@ int smx_create(const smx_config* cfg, smx_ctx** out) {
   HIPCHK(hipMalloc(&d.pool, cfg->pool_capacity * sizeof(Sec)));
   HIPCHK(hipMalloc(&d.freelist, cfg->pool_capacity * 4));
   HIPCHK(hipMalloc(&d.free_count, 64));
-  HIPCHK(hipMalloc(&d.flags, n));
+  HIPCHK(hipMalloc(&d.flags, n + 8));   // (whole 32-bit words: SerialPolicy::set_flag)
   HIPCHK(hipMalloc(&d.wfreq, n * 4)); HIPCHK(hipMalloc(&d.wtrack, n * 4)); HIPCHK(hipMalloc(&d.windfreq, n * 4));
   HIPCHK(hipMalloc(&d.rnd, sizeof(RandState)));
   HIPCHK(hipMalloc(&d.ctr, C_COUNT * 8));
@@ -1086,6 +1100,13 @@ int smx_load(smx_ctx* ctx, const char* path) {
   if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMXSNAP1", 8) != 0) { fclose(f); ctx->err = "smx_load: not a soilmx snapshot"; return -7; }
   if (h.dimx != ctx->cfg.dimx || h.dimy != ctx->cfg.dimy || h.ncells != ctx->ncells) { fclose(f); ctx->err = "smx_load: snapshot dimensions differ from the context's"; return -2; }
   const size_t n = ctx->ncells; const uint64_t ns = h.nsec;
+  // the header is untrusted input: the section count sizes five arrays below and every later index
+  {
+    struct stat sb;
+    const uint64_t need = sizeof(SnapHdr) + 4ull * n + 28ull * ns + 12ull * n;
+    if (ns > ctx->cfg.pool_capacity) { fclose(f); ctx->err = "smx_load: the snapshot holds more sections than pool_capacity"; return -4; }
+    if (fstat(fileno(f), &sb) != 0 || (uint64_t)sb.st_size < need) { fclose(f); ctx->err = "smx_load: truncated snapshot (shorter than its header promises)"; return -7; }
+  }
   std::vector<uint32_t> count(n), type(ns);
   std::vector<double> size(ns), floor(ns), sat(ns);
   std::vector<float> wf(n), wt(n), wi(n);
@@ -1095,6 +1116,13 @@ int smx_load(smx_ctx* ctx, const char* path) {
   RandTrailer tr; const bool have_rand = ok && fread(&tr, sizeof(tr), 1, f) == 1 && memcmp(tr.magic, "SMXRAND1", 8) == 0;
   fclose(f);
   if (!ok) { ctx->err = "smx_load: truncated snapshot"; return -7; }
+  {
+    uint64_t total = 0;
+    for (size_t c = 0; c < n; c++) total += count[c];
+    if (total != ns) { ctx->err = "smx_load: per-cell section counts do not add up to the header's section count"; return -2; }
+    for (uint64_t i = 0; i < ns; i++)
+      if (type[i] >= (uint32_t)ctx->nsoils) { ctx->err = "smx_load: a section's soil type is outside the context's soil table (smx_set_soils first)"; return -2; }
+  }
   if (smx_import_columns(ctx, count.data(), type.data(), size.data(), floor.data(), sat.data())) return -1;
   if (smx_import_frequency(ctx, wf.data(), wt.data(), wi.data())) return -1;
   if (have_rand) {
@@ -1724,7 +1752,9 @@ int smx_grid_pass(smx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, ctx->stream));
   launch_classify(ctx);
-  hipLaunchKernelGGL(k_grid_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d);
+  static const bool window = [] { const char* e = getenv("SMX_GRID_WINDOW"); return e ? atoi(e) != 0 : true; }();
+  if (window) hipLaunchKernelGGL(k_grid_serial_win, dim3(1), dim3(64), 0, ctx->stream, ctx->d);
+  else hipLaunchKernelGGL(k_grid_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1815,7 +1845,6 @@ int smx_digest(smx_ctx* ctx, double* sumh, uint64_t* nsec, uint64_t* typehash) {
   const size_t n = ctx->ncells;
   const uint64_t cap = ctx->cfg.pool_capacity;
   std::vector<Sec> cells(n);
-  std::vector<uint32_t> ptype(cap), pprev(cap);             // of a buried section only type and prev matter here
   HIPCHK(hipMemcpyAsync(cells.data(), ctx->d.cells, n * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
   // {type, prev} = the last 8 bytes of every 32-byte pool record: one strided 2D copy instead of the whole pool
   std::vector<uint64_t> tp(cap);

@@ -15,6 +15,7 @@
 #define SMX_HOSTSIM 1
 #include "../../soilmachine_amd/csrc/soil_core.h"
 #include "../../soilmachine_amd/csrc/soil_serial.h"
+#include "../../soilmachine_amd/csrc/soil_grid.h"
 #include "../../soilmachine_amd/csrc/soil_spec.h"
 #include <type_traits>
 #include "../../soilmachine_amd/csrc/soil_coop.h"
@@ -58,7 +59,7 @@ hs_ctx* hs_create(int dimx, int dimy, int scale, uint64_t cap) {
   memset(&c->d, 0, sizeof(c->d));
   c->d.dimx = dimx; c->d.dimy = dimy; c->d.scale = scale; c->d.pool_capacity = cap;
   c->n = (size_t)dimx * dimy;
-  c->cells.resize(c->n); c->pool.resize(cap); c->freelist.resize(cap); c->flags.assign(c->n, 0);
+  c->cells.resize(c->n); c->pool.resize(cap); c->freelist.resize(cap); c->flags.assign(c->n + 8, 0);   // (whole 32-bit words: SerialPolicy::set_flag)
   for (size_t i = 0; i < c->n; i++) { Sec& s = c->cells[i]; s.size = s.floor = s.sat = 0; s.type = EMPTY; s.prev = NIL; }
   for (uint64_t i = 0; i < cap; i++) c->freelist[i] = (uint32_t)(cap - 1 - i);
   c->free_count = (uint32_t)cap;
@@ -155,11 +156,11 @@ void hs_wind(hs_ctx* c, int n) {
   }
   sim.flush_counters(); pol.finish(s);
 }
-void hs_grid(hs_ctx* c) {
+static void grid_classify(hs_ctx* c) {                      // k_grid_classify
   const DevState& s = c->d;
   const size_t n = c->n;
   std::fill(c->a0.begin(), c->a0.end(), 0); std::fill(c->a1.begin(), c->a1.end(), 0); std::fill(c->a2.begin(), c->a2.end(), 0);
-  for (size_t cc = 0; cc < n; cc++) {                       // k_grid_classify
+  for (size_t cc = 0; cc < n; cc++) {
     const int x = (int)(cc / s.dimy), y = (int)(cc % s.dimy);
     bool act = (s.flags[cc] & F_SAT) != 0;
     for (int dx = -1; dx <= 1 && !act; dx++) for (int dy = -1; dy <= 1; dy++) {
@@ -167,6 +168,18 @@ void hs_grid(hs_ctx* c) {
       if (s.flags[(size_t)nx * s.dimy + ny] & F_AIR) { act = true; break; }
     }
     if (act) { c->a0[cc >> 6] |= 1ull << (cc & 63); c->a1[cc >> 12] |= 1ull << ((cc >> 6) & 63); c->a2[cc >> 18] |= 1ull << ((cc >> 12) & 63); }
+  }
+}
+static int g_grid_window = 0;                               // 1: the exact grid pass runs through the LDS-window walker (soil_grid.h)
+void hs_set_grid_window(int on) { g_grid_window = on; }
+void hs_grid(hs_ctx* c) {
+  const DevState& s = c->d;
+  const size_t n = c->n;
+  grid_classify(c);
+  if (g_grid_window) {                                      // k_grid_serial_win: one thread plays the whole team
+    std::vector<Sec> win((size_t)WIN_ROWS * WIN_WY);
+    grid_walk_windowed(s, s.soils, win.data(), 0u, 1u, [] {}, [](size_t v) { return v; });
+    return;
   }
   SerialPolicy pol(s);
   Sim<SerialPolicy> sim(s, s.soils, pol);

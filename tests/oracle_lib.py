@@ -202,8 +202,11 @@ def run_ref(soil: str, seed: int = 0, size: int = 0, ticks: int = 1, nwater: int
     raise RuntimeError("soil_ref produced no JSON line:\n" + out)
 
 
+LBM_REF_LIB = os.path.join(ORACLE_DIR, "_ref", "liblbm_ref.so")
+
+
 class LbmOracle:
-    """oracle/lbm_oracle.cpp: the reference's LBM shaders restated on the CPU (parity unpinned: see its header)."""
+    """oracle/lbm_oracle.cpp: the reference's LBM shaders restated on the CPU; pinned to the shaders themselves (LbmRef)."""
     Q = 19
 
     def __init__(self, nx, ny, nz):
@@ -237,3 +240,26 @@ class LbmOracle:
         p = np.ascontiguousarray(pos4, dtype=np.float32).copy()
         self.L.lo_move(self.h, _p(p), p.shape[0])
         return p
+
+
+_lbm_ref = None
+
+
+class LbmRef(LbmOracle):
+    """oracle/_ref/liblbm_ref.so: the reference's OWN LBM compute shaders compiled as C++ (oracle/lbm_ref.cpp) -- same calls."""
+
+    def __init__(self, nx, ny, nz):
+        global _lbm_ref
+        if _lbm_ref is None:
+            R = C.CDLL(LBM_REF_LIB)
+            vp = C.c_void_p
+            R.lo_create.argtypes = [C.c_int] * 3; R.lo_create.restype = vp
+            R.lo_destroy.argtypes = [vp]; R.lo_set_boundary.argtypes = [vp, vp]; R.lo_initialize.argtypes = [vp]
+            R.lo_step.argtypes = [vp, C.c_int]; R.lo_read.argtypes = [vp, vp, vp, vp]; R.lo_write_f.argtypes = [vp, vp]
+            R.lo_move.argtypes = [vp, vp, C.c_int]
+            for f in ("lo_destroy", "lo_set_boundary", "lo_initialize", "lo_step", "lo_read", "lo_write_f", "lo_move"):
+                getattr(R, f).restype = None
+            _lbm_ref = R
+        self.L = _lbm_ref
+        self.nx, self.ny, self.nz, self.n = nx, ny, nz, nx * ny * nz
+        self.h = self.L.lo_create(nx, ny, nz)

@@ -1,13 +1,19 @@
 """LBM wind (reference: source/include/lbmwind/lbmwind.h + shader/LBM/*.cs + shader/move.cs).
 
-The reference has no test or golden vector for this path and its GLSL cannot run here, so the CPU restatement
-(oracle/lbm_oracle.cpp) is PARITY-UNPINNED; what pins it instead is the published D3Q19 / TRT algebra it must satisfy
-(moments of the equilibrium, conservation in collisions, rest state, symmetry) and the reference's stated boundary rules.
-GPU (-m gpu): the fused HIP kernel (csrc/soil_lbm.h) against that restatement, bit for bit."""
+The reference has no test or golden vector for this path and no GL runs here -- but its shaders are near-C: the unmodified
+statements of lbmwind/shader/LBM/*.cs and shader/move.cs are compiled as C++ (oracle/lbm_ref.cpp through oracle/glsl2cpp.py +
+oracle/shim/glsl_cs.h) into oracle/_ref/liblbm_ref.so. That PINS the CPU restatement (oracle/lbm_oracle.cpp): live against
+the compiled shaders where /root/reference exists, against the committed vectors they produced (tests/golden/lbm_ref.npz)
+everywhere. On top: the published D3Q19 / TRT algebra (moments of the equilibrium, conservation in collisions, rest state,
+symmetry). GPU (-m gpu): the fused HIP kernel (csrc/soil_lbm.h) against the restatement and the golden vectors, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
-from oracle_lib import LbmOracle
+from oracle_lib import LbmOracle, LbmRef, LBM_REF_LIB
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lbm_ref.npz")
 
 CX = np.array([0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 0, 0, 1, -1, 1, -1, 0, 0])
 CY = np.array([0, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 1, -1])
@@ -23,6 +29,40 @@ def terrain_boundary(nx, ny, nz, seed=1):
     hx = 3 + 4 * (np.sin(np.arange(nx)[:, None] / 5.0) + np.cos(np.arange(nz)[None, :] / 7.0)) + rng.random((nx, nz))
     y = np.arange(ny)[None, :, None]
     return (hx[:, None, :] > y).astype(np.float32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_restatement_reproduces_the_reference_shaders_golden_vectors(case):
+    """tests/golden/lbm_ref.npz = outputs of the reference's own shader text (make_golden_lbm.py): init, N x {collide, stream}, move"""
+    g = np.load(GOLD)
+    dims, steps, seed = tuple(int(v) for v in g[f"{case}_dims"]), int(g[f"{case}_steps"]), int(g[f"{case}_seed"])
+    o = LbmOracle(*dims)
+    o.set_boundary(terrain_boundary(*dims, seed=seed)); o.initialize()
+    assert np.array_equal(bits(o.read()[2]), bits(g[f"{case}_f0"]))                            # init.cs
+    o.step(steps)
+    for name, a in zip(("rho", "v", "f"), o.read()):
+        assert np.array_equal(bits(a), bits(g[f"{case}_{name}"])), name                        # collide.cs + stream.cs
+    assert np.array_equal(bits(o.move(g[f"{case}_p"])), bits(g[f"{case}_moved"]))              # move.cs
+
+
+@pytest.mark.skipif(not os.path.exists(LBM_REF_LIB), reason="oracle/_ref/liblbm_ref.so is built where /root/reference exists")
+@pytest.mark.parametrize("dims,steps", [((64, 40, 64), 6), ((33, 17, 70), 7), ((5, 4, 3), 12)])
+def test_restatement_equals_the_compiled_reference_shaders_live(dims, steps):
+    """the reference's lattice (lbmwind.h:18-21) and two awkward shapes, every step, all three buffers + the tracers"""
+    b = terrain_boundary(*dims)
+    o, r = LbmOracle(*dims), LbmRef(*dims)
+    o.set_boundary(b); r.set_boundary(b); o.initialize(); r.initialize()
+    for k in range(steps + 1):
+        for name, a, w in zip(("rho", "v", "f"), o.read(), r.read()):
+            assert np.array_equal(bits(a), bits(w)), (name, k)
+        o.step(1); r.step(1)
+    rng = np.random.default_rng(2)
+    p = (rng.random((3000, 4)) * np.array([dims[0] - 2, dims[1] - 2, dims[2] - 2, 1]) + np.array([0.5, 0.5, 0.5, 0])).astype(np.float32)
+    assert np.array_equal(bits(o.move(p)), bits(r.move(p)))
 
 
 def test_velocity_set_is_d3q19():
@@ -118,7 +158,56 @@ def test_tracers_follow_a_uniform_wind():
     assert np.allclose(q[:, :3] - p[:, :3], v[0, :3], atol=1e-6) and np.allclose(q[:, 3], 1.0)
 
 
+def stray_tracers(nx, ny, nz):
+    """tracers the reference moves before its range check (lbmwind.h:193-215): in [N-1, N), below 0, far out, NaN"""
+    return np.array([[nx - 0.5, 2.0, 3.0, 1.0], [1.0, ny - 0.01, 2.0, 1.0], [2.0, 2.0, nz - 0.25, 1.0], [-0.75, 1.0, 1.0, 1.0],
+                     [3.0, -2.5, 1.0, 1.0], [1e9, 1.0, 1.0, 1.0], [1.0, 1.0, -1e9, 1.0], [np.nan, 1.0, 1.0, 1.0],
+                     [nx - 1.0, ny - 1.0, nz - 1.0, 1.0]], np.float32)
+
+
+def test_stray_tracers_sample_the_nearest_cell_and_never_leave_the_buffer():
+    nx, ny, nz = 8, 7, 9
+    o = LbmOracle(nx, ny, nz)
+    o.set_boundary(terrain_boundary(nx, ny, nz)); o.initialize(); o.step(2)
+    p = stray_tracers(nx, ny, nz)[:7]                                                          # (NaN -> int is undefined on the host)
+    q = o.move(p)
+    assert np.isfinite(q[:3]).all()
+    _, v, _ = o.read()
+    v = v.reshape(nx, ny, nz, 4)
+    # a tracer past the last cell in x, exactly on the lattice otherwise: both x samples clamp to the last plane
+    assert np.allclose(q[0, :3] - p[0, :3], v[nx - 1, 2, 3, :3], atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_hip_lbm_reproduces_the_reference_shaders_golden_vectors(case):
+    from soilmachine_amd.lbm import LbmWind
+    g = np.load(GOLD)
+    dims, steps, seed = tuple(int(v) for v in g[f"{case}_dims"]), int(g[f"{case}_steps"]), int(g[f"{case}_seed"])
+    w = LbmWind(*dims)
+    w.set_boundary(terrain_boundary(*dims, seed=seed)); w.initialize()
+    assert np.array_equal(bits(w.read(f=True)[2]), bits(g[f"{case}_f0"]))
+    w.step(steps)
+    for name, a in zip(("rho", "v", "f"), w.read(f=True)):
+        assert np.array_equal(bits(a), bits(g[f"{case}_{name}"])), name
+    assert np.array_equal(bits(w.move(g[f"{case}_p"])), bits(g[f"{case}_moved"]))
+
+
+@pytest.mark.gpu
+def test_hip_stray_tracers_are_clamped_like_the_restatement():
+    from soilmachine_amd.lbm import LbmWind
+    nx, ny, nz = 16, 9, 12
+    b = terrain_boundary(nx, ny, nz)
+    g, o = LbmWind(nx, ny, nz), LbmOracle(nx, ny, nz)
+    g.set_boundary(b); o.set_boundary(b); g.initialize(); o.initialize(); g.step(3); o.step(3)
+    p = stray_tracers(nx, ny, nz)
+    a, w = g.move(p), o.move(p[:7])
+    assert np.array_equal(a[:7].view(np.uint32), w.view(np.uint32))
+    assert np.array_equal(a[8].view(np.uint32), o.move(p[8:9])[0].view(np.uint32))
+    g.step(1)                                                                                  # the context survived the stray reads
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims,steps", [((64, 40, 64), 12), ((33, 17, 70), 7), ((8, 6, 300), 5)])
 def test_hip_lbm_equals_the_restatement_bit_for_bit(dims, steps):

@@ -1,0 +1,56 @@
+#!/bin/bash
+# ONE parameterised GPU job script (replaces the per-run scripts of earlier rounds):
+#   gpurun --timeout T -- 'tools/gpu_run.sh <tag> <budget-seconds> step [step ...]'
+# Every step has its own timeout, writes gpurun_out/<tag>/<step>.{log,err} and leaves a line in status.txt; steps that no
+# longer fit the budget are skipped and say so. Steps (most are thin wrappers around tools/*.py, tests/ and bench.py):
+#   smoke | quick | parity | gpusuite | wet | bench | benchfull | trace | pmc | exact4096 | envelope | relaxed | strips2 | deep300 | deep1000 | rmse10k
+set -u
+tag=$1; budget=$2; shift 2
+root="${GRAFT_REPO_ROOT:-/root/repo}"
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$root"
+t0=$(date +%s)
+left() { echo $(( budget - ($(date +%s) - t0) )); }
+note() { echo "[$(( $(date +%s) - t0 ))s] $*" | tee -a $out/status.txt; }
+run() {  # run <name> <need-seconds> <timeout> <cmd...>
+  local name=$1 need=$2 to=$3; shift 3
+  if [ "$(left)" -lt "$need" ]; then note "$name SKIPPED (left $(left)s < $need s)"; return 1; fi
+  local lim=$to; [ "$(left)" -lt "$lim" ] && lim=$(left)
+  timeout $lim "$@" > $out/$name.log 2> $out/$name.err; local rc=$?
+  note "$name rc=$rc"
+  tail -c 1500 $out/$name.log
+  [ $rc -ne 0 ] && tail -c 600 $out/$name.err
+  return $rc
+}
+for s in "$@"; do
+  case $s in
+    smoke)     run smoke 20 180 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    quick)     run quick 40 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu ;;
+    parity)    run parity 60 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_depth.py tests/test_host_compat.py -x -q -m gpu ;;
+    gpusuite)  run gpusuite 120 1500 python -m pytest tests -x -q -m gpu --durations=15 ;;
+    wet)       run wet 30 400 python tools/gpu_wet_exact.py --run ;;
+    bench)     run bench 60 400 python bench.py; cp $out/bench.log $out/bench.json 2>/dev/null ;;
+    benchfull) run benchfull 120 900 python bench.py --full; cp $out/benchfull.log $out/benchfull.json 2>/dev/null ;;
+    trace)     run trace 60 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
+    pmc)       for set in "FETCH_SIZE WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+                 n=$(echo $set | tr ' ' '_' | cut -c1-24)
+                 run pmc_$n 60 300 rocprofv3 --pmc $set --output-format csv -d $out/pmc_$n -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+               done ;;
+    pmcwet)    i=0; for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM" \
+                                  "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_BRANCH"; do
+                 i=$((i+1))
+                 run pmcwet$i 40 300 env SMX_WET_N=5 SMX_GRID_WINDOW=${WINDOW:-0} rocprofv3 --pmc $set --output-format csv -d $out/pmcwet$i -o p -- python tools/gpu_wet_exact.py --one ${ENGINE:-serial}
+                 python tools/pmc_by_kernel.py $out/pmcwet$i | tee $out/pmcwet$i.summary
+               done ;;
+    exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
+    envelope)  run envelope 60 900 python tools/p2_envelope.py --size 1024 --ticks 20 --streams 4 ;;
+    relaxed)   run relaxed 60 600 python tools/relaxed_experiment.py ;;
+    strips2)   run strips2 60 600 python tools/strips_shared_gpu.py ;;
+    deep300)   run deep300 60 900 env SMX_DEEP=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k "300" ;;
+    deep1000)  run deep1000 120 2400 env SMX_DEEP=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k "1000" ;;
+    rmse10k)   run rmse10k 120 2400 python tools/rmse_10k.py ;;
+    *)         note "unknown step $s" ;;
+  esac
+done
+note "done, $(left)s of the budget left"
