@@ -150,9 +150,6 @@ template <class P> struct RecRes { P pol; Blk b; bool ab, moved; };
 #define SMX_NOINLINE __device__ __attribute__((noinline))
 #endif
 template <class P> SMX_NOINLINE RecRes<P> wind_recurse(DevState s, const SoilP* soils, P pol, float cx, float cy, int ix, int iy);
-// P::WINDOWED: the policy keeps a window of the map's cell records somewhere faster (LDS) and redirects accesses: cref()
-template <class P, class = void> struct has_window { static constexpr bool value = false; };
-template <class P> struct has_window<P, decltype((void)P::WINDOWED)> { static constexpr bool value = P::WINDOWED; };
 template <class P, class = void> struct outline_recursion { static constexpr bool value = false; };
 template <class P> struct outline_recursion<P, decltype((void)P::OUTLINE_RECURSION)> { static constexpr bool value = P::OUTLINE_RECURSION; };
 
@@ -184,13 +181,10 @@ struct Sim {
   }
 
   // ---------------- cell access (every access announces itself to the policy first) ----------------
-  SMX_D Sec& cs(size_t c) const {                           // the record of cell c, wherever the policy keeps it
-    if constexpr (has_window<P>::value) return pol.cref(s, c); else return s.cells[c];
-  }
   SMX_D Sec& cell(int x, int y) {
     const size_t c = cidx(x, y);
     if (!pol.touch(s, c, fidx(x, y))) ab = true;
-    return cs(c);
+    return s.cells[c];
   }
   SMX_D double height(int x, int y) {                       // Layermap::height(ivec2) layermap.h:422-425
     const Sec& c = cell(x, y);
@@ -208,7 +202,7 @@ struct Sim {
   SMX_D static double vh(const View& v) { return v.floor + v.size; }
   SMX_D static uint32_t vsurf(const View& v) { return v.type == EMPTY ? 0u : v.type; }
   SMX_D View load_view(size_t c) const {
-    const Sec& r = cs(c);
+    const Sec& r = s.cells[c];
     View v; v.size = r.size; v.floor = r.floor; v.type = r.type;
     return v;
   }
@@ -219,7 +213,7 @@ struct Sim {
     pol.template prefetch<N>(s, c, f, pf);                  // stamps, claims, undo words: loads only, no waiting
     Sec r[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) r[i] = cs(c[i]);            // whole 32-byte records: the views AND the undo snapshots
+    for (int i = 0; i < N; i++) r[i] = s.cells[c[i]];       // whole 32-byte records: the views AND the undo snapshots
     if (!pol.template acquire_log<N>(s, c, pf, r)) ab = true;
 #pragma unroll
     for (int i = 0; i < N; i++) { v[i].size = r[i].size; v[i].floor = r[i].floor; v[i].type = r[i].type; }
@@ -410,7 +404,7 @@ struct Sim {
   SMX_D void add(int x, int y, double size, uint32_t type, bool owned = false) {
     if (ab) return;
     if constexpr (P::READ_ONLY) { if (!owned) (void)cell(x, y); return; }   // scout: footprint only, never writes
-    Sec& c = owned ? cs(cidx(x, y)) : cell(x, y);
+    Sec& c = owned ? s.cells[cidx(x, y)] : cell(x, y);
     if (ab) return;
     // pool.get(): the reference takes a node for EVERY get (even if add() merges and returns it at once),
     // so get() fails exactly when live sections == capacity; add(NULL) is ignored (:233)
@@ -434,7 +428,7 @@ struct Sim {
     if (popped) *popped = false;
     if (ab) return 0.0;
     if constexpr (P::READ_ONLY) { if (!owned) (void)cell(x, y); return 0.0; }
-    Sec& c = owned ? cs(cidx(x, y)) : cell(x, y);
+    Sec& c = owned ? s.cells[cidx(x, y)] : cell(x, y);
     if (ab) return 0.0;
     if (c.type == EMPTY) return 0.0;
     if (c.size <= 0.0) { pop_top(c); sync_air_flag(x, y, c.type); if (popped) *popped = true; return 0.0; }
@@ -456,7 +450,7 @@ struct Sim {
       if (h <= 0.0) return 0.0;                             // layermap.h:325
       if (h < v.size) {                                     // :328-337 with diff < 0: shrink, nothing pops
         v.size -= h;
-        cs(c).size = v.size;
+        s.cells[c].size = v.size;
         return 0.0;
       }
     }
@@ -470,7 +464,7 @@ struct Sim {
     if (size <= 0) { if (!pol.can_get(s)) n_overflow++; return; }   // pool.get + unget of an empty section (layermap.h:237-240)
     if (v.type == type && v.type != EMPTY && size > 0 && pol.can_get(s)) {   // layermap.h:249-253 elongate (pool.get + unget: net 0)
       v.size += size;
-      cs(c).size = v.size;
+      s.cells[c].size = v.size;
       return;
     }
     add(x, y, size, type, true);

@@ -25,7 +25,6 @@
 #include "../../include/soilmx.h"
 #include "soil_core.h"
 #include "soil_serial.h"
-#include "soil_grid.h"
 #include "soil_spec.h"
 #include <type_traits>
 #include <chrono>
@@ -181,18 +180,6 @@ __global__ void __launch_bounds__(64) k_grid_serial(DevState s) {
   sim.flush_counters();
   pol.add_counter(s, C_GRID_ACTIVE, visited);
   pol.finish(s);
-}
-
-// the same walk with its working set in LDS (soil_grid.h): lane 0 walks, the wavefront moves the 9 x 64-cell window
-__global__ void __launch_bounds__(64) k_grid_serial_win(DevState s) {
-  SMX_LOAD_SOILS(sh)
-  __shared__ Sec win[WIN_ROWS * WIN_WY];
-  if (blockIdx.x != 0) return;
-  grid_walk_windowed(s, sh, win, threadIdx.x, 64u, [] { __syncthreads(); },
-                     [](size_t v) {
-                       const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-                       return ((size_t)hi << 32) | (size_t)lo;
-                     });
 }
 
 // ---------------- speculative engine kernels (protocol: soil_spec.h) ----------------
@@ -1752,9 +1739,7 @@ int smx_grid_pass(smx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, ctx->stream));
   launch_classify(ctx);
-  static const bool window = [] { const char* e = getenv("SMX_GRID_WINDOW"); return e ? atoi(e) != 0 : true; }();
-  if (window) hipLaunchKernelGGL(k_grid_serial_win, dim3(1), dim3(64), 0, ctx->stream, ctx->d);
-  else hipLaunchKernelGGL(k_grid_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d);
+  hipLaunchKernelGGL(k_grid_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -46,7 +46,8 @@ def _stoi(s: str) -> int:
 
 @dataclass
 class SurfParam:
-    """POD part of SurfParam (surface.h:11-39); colour / phong are render-only and dropped."""
+    """SurfParam (surface.h:11-39). `color` / `phong` are render-only: they never reach the device tables (soils_array), but they
+    are parsed and written back so that a file written by writesoil() gives the reference GUI the same look."""
     name: str = ""
     density: float = 0.0      # uninitialised in the reference (surface.h:15); never read on the hot path
     porosity: float = 0.0
@@ -62,6 +63,13 @@ class SurfParam:
     abrades: int = 0
     suspension: float = 0.0
     abrasion: float = 0.0
+    color: str = "808080"     # COLOR rrggbb (io.h:23-33,158); surface.h:17 default vec4(0.5, 0.5, 0.5, 1.0)
+    phong: tuple = (0.5, float(np.float32(0.8)), float(np.float32(0.2)), 32.0)   # Ka Kd Ks Kk (io.h:180-183); surface.h:18 (float)
+
+    def color_rgba(self):
+        """vec4(R, G, B, 255) / 255 as hexcol computes it (io.h:23-33)"""
+        h = self.color
+        return tuple(float(np.float32(int(h[i:i + 2], 16)) / np.float32(255.0)) for i in (0, 2, 4)) + (1.0,)
 
 
 @dataclass
@@ -102,7 +110,7 @@ def _air() -> SurfParam:
     # surface.h:43-49
     return SurfParam(name="Air", density=0.0, porosity=1.0, transports=0, solubility=0.0, equrate=0.0,
                      friction=0.0, erodes=0, erosionrate=0.0, cascades=0, maxdiff=0.0, settling=0.0,
-                     abrades=0, suspension=0.0, abrasion=0.0)
+                     abrades=0, suspension=0.0, abrasion=0.0, color="003366")   # vec4(0.0, 0.2, 0.4, 1.0)
 
 
 def loadsoil(path: str) -> SoilConfig:
@@ -175,6 +183,12 @@ def loadsoil(path: str) -> SoilConfig:
                 param.suspension = _stof(val)
             elif tag == "ABRASION":
                 param.abrasion = _stof(val)
+            elif tag == "COLOR":                                  # hexcol (io.h:23-33): >= 6 characters, all of 0-9A-F
+                if len(val) < 6 or any(ch not in "0123456789ABCDEF" for ch in val):
+                    raise SyntaxError(f"Incorrect Syntax in Line {linenr}")
+                param.color = val[:6]
+            elif tag in ("Ka", "Kd", "Ks", "Kk"):
+                ph = list(param.phong); ph["adsk".index(tag[1])] = _stof(val); param.phong = tuple(ph)
         if soillayer == "LAYER":
             lay = cfg.layers[-1]
             if tag == "MIN":
@@ -227,7 +241,9 @@ def layers_array(cfg: SoilConfig) -> np.ndarray:
 
 def writesoil(cfg: SoilConfig, path: str) -> None:
     """The writer the reference only announces (io.h:232 "Should be able to also WRITE to file"): a `.soil` text that
-    ``loadsoil`` -- this module's and the reference's -- parses back into exactly these tables. Because soil indices are
+    ``loadsoil`` -- this module's and the reference's -- parses back into exactly these tables, render attributes (COLOR, Ka/Kd/Ks/Kk)
+    included: the reference carries `param` over from block to block (io.h:35), so a soil written without them would take the
+    previous block's colour in the reference GUI. Because soil indices are
     handed out at first mention (io.h:125-152) the file first declares every soil by an empty block, in index order, and
     then defines each one with ALL its keys (so nothing is inherited from the previous block, io.h:35)."""
     f32 = lambda v: repr(float(np.float32(v)))
@@ -243,7 +259,8 @@ def writesoil(cfg: SoilConfig, path: str) -> None:
                 f"SOLUBILITY {f32(s.solubility)}", f"EQUILIBRIUM {f32(s.equrate)}", f"FRICTION {f32(s.friction)}",
                 f"ERODES {names[s.erodes]}", f"EROSIONRATE {f32(s.erosionrate)}", f"CASCADES {names[s.cascades]}",
                 f"MAXDIFF {f32(s.maxdiff)}", f"SETTLING {f32(s.settling)}", f"ABRADES {names[s.abrades]}",
-                f"SUSPENSION {f32(s.suspension)}", f"ABRASION {f32(s.abrasion)}", "}", ""]
+                f"SUSPENSION {f32(s.suspension)}", f"ABRASION {f32(s.abrasion)}", f"COLOR {s.color}",
+                f"Ka {f32(s.phong[0])}", f"Kd {f32(s.phong[1])}", f"Ks {f32(s.phong[2])}", f"Kk {f32(s.phong[3])}", "}", ""]
     for l in cfg.layers:
         out += [f"LAYER {names[l.type]} {{", f"MIN {f32(l.min)}", f"BIAS {f32(l.bias)}", f"SCALE {f32(l.scale)}",
                 f"OCTAVES {f32(l.octaves)}", f"LACUNARITY {f32(l.lacunarity)}", f"GAIN {f32(l.gain)}",

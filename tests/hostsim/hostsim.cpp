@@ -15,7 +15,6 @@
 #define SMX_HOSTSIM 1
 #include "../../soilmachine_amd/csrc/soil_core.h"
 #include "../../soilmachine_amd/csrc/soil_serial.h"
-#include "../../soilmachine_amd/csrc/soil_grid.h"
 #include "../../soilmachine_amd/csrc/soil_spec.h"
 #include <type_traits>
 #include "../../soilmachine_amd/csrc/soil_coop.h"
@@ -170,17 +169,10 @@ static void grid_classify(hs_ctx* c) {                      // k_grid_classify
     if (act) { c->a0[cc >> 6] |= 1ull << (cc & 63); c->a1[cc >> 12] |= 1ull << ((cc >> 6) & 63); c->a2[cc >> 18] |= 1ull << ((cc >> 12) & 63); }
   }
 }
-static int g_grid_window = 0;                               // 1: the exact grid pass runs through the LDS-window walker (soil_grid.h)
-void hs_set_grid_window(int on) { g_grid_window = on; }
 void hs_grid(hs_ctx* c) {
   const DevState& s = c->d;
   const size_t n = c->n;
   grid_classify(c);
-  if (g_grid_window) {                                      // k_grid_serial_win: one thread plays the whole team
-    std::vector<Sec> win((size_t)WIN_ROWS * WIN_WY);
-    grid_walk_windowed(s, s.soils, win.data(), 0u, 1u, [] {}, [](size_t v) { return v; });
-    return;
-  }
   SerialPolicy pol(s);
   Sim<SerialPolicy> sim(s, s.soils, pol);
   sim.grid_mode = true;

@@ -40,7 +40,7 @@ for s in "$@"; do
     pmcwet)    i=0; for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM" \
                                   "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_BRANCH"; do
                  i=$((i+1))
-                 run pmcwet$i 40 300 env SMX_WET_N=5 SMX_GRID_WINDOW=${WINDOW:-0} rocprofv3 --pmc $set --output-format csv -d $out/pmcwet$i -o p -- python tools/gpu_wet_exact.py --one ${ENGINE:-serial}
+                 run pmcwet$i 40 300 env SMX_WET_N=5 rocprofv3 --pmc $set --output-format csv -d $out/pmcwet$i -o p -- python tools/gpu_wet_exact.py --one ${ENGINE:-serial}
                  python tools/pmc_by_kernel.py $out/pmcwet$i | tee $out/pmcwet$i.summary
                done ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Exact engines in the wet regime, from a committed-size CPU-made start state (256^2 default.soil after T0 ticks):
-per-phase ms/tick over the next N ticks for {serial, speculative} x {windowed, plain} grid walker, each in its own process
-(the switches are read once per process), and the state digest against the oracle's (made by --make on the CPU).
+per-phase ms/tick over the next N ticks for the serial and the speculative engine, each in its own process, and the state
+digest against the oracle's (made by --make on the CPU).
   --make T0 N   (CPU, container)  writes build/wet/start.snap + build/wet/expect.json
   --run         (GPU)             prints one JSON line per variant"""
 import json, os, subprocess, sys, time
@@ -46,7 +46,7 @@ def one(engine):
     dt = time.perf_counter() - t
     tm = sm.map.timing(); d = sm.map.digest()
     ok = d["nsec"] == ex["digest"]["nsec"] and d["typehash"] == ex["digest"]["typehash"] and d["sumh"] == ex["digest"]["sumh"] and d["rand_calls"] == ex["rand_calls"]
-    print(json.dumps(dict(engine=engine, window=os.environ.get("SMX_GRID_WINDOW", "1"), ticks=[ex["t0"], ex["t0"] + ex["n"]], ms_tick=1e3 * dt / ex["n"],
+    print(json.dumps(dict(engine=engine, ticks=[ex["t0"], ex["t0"] + ex["n"]], ms_tick=1e3 * dt / ex["n"],
                           ms_water=tm["ms_water"] / ex["n"], ms_grid=tm["ms_grid"] / ex["n"], bit_identical_to_oracle=ok, oracle_ms_tick=ex["oracle_ms_tick"])), flush=True)
 
 
@@ -55,5 +55,4 @@ if __name__ == "__main__":
     elif sys.argv[1] == "--one": one(sys.argv[2])
     else:
         for eng in ("serial", "spec"):
-            for win in ("1", "0"):
-                subprocess.call([sys.executable, __file__, "--one", eng], env=dict(os.environ, SMX_GRID_WINDOW=win))
+            subprocess.call([sys.executable, __file__, "--one", eng])
