@@ -56,8 +56,8 @@ def host_cpu_model() -> str:
     return ""
 
 
-def run_ref_lean(soil: str, size: int, nwater: int, nwind: int, seed: int, ticks: int, pool: int, core: int | None):
-    exe = os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean")
+def run_ref_lean(soil: str, size: int, nwater: int, nwind: int, seed: int, ticks: int, pool: int, core: int | None, exe_name: str = "soil_ref_lean"):
+    exe = os.path.join(ROOT, "oracle", "_ref", exe_name)
     cmd = [exe, "--soil", os.path.join(ROOT, "soilmachine_amd", "soils", soil), "--seed", str(seed), "--size", str(size),
            "--ticks", str(ticks), "--nwater", str(nwater), "--nwind", str(nwind), "--pool", str(pool)]
     if core is not None:
@@ -101,6 +101,19 @@ def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool
         "steps_per_tick": steps / ticks, "host_cpu": host_cpu_model(), "host_cores_total": os.cpu_count(), "wall_s": wall,
         "init_s": j["t_init"],
     }
+    out["regime_note"] = ("NOT the GPU line's tick window: the CPU sample is tick 1 of a dry map at reduced particle counts (its O(cells) grid "
+                          "pass over a dry map dominates ms_per_tick), the GPU line times later ticks at the full counts. particle-steps/s of "
+                          "the particle phases (particle_phase_steps_per_s) does not depend on the count and is the like-for-like figure; "
+                          "ms_per_tick is not comparable. tools/wet_regime.py times CPU and GPU over the same window where that fits a run.")
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref")):   # SURVEY 8d "as-is": Layermap::update's render work kept (layermap.h:475-549)
+        p = run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, 0, "soil_ref")
+        ja = parse_ref(p.communicate()[0])
+        if ja is not None:
+            ta = ja["t_water"] + ja["t_grid"] + ja["t_wind"] + ja["t_freq"]
+            out["as_is"] = {"value": (ja["steps_water_top"] + ja["steps_wind"]) / ta if ta > 0 else None, "unit": "particle-steps/s", "cores": 1, "kind": "reference",
+                            "sample": "the same sample with oracle/_ref/soil_ref: the reference's headers UNCHANGED, Layermap::update(ivec2, Vertexpool&) doing its "
+                                      "render-side work after every edit as in the real application",
+                            "ms_per_tick": 1e3 * ta / ticks, "ms_water": 1e3 * ja["t_water"] / ticks, "ms_grid": 1e3 * ja["t_grid"] / ticks, "ms_wind": 1e3 * ja["t_wind"] / ticks}
     if all_cores:
         # the reference is single-threaded: "all cores" = independent processes with different SEEDs,
         # as many as fit the box's memory (each holds its own 4096^2 layermap + POOLSIZE)
@@ -124,11 +137,14 @@ def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool
     return out
 
 
-def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None):
-    """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers)."""
+def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None, rand_seed=None, keep_heights=False):
+    """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers).
+    rand_seed: re-seed the libc stream after the terrain is built (same map, another rand() stream: the parity control)."""
     from soilmachine_amd.machine import SoilMachine
     sm = SoilMachine(cfg, n, seed=seed, nwater=nwater, nwind=nwind, dowind=dowind, pool=pool, device=device, engine=engine)
     m = sm.map
+    if rand_seed is not None:
+        m._chk(m.L.smx_srand(m.h, int(rand_seed)))
     sm.tick(warmup, sync=True)
     c0 = m.counters()
     b0 = m.batch_stats()
@@ -153,8 +169,39 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
         "engine_stats": dict({k: c1[k] - c0[k] for k in ("spec_rounds", "spec_aborts", "spec_fallbacks", "spec_executed")},
                              **{k: b1[k] - b0[k] for k in b1}),
     }
+    if keep_heights:
+        r["heights"] = m.heights()
     sm.map.close()
     return r
+
+
+def parity_block(cfg, soil, n, nwater, nwind, pool, device, ticks, nstreams, engines):
+    """Device-side parity of the throughput schedules against the EXACT engine: every run starts from the same
+    terrain (SEED 0) and ticks `ticks` times; `control` = the exact engine itself with other rand() streams (what the reference's
+    own chaos does to the same figures). Heights in map units; *_rel = value / exact - 1."""
+    import numpy as np
+    from soilmachine_amd import capi
+    def run(engine, rand_seed=None):
+        r = measure(cfg, soil, n, 0, nwater, nwind, nwind > 0, engine, pool, device, ticks, 0, rand_seed=rand_seed, keep_heights=True)
+        return r
+    t0 = time.time()
+    ex = run(capi.ENGINE_SPECULATIVE)
+    def versus(r):
+        d = r["heights"] - ex["heights"]
+        return {"height_rmse": float(np.sqrt(np.mean(d * d))), "height_max_abs": float(np.max(np.abs(d))),
+                "nsec_rel": r["digest"]["nsec"] / ex["digest"]["nsec"] - 1.0, "sumh_rel": r["digest"]["sumh"] / ex["digest"]["sumh"] - 1.0,
+                "steps_water_rel": r["steps_w"] / max(ex["steps_w"], 1) - 1.0, "steps_wind_rel": (r["steps_d"] / ex["steps_d"] - 1.0) if ex["steps_d"] else None,
+                "floods": r["floods"], "nested": r["nested"], "ms_per_tick": 1e3 * r["dt"] / ticks}
+    out = {"workload": f"{n}x{n}, soil/{soil}, SEED 0, nwater={nwater}, nwind={nwind}, ticks 1-{ticks} from the initial terrain",
+           "exact": {"nsec": ex["digest"]["nsec"], "sumh": ex["digest"]["sumh"], "steps_water": ex["steps_w"], "steps_wind": ex["steps_d"], "floods": ex["floods"],
+                     "nested": ex["nested"], "ms_per_tick": 1e3 * ex["dt"] / ticks},
+           "control_exact_other_rand_stream": [versus(run(capi.ENGINE_SPECULATIVE, rand_seed=1000 + k)) for k in range(nstreams)]}
+    for name, eng in engines:
+        out[name] = versus(run(eng))
+    ctl = [c["height_rmse"] for c in out["control_exact_other_rand_stream"]]
+    out["control_height_rmse_max"] = max(ctl) if ctl else None
+    out["wall_s"] = time.time() - t0
+    return out
 
 
 def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dist, barrier, torch):
@@ -229,8 +276,9 @@ def line_of(r, name, workload, engine_name, steps):
                 if ms > 0 else None)
             for k, nb, ms, ln in (("water", r["steps_w"] * B_WATER_STEP, tm["ms_kernel_water"], tm["launches_kernel_water"]),
                                   ("wind", r["steps_d"] * B_WIND_STEP, tm["ms_kernel_wind"], tm["launches_kernel_wind"]))},
-        "parity": "bit-exact vs the reference (tests/golden)" if engine_name != "batched" else
-                  "P2: deterministic, bit-exact vs its CPU restatement, statistical vs the reference",
+        "parity": "bit-exact vs the reference (tests/golden)" if engine_name not in ("batched", "relaxed") else
+                  ("P2: deterministic, bit-exact vs its CPU restatement, statistical vs the reference" if engine_name == "batched" else
+                   "P2: deterministic (device == host threads, any interleaving), statistical vs the reference"),
     }
 
 
@@ -243,7 +291,9 @@ def main():
     ap.add_argument("--soil", type=str, default=SOIL)
     ap.add_argument("--nwater", type=int, default=None)
     ap.add_argument("--nwind", type=int, default=None)
-    ap.add_argument("--engine", type=str, default="batched", choices=["auto", "serial", "spec", "batched"])
+    ap.add_argument("--engine", type=str, default="relaxed", choices=["auto", "serial", "spec", "batched", "relaxed"])
+    ap.add_argument("--only", type=str, default=None, help="measure just this extra line (by name) and print it")
+    ap.add_argument("--full", action="store_true", help="all extra lines (16384^2, both throughput schedules on every map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lines", action="store_true", help="only the headline measurement")
     ap.add_argument("--cpu-ticks", type=int, default=1)
@@ -264,9 +314,11 @@ def main():
     cfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", soil))
     n = args.size
     eng_name = "spec" if args.engine == "auto" else args.engine
-    engine = {"serial": capi.ENGINE_SERIAL, "spec": capi.ENGINE_SPECULATIVE, "batched": capi.ENGINE_BATCHED}[eng_name]
+    ENG = {"serial": capi.ENGINE_SERIAL, "spec": capi.ENGINE_SPECULATIVE, "batched": capi.ENGINE_BATCHED, "relaxed": capi.ENGINE_RELAXED}
+    engine = ENG[eng_name]
+    throughput = eng_name in ("batched", "relaxed")
     area = (n / 256.0) ** 2
-    if eng_name == "batched":       # throughput configuration: area-scaled counts, same ratio as the .soil file
+    if throughput:                  # throughput configuration: area-scaled counts, same ratio as the .soil file
         nwater = int(250 * area) if args.nwater is None else args.nwater
         nwind = int(250 * area * cfg.NWIND / max(cfg.NWATER, 1)) if args.nwind is None else args.nwind
     else:
@@ -282,7 +334,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    strips = world > 1 and eng_name == "batched"
+    strips = world > 1 and throughput
     dimx = n
     if strips:
         # ONE map in `world` column strips. Default (weak scaling): the map grows with N -- every GPU owns a size x size strip of
@@ -301,19 +353,21 @@ def main():
     if rank == 0:
         tm = r["tm"]
         kname = {"serial": ("k_water_serial", "k_wind_serial"), "spec": ("k_spec_exec_coop<water>", "k_spec_exec_coop<wind>"),
-                 "batched": ("k_batch_epoch<water>", "k_batch_epoch<wind>")}[eng_name]
+                 "batched": ("k_batch_epoch<water>", "k_batch_epoch<wind>"),
+                 "relaxed": ("k_relax_step<water>", "k_relax_step<wind> (+ k_batch_epoch<wind> for the exclusive tail)")}[eng_name]
         kernels = {"water": (tm["ms_kernel_water"], tm["launches_kernel_water"], r["steps_w"] * B_WATER_STEP, kname[0]),
                    "wind": (tm["ms_kernel_wind"], tm["launches_kernel_wind"], r["steps_d"] * B_WIND_STEP, kname[1])}
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, nbytes, kn = kernels[dom]
         ach = (nbytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src = None, ("not collected in this process: rocprofv3 --pmc runs as its own job (tools/gpu_run.sh pmc); no committed pass "
+                                      "matches this workload string")
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-            k = pmc.get("kernels", {}).get(kn)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+            k = pmc.get("kernels", {}).get(kn.split(" ")[0])
             if k and pmc.get("workload") == f"{n}/{nwater}/{nwind}/{eng_name}":
                 traffic = k["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r02_pmc.json (separate rocprofv3 --pmc passes of this command, not measured in this run)"
+                traffic_src = "profiles/r03_pmc.json (separate rocprofv3 --pmc passes of this command on the same box type, not measured in this run)"
         except (OSError, ValueError, KeyError):
             pass
         ncells = n * n
@@ -325,54 +379,80 @@ def main():
                         "algorithmic_bytes_per_launch": bytes_per_launch}
             return None
         phases["grid_classify"] = stream(tm["ms_kernel_classify"], tm["launches_kernel_classify"], ncells * 1.125, "k_grid_classify8 (1 flag byte/cell in, 1 bit/cell out)")
-        phases["map_frequency"] = stream(tm["ms_kernel_mapfreq"], tm["launches_kernel_mapfreq"], ncells * 12.0, "k_map_frequency (freq r/w + track r, 12 B/cell)")
-        phases["particles_water"] = {"kernel": kname[0], "achieved": kernels["water"][2] / max(kernels["water"][0] * 1e-3, 1e-12) / 1e9, "unit": "GB/s",
-                                     "frac": kernels["water"][2] / max(kernels["water"][0] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                                     "launches": kernels["water"][1], "algorithmic_bytes_per_step": B_WATER_STEP}
-        phases["particles_wind"] = {"kernel": kname[1], "achieved": kernels["wind"][2] / max(kernels["wind"][0] * 1e-3, 1e-12) / 1e9, "unit": "GB/s",
-                                    "frac": kernels["wind"][2] / max(kernels["wind"][0] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                                    "launches": kernels["wind"][1], "algorithmic_bytes_per_step": B_WIND_STEP}
+        phases["map_frequency"] = stream(tm["ms_kernel_mapfreq"], tm["launches_kernel_mapfreq"], ncells * 12.0,
+                                         "k_map_frequency (freq r/w + track r, 12 B/cell; %d MB working set%s)" % (ncells * 12 // 2**20, ", below the 256 MiB Infinity Cache: see lines[*8192*] for one past it" if ncells * 12 < 256 * 2**20 else ""))
+        for key, kk in (("particles_water", "water"), ("particles_wind", "wind")):
+            g = kernels[kk][2] / max(kernels[kk][0] * 1e-3, 1e-12) / 1e9
+            phases[key] = {"kernel": kernels[kk][3], "achieved": g, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "launches": kernels[kk][1],
+                           "avg_launch_us": 1e3 * kernels[kk][0] / max(kernels[kk][1], 1), "algorithmic_bytes_per_step": B_WATER_STEP if kk == "water" else B_WIND_STEP}
+        # whole-tick figure of SURVEY 8d: B_tick = cells * (32 + 24 * sections/cell) + 192 * water steps + 256 * wind steps, over the tick
+        spc = r["digest"]["nsec"] / ncells if isinstance(r["digest"].get("nsec"), int) else 1.5
+        b_tick = ncells * (32 + 24 * spc) + (B_WATER_STEP * r["steps_w"] + B_WIND_STEP * r["steps_d"]) / args.steps
+        tick_gbs = b_tick / (tmax / args.steps) / 1e9
         roofline = {"bound": "hbm", "kernel": kn, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": ms / max(launches, 1), "launches": launches,
                     "algorithmic_bytes_per_launch": nbytes / max(launches, 1), "phases": phases,
-                    "note": "particle kernels: a step is a ~1000-instruction dependent chain around 9 scattered 32-byte records; what bounds a "
-                            "phase is particles excluding each other where they drain together (pits, lake shores) and the longest single "
-                            "particle, not bandwidth (DESIGN.md). The O(cells) kernels are the HBM-streaming ones (phases)."}
+                    "whole_tick": {"algorithmic_bytes_per_tick": b_tick, "achieved": tick_gbs, "unit": "GB/s", "frac": tick_gbs / HBM_PEAK_GBS},
+                    "note": ("relaxed schedule: k_relax_step advances EVERY running particle by one step per launch (two 3x3 blocks of 32-byte records in, one "
+                             "request record out); each launch is bracketed by its own HIP events. " if eng_name == "relaxed" else "") +
+                            "A particle step is a ~1000-instruction f64 chain around scattered 32-byte records: latency- and issue-bound, not a stream "
+                            "(DESIGN.md). The O(cells) kernels are the HBM-streaming ones (phases)."}
 
         workload = (f"{dimx}x{n} layermap{f' (one map, {world} column strips of {dimx // world}x{n})' if strips else ''}, soil/{soil}, SEED 0, nwater={nwater}, nwind={nwind} per tick"
-                    f"{' (area-scaled, SURVEY 8d)' if eng_name == 'batched' and args.nwater is None else ''}, "
+                    f"{' (area-scaled, SURVEY 8d)' if throughput and args.nwater is None else ''}, "
                     f"tick = water + grid pass + wind + frequency")
         head = line_of(r, "headline", workload, eng_name, args.steps)
         lines = []
+        parity = None
         if not args.no_lines and world == 1:
-            k3, w3 = max(2, min(args.steps, 5)), max(1, min(args.warmup, 2))
-            extra = []
-            if eng_name == "batched":
-                extra.append(("exact_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, "spec", pool, k3, w3,
-                              f"{n}x{n}, soil/{soil}, the file's own NWATER={cfg.NWATER} / NWIND={cfg.NWIND} (round-1 headline workload)"))
-                extra.append(("batched_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, "batched", pool, k3, w3,
-                              f"{n}x{n}, soil/{soil}, NWATER={cfg.NWATER} / NWIND={cfg.NWIND}"))
+            k3, w3 = max(2, min(args.steps, 3)), max(1, min(args.warmup, 2))
             dcfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", "default.soil"))
+            bcfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", "rockgravelpebbles_big.soil"))
+            fc = f"{n}x{n}, soil/{soil}, the file's own NWATER={cfg.NWATER} / NWIND={cfg.NWIND}"
+            extra = []   # name, cfg, soil, size, nwater, nwind, engine, pool, steps, warmup, workload, in the default run?
+            if throughput:
+                # the bit-exact engine on the HEADLINE's workload (same map, same counts): what parity-green throughput is today
+                extra.append(("exact_area_scaled", cfg, soil, n, nwater, nwind, "spec", pool, 1, 1, workload, True))
+                other = "batched" if eng_name == "relaxed" else "relaxed"
+                extra.append((f"{other}_area_scaled", cfg, soil, n, nwater, nwind, other, pool, k3, w3, workload, True))
+                extra.append(("exact_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, "spec", pool, k3, w3, fc + " (round-1 headline workload)", True))
+                extra.append((f"{eng_name}_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, eng_name, pool, k3, w3, fc, True))
             for nm, wind in (("configs1_1024_default_hydraulic", 0), ("configs2_1024_default_coupled", 250)):
-                for e in ("spec", "batched"):
+                for e in ("spec", eng_name if throughput else "relaxed"):
                     extra.append((f"{nm}_{'exact' if e == 'spec' else e}", dcfg, "default.soil", 1024, 250, wind, e, 10_000_000, k3, w3,
-                                  f"1024x1024, soil/default.soil, NWATER=250, NWIND={wind} (BASELINE {nm.split('_')[0]})"))
-            if eng_name == "batched":
-                # the same density on larger maps: the phases are latency chains of about constant length, so the
-                # rate grows with the area. configs[4]'s map size with its own soil file and with the headline's.
-                bcfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", "rockgravelpebbles_big.soil"))
-                for nm, c_, s_, n_ in (("configs4_8192_rockgravelpebbles_big_batched", bcfg, "rockgravelpebbles_big.soil", 8192),
-                                       ("area_8192_batched", cfg, soil, 8192), ("area_16384_batched", cfg, soil, 16384)):
+                                  f"1024x1024, soil/default.soil, NWATER=250, NWIND={wind} (BASELINE {nm.split('_')[0]})", True))
+            if throughput:
+                # the same particle density on larger maps; configs[4]'s map size with its own soil file and with the headline's
+                for nm, c_, s_, n_, dflt in ((f"configs4_8192_rockgravelpebbles_big_{eng_name}", bcfg, "rockgravelpebbles_big.soil", 8192, True),
+                                             (f"area_8192_{eng_name}", cfg, soil, 8192, False), (f"area_16384_{eng_name}", cfg, soil, 16384, False)):
                     a_ = (n_ / 256.0) ** 2
                     nw_, nd_ = int(250 * a_), int(250 * a_ * c_.NWIND / max(c_.NWATER, 1))
-                    extra.append((nm, c_, s_, n_, nw_, nd_, "batched", max(10_000_000, 3 * n_ * n_), 2, 1,
-                                  f"{n_}x{n_}, soil/{s_}, area-scaled NWATER={nw_} / NWIND={nd_}"))
-            for (nm, c_, s_, n_, nw_, nd_, e_, pool_, k_, w_, wl_) in extra:
-                eng_ = {"spec": capi.ENGINE_SPECULATIVE, "batched": capi.ENGINE_BATCHED}[e_]
-                rr = measure(c_, s_, n_, 0, nw_, nd_, nd_ > 0, eng_, pool_, local_rank, k_, w_)
-                ln = line_of(rr, nm, wl_, "exact (speculative)" if e_ == "spec" else "batched", k_)
+                    extra.append((nm, c_, s_, n_, nw_, nd_, eng_name, max(10_000_000, 3 * n_ * n_), 2, 1,
+                                  f"{n_}x{n_}, soil/{s_}, area-scaled NWATER={nw_} / NWIND={nd_}", dflt))
+            for (nm, c_, s_, n_, nw_, nd_, e_, pool_, k_, w_, wl_, dflt) in extra:
+                if args.only is not None and nm != args.only:
+                    continue
+                if args.only is None and not (dflt or args.full):
+                    continue
+                rr = measure(c_, s_, n_, 0, nw_, nd_, nd_ > 0, ENG[e_], pool_, local_rank, k_, w_)
+                ln = line_of(rr, nm, wl_, "exact (speculative)" if e_ == "spec" else e_, k_)
                 ln["steps"], ln["warmup"] = k_, w_
+                ln["map_frequency_GBs"] = (n_ * n_ * 12.0 * rr["tm"]["launches_kernel_mapfreq"] / (rr["tm"]["ms_kernel_mapfreq"] * 1e-3) / 1e9) if rr["tm"]["ms_kernel_mapfreq"] > 0 else None
                 lines.append(ln)
+            if throughput and args.only is None:
+                # parity of the throughput schedules against the exact engine, ON THE DEVICE, next to the exact engine's own stream-to-stream
+                # spread: 1024^2 of the headline's soil at the headline's particle density (the 4096^2 version of the same table, 20 ticks and
+                # 4 control streams, is profiles/r03_p2_envelope.json: the exact engine needs minutes for it)
+                try:
+                    parity = parity_block(cfg, soil, 1024, int(250 * 16), int(250 * 16 * cfg.NWIND / max(cfg.NWATER, 1)), 10_000_000, local_rank, 8, 2,
+                                          [("relaxed", capi.ENGINE_RELAXED), ("batched", capi.ENGINE_BATCHED)])
+                except Exception as e:
+                    parity = {"error": str(e)}
+        if args.only is not None:
+            print(json.dumps(lines[0] if lines else {"error": f"no line named {args.only}"}), flush=True)
+            if dist is not None:
+                dist.barrier(); dist.destroy_process_group()
+            return
         lbm = None
         if not args.no_lines and world == 1:
             try:
@@ -384,6 +464,7 @@ def main():
             # bounded sample: an eighth of the headline's particle counts for one tick (CPU steps/s does not depend on the count)
             cw, cd = (max(nwater // 8, 1000), max(nwind // 8, 250 if nwind else 0)) if nwater > 8000 else (nwater, nwind)
             cpu = cpu_baseline(soil, n, cw, cd, args.cpu_ticks, pool, all_cores=True)
+        p2 = "P2: deterministic, statistical vs the reference (parity_vs_exact; never claimed bit-exact)"
         out = {
             "metric": "particle-steps/s", "value": total_steps / tmax, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True,
@@ -392,15 +473,15 @@ def main():
                        "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
                        "scaling_note": (None if world == 1 else ("--strong: the N=1 map split into N strips" if (strips and args.strong) else
                                         "weak: one (N*size) x size map, every GPU owns a size x size strip and 1/N of N x the particles "
-                                        "(per-GPU work = the N=1 line); the particle phases are latency chains, so splitting the N=1 map "
-                                        "(--strong) cannot shorten a tick (DESIGN.md 7)") if strips else "independent replicas (exact engines do not shard)"),
-                       "parity": head["parity"]},
+                                        "(per-GPU work = the N=1 line)") if strips else "independent replicas (exact engines do not shard)"),
+                       "parity": p2 if throughput else head["parity"],
+                       "bit_exact_line": "lines[exact_area_scaled]: the speculative engine (bit-identical to the reference) on this very workload"},
             "value_top_level": head["value_top_level"] if world == 1 else None,
             "steps_definition": "value: move()==true + interact(), top-level AND nested particles; value_top_level: top-level only "
                                 "(what cpu_baseline can count)",
             "ms_per_tick": 1e3 * tmax / args.steps, "phase_ms_per_tick": head["phase_ms_per_tick"],
             "steps_per_tick": head["steps_per_tick"], "engine_stats": head["engine_stats"], "digest": head["digest"],
-            "roofline": roofline, "cpu_baseline": cpu, "lines": lines, "lbm_wind": lbm,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_exact": parity, "lines": lines, "lbm_wind": lbm,
             # nothing was dropped inside the timed region (nested particles that did not fit the children buffer, sediment
             # that found no pool node): a line with work skipped would not be a measurement
             "work_dropped": {"children_lost": int(head["engine_stats"].get("children_lost", 0)), "pool_overflow": int(head.get("pool_overflow") or 0)},

@@ -38,9 +38,13 @@ typedef struct smx_layer {
 
 enum { SMX_ENGINE_SERIAL = 0,      /* one device walker, reference order (parity anchor)            */
        SMX_ENGINE_SPECULATIVE = 1, /* optimistic parallel particles, ordered commit, same results    */
-       SMX_ENGINE_BATCHED = 2      /* THROUGHPUT mode: all particles of a phase advance concurrently, one step
+       SMX_ENGINE_BATCHED = 2,     /* THROUGHPUT mode: all particles of a phase advance concurrently, one step
                                       per epoch, each step atomic and isolated (claim tiles). Deterministic, but NOT
-                                      the reference's particle order: statistical parity only        */ };
+                                      the reference's particle order: statistical parity only        */
+       SMX_ENGINE_RELAXED = 3      /* the batched engine with RELAXED isolation (csrc/soil_relax.h): every running particle steps
+                                      in every epoch on the epoch's start state; erosion / deposit are queued per cell and applied
+                                      in slot order with Layermap::add / remove, Particle::cascade runs once per touched cell in nine
+                                      colour passes; floods and nested particles as in BATCHED. Deterministic; statistical parity  */ };
 
 typedef struct smx_config {
   int32_t dimx, dimy;              /* SIZEX, SIZEY (SoilMachine.cpp:9-10)                            */
@@ -165,6 +169,12 @@ int smx_set_engine(smx_ctx* ctx, int32_t engine);
 /* batched engine only: widen every reservation by `tiles` 4x4-cell tiles (0 = default; >= the map's tile count makes
  * the engine run the particles strictly one after the other, i.e. in the reference's order) */
 int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles);
+/* relaxed schedule (SMX_ENGINE_RELAXED), wind phase: relaxed epochs -- every running particle takes up to `steps_per_epoch` (1..8)
+ * steps on the epoch's start state -- while more than `min_running` particles run; the survivors, a few thousand particles that fly
+ * on for up to ~13 000 steps, go on under the exclusive schedule (32 steps per launch). Part of the schedule's definition: results
+ * depend on it. Default: min_running = 0xFFFFFFFF, i.e. wind always runs the exclusive schedule (measured faster, profiles/r03_relaxed.md);
+ * 4 steps per epoch. */
+int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epoch);
 /* batched engine: column strips (DESIGN.md "Multi-GPU"). The schedule alternates INTERIOR chunks (a particle acts iff its
  * reservation lies `inset` cells inside one of `nstrips` equal x-strips) and SEAM chunks (iff inside one seam zone of
  * +-seam_halfwidth cells around a strip boundary). nstrips == 1 (default) = the single-strip schedule. The result is a

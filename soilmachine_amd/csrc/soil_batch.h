@@ -61,7 +61,11 @@ struct BChild {                               // a nested WaterParticle waiting 
 struct BStrips { int n; int x[9]; int a, b; };
 constexpr int STRIP_INTERIOR = 0, STRIP_SEAM = 1;
 
-enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_COUNT = 16 };
+// relaxed schedule, per epoch parity p = epoch & 1: BC_NFLOOD + p = length of the flood list, BC_NFLAG + p = cells flagged for a cascade,
+// BC_NCASC + 9 * p + colour = length of a colour's cascade list
+// BC_NRUN + p = particles that stepped in the epoch
+enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_LIST_LOST, BC_NFLOOD = 8, BC_NFLAG = 10, BC_NCASC = 12, BC_NRUN = 30, BC_COUNT = 32 };
+constexpr int R_MAXSTEPS = 8;                 // relaxed schedule: steps one wind particle may take per epoch (2 request entries each)
 
 struct BatchShared {
   unsigned long long* claim[2];               // sized for one word per CELL; indexed [tx * nty + ty] at the current granularity
@@ -77,7 +81,19 @@ struct BatchShared {
   BStrips strips; int sphase;                 // column strips and the kind of the running chunk
   uint8_t* dirty;                             // [grid tiles] strips only: columns of this 4x4 tile changed since the last halo exchange
   int own_x0, own_x1;                         // strips on several devices: particles spawning outside [own_x0, own_x1) live elsewhere
+  // RELAXED schedule (soil_relax.h): running particles step without reservations; their map edits are queued per cell
+  int relaxed;                                // 1: the epoch kernel only runs floods (B_ENDED); running particles belong to relax_*_step
+  int rstride, rsteps;                        // request entries per slot (2 per step); steps a particle may take per epoch (water 1)
+  uint32_t rtag;                              // this epoch's tag for the cascade flags (unique over the context's life, never 0)
+  struct RReq* req;                           // [rstride * slots] queued edits of this epoch
+  uint32_t* rnext;                            // [rstride * slots] next entry of the same cell's list
+  uint32_t* rcount;                           // [slots] entries this slot queued in this epoch
+  uint32_t* rhead;                            // [cells] newest entry queued for the cell (NIL: none)
+  uint32_t* cflag;                            // [cells] tag of the last epoch that asked for Particle::cascade here
+  uint32_t* flist[2]; uint32_t* flagl[2]; uint32_t* clist[2];   // per epoch parity: flood list (slots), flagged cells, cascade lists [9 colours][clist_cap]
+  uint32_t list_cap, flag_cap, clist_cap;
 };
+struct RReq { double amount, vol; uint32_t cell, type, kind, casc; };   // kind: R_* bits; casc: cell whose cascade this step asks for (NIL: none)
 
 SMX_D unsigned long long btag(uint32_t epoch, uint32_t slot) { return ((unsigned long long)(epoch + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - slot); }
 SMX_D bool brect_empty(const BRect& r) { return r.tx1 < r.tx0; }
@@ -277,6 +293,7 @@ SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
   // reference constructs a particle right before it runs, so it sees what earlier particles did to that cell. (A nested
   // particle takes it from a random cell somewhere on the map, water.h:251 -- that read happens here, where nothing writes.)
   q.w = w; q.state = child ? B_RUN : B_NEW;
+  if (bs.rcount) bs.rcount[slot] = 0u;
   q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.hint = 0; q.pnx = -1; q.pny = -1;
   q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_water_reclaim
   if (w.ix < bs.own_x0 || w.ix >= bs.own_x1) q.state = B_AWAY;
@@ -296,6 +313,7 @@ SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
   const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
   Wind d;
   sim.wind_init(d, rx, ry);
+  if (bs.rcount) bs.rcount[slot] = 0u;
   q.d = d; q.hint = 0; q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad2 = 0; q.pnx = -1; q.pny = -1;
   q.state = B_NEW;                                           // `contains` (wind.h:19-21) is read when the particle first acts
   q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_wind_reclaim
@@ -309,6 +327,7 @@ template <class P>
 SMX_D void batch_water_reclaim(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
   BWater& q = bs.water[slot];
   if (q.state == B_DONE || q.state == B_AWAY) return;
+  if (bs.relaxed && (q.state == B_RUN || q.state == B_NEW)) { q.rect = BRect{0, -1, 0, -1}; return; }   // (steps without reservations)
   BRect r;
   if (q.state == B_ENDED) {
     if (!water_floods(q.w)) { q.state = B_DONE; q.rect = BRect{0, -1, 0, -1}; return; }
@@ -326,6 +345,7 @@ template <class P>
 SMX_D void batch_wind_reclaim(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
   BWind& q = bs.wind[slot];
   if (q.state == B_DONE || q.state == B_AWAY) return;
+  if (bs.relaxed) { q.rect = BRect{0, -1, 0, -1}; return; }  // (steps without reservations)
   Blk A;
   sim.template load_block<1>(q.d.ix, q.d.iy, A);
   Wind t; bool mv;
@@ -344,6 +364,7 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
   BWater& q = bs.water[slot];
   uint32_t state = q.state;
   if (state == B_DONE || state == B_AWAY) return;
+  if (bs.relaxed && (state == B_RUN || state == B_NEW)) return;   // relaxed schedule: this kernel only runs the floods
   BRect rect = q.rect;
   const int cur = (int)(epoch & 1u), nxt = cur ^ 1;
   // A particle that acted in the previous epoch is, as a rule, the head of its queue and holds again: request the two

@@ -64,6 +64,7 @@ inline uint32_t host_atomic_cas(uint32_t* p, uint32_t expected, uint32_t desired
 #define SMX_A_SUB(p, v) __atomic_fetch_sub((p), (v), __ATOMIC_SEQ_CST)
 #define SMX_A_ADD64(p, v) __atomic_fetch_add((p), (unsigned long long)(v), __ATOMIC_SEQ_CST)
 #define SMX_A_MAX64(p, v) smx::host_atomic_max64((p), (v))
+#define SMX_A_XCHG(p, v) __atomic_exchange_n((p), (v), __ATOMIC_SEQ_CST)
 namespace smx {
 inline unsigned long long host_atomic_max64(unsigned long long* p, unsigned long long v) {
   unsigned long long o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
@@ -81,6 +82,7 @@ inline unsigned long long host_atomic_max64(unsigned long long* p, unsigned long
 #define SMX_A_SUB(p, v) atomicSub((p), (v))
 #define SMX_A_ADD64(p, v) atomicAdd((p), (unsigned long long)(v))
 #define SMX_A_MAX64(p, v) atomicMax((p), (unsigned long long)(v))
+#define SMX_A_XCHG(p, v) atomicExch((p), (v))
 #endif
 
 namespace smx {

@@ -31,6 +31,7 @@
 #include "soil_coop.h"
 #include "soil_noise.h"
 #include "soil_batch.h"
+#include "soil_relax.h"
 #include "soil_lbm.h"
 #include <algorithm>
 
@@ -296,6 +297,181 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if constexpr (WIND) batch_wind_epoch(sim, bs, bs.live[i], epoch);
   else { Frame st[MAX_FRAMES]; batch_water_epoch(sim, bs, bs.live[i], epoch, st); }
   sim.flush_counters(); pol.finish(s);
+}
+// ---------------- relaxed schedule (soil_relax.h): step -> apply -> nine cascade colours (-> floods), per epoch ----------------
+template <bool WIND>
+__global__ void __launch_bounds__(64) k_relax_step(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch, uint32_t lpw) {
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * lpw + threadIdx.x;
+  if (threadIdx.x >= lpw || i >= nlive) return;
+  BatchPolicy pol(s, bs);
+  Sim<BatchPolicy> sim(s, sh, pol);
+  if constexpr (WIND) relax_wind_step(sim, bs, bs.live[i], epoch); else relax_water_step(sim, bs, bs.live[i], epoch);
+}
+__global__ void __launch_bounds__(64) k_relax_apply(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch) {
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i == 0u) {                                             // the lists of the NEXT epoch start empty (their last readers finished an epoch ago)
+    const uint32_t par = (epoch + 1u) & 1u;
+    bs.ctrl[BC_NFLOOD + par] = 0u; bs.ctrl[BC_NFLAG + par] = 0u; bs.ctrl[BC_NRUN + par] = 0u;
+    for (uint32_t k = 0; k < 9u; k++) bs.ctrl[BC_NCASC + 9u * par + k] = 0u;
+  }
+  if (i >= nlive) return;
+  BatchPolicy pol(s, bs);
+  Sim<BatchPolicy> sim(s, sh, pol);
+  relax_apply_slot(sim, bs, bs.live[i]);
+  sim.flush_counters(); pol.finish(s);
+}
+// wave-reduced commit of the cascade counters of the relaxed kernels (one atomic per wavefront)
+__device__ __forceinline__ void relax_commit_cascade_counters(const DevState& s, unsigned long long nc, unsigned long long nt) {
+  for (int off = 32; off > 0; off >>= 1) { nc += (unsigned long long)__shfl_down((long long)nc, off); nt += (unsigned long long)__shfl_down((long long)nt, off); }
+  if ((threadIdx.x & 63u) == 0) { if (nc) atomicAdd(&s.ctr[C_CASCADE_CALLS], nc); if (nt) atomicAdd(&s.ctr[C_CASCADE_TRANSFERS], nt); }
+}
+__global__ void __launch_bounds__(64) k_relax_filter(DevState s, BatchShared bs, uint32_t epoch) {
+  const uint32_t par = epoch & 1u;
+  uint32_t n = bs.ctrl[BC_NFLAG + par];
+  if (n > bs.flag_cap) n = bs.flag_cap;
+  if (blockIdx.x * 64u >= n) return;                         // (the launch is sized for the worst case: most blocks leave here)
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  BatchPolicy pol(s, bs);
+  Sim<BatchPolicy> sim(s, sh, pol);
+  relax_filter(sim, bs, i < n ? bs.flagl[par][i] : 0u, i < n, epoch);
+  sim.flush_counters();
+  relax_commit_cascade_counters(s, pol.a_casc, 0ull);
+}
+__global__ void __launch_bounds__(64) k_relax_cascade(DevState s, BatchShared bs, uint32_t epoch, uint32_t colour) {
+  const uint32_t par = epoch & 1u;
+  uint32_t n = bs.ctrl[BC_NCASC + 9u * par + colour];
+  if (n > bs.clist_cap) n = bs.clist_cap;
+  if (blockIdx.x * 64u >= n) return;
+  SMX_LOAD_SOILS(sh)
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  unsigned long long nc = 0, nt = 0;
+  if (i < n) {
+    BatchPolicy pol(s, bs);
+    Sim<BatchPolicy> sim(s, sh, pol);
+    relax_cascade(sim, bs.clist[par][(size_t)colour * bs.clist_cap + i]);
+    sim.flush_counters(); pol.finish(s);
+    nc = pol.a_casc; nt = pol.a_tr;
+  }
+  relax_commit_cascade_counters(s, nc, nt);
+}
+// the floods of the relaxed schedule: batch_water_epoch over this epoch's list of ended particles; who is not done joins the next
+// list. The launch has a fixed number of wavefronts; the floods are spread over them as thinly as the list allows (a wavefront costs
+// the union of its lanes' paths, and a flood is a long, branchy path).
+__global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs, uint32_t epoch) {
+  const uint32_t par = epoch & 1u;
+  uint32_t n = bs.ctrl[BC_NFLOOD + par];
+  if (n > bs.list_cap) n = bs.list_cap;
+  uint32_t lpw = (n + gridDim.x - 1u) / gridDim.x;
+  if (lpw > 64u) lpw = 64u;
+  if (blockIdx.x * lpw >= n) return;
+  SMX_LOAD_SOILS(sh)
+  // (n > 64 * gridDim.x cannot happen: the host sizes the launch for the generation's slots)
+  const uint32_t i = blockIdx.x * lpw + threadIdx.x;
+  const bool act = threadIdx.x < lpw && i < n;
+  bool again = false; uint32_t slot = 0u;
+  if (!relax_floods_due(epoch, n, bs.ctrl[BC_NRUN + par])) {  // not this epoch: the whole list moves on
+    if (act) slot = bs.flist[par][i];
+    relax_flood_later(bs, slot, par ^ 1u, act);
+    return;
+  }
+  if (act) {
+    slot = bs.flist[par][i];
+    BatchPolicy pol(s, bs);
+    Sim<BatchPolicy> sim(s, sh, pol);
+    Frame st[MAX_FRAMES];
+    batch_water_epoch(sim, bs, slot, epoch, st);
+    sim.flush_counters(); pol.finish(s);
+    again = bs.water[slot].state != B_DONE;
+  }
+  relax_flood_later(bs, slot, par ^ 1u, again);
+}
+// The tail of a relaxed water generation (a few hundred particles left, for hundreds of epochs; and every nested generation after
+// its first steps): ONE workgroup runs whole epochs back to back -- step, apply, filter, nine cascade colours, floods -- with
+// workgroup barriers where the dense schedule has kernel boundaries. Same phases, same order, same results; no launch per phase.
+constexpr uint32_t RELAX_TAIL = 1024;                         // running particles up to which the tail kernel takes over
+__global__ void __launch_bounds__(256) k_relax_tail(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch0, uint32_t nepochs, uint32_t tag0) {
+  SMX_LOAD_SOILS(sh)
+  __shared__ uint32_t busy;
+  for (uint32_t k = 0; k < nepochs; k++) {
+    const uint32_t epoch = epoch0 + k, par = epoch & 1u;
+    bs.rtag = tag0 + k;
+    if (threadIdx.x == 0) busy = 0u;
+    __syncthreads();
+    uint32_t mine = 0u;
+    for (uint32_t i = threadIdx.x; i < nlive; i += 256u) {                                       // step
+      BatchPolicy pol(s, bs);
+      Sim<BatchPolicy> sim(s, sh, pol);
+      const uint32_t slot = bs.live[i];
+      relax_water_step(sim, bs, slot, epoch);
+      mine |= (bs.water[slot].state != B_DONE || bs.rcount[slot] != 0u) ? 1u : 0u;   // (a particle's last step still has edits to apply)
+    }
+    if (mine) busy = 1u;
+    if (threadIdx.x == 0) {                                                                      // the lists of the next epoch start empty
+      bs.ctrl[BC_NFLOOD + (par ^ 1u)] = 0u; bs.ctrl[BC_NFLAG + (par ^ 1u)] = 0u; bs.ctrl[BC_NRUN + (par ^ 1u)] = 0u;
+      for (uint32_t q = 0; q < 9u; q++) bs.ctrl[BC_NCASC + 9u * (par ^ 1u) + q] = 0u;
+    }
+    __syncthreads();
+    if (!busy) break;                                                                            // every particle of the generation is done
+    for (uint32_t i = threadIdx.x; i < nlive; i += 256u) {                                       // apply
+      BatchPolicy pol(s, bs);
+      Sim<BatchPolicy> sim(s, sh, pol);
+      relax_apply_slot(sim, bs, bs.live[i]);
+      sim.flush_counters(); pol.finish(s);
+    }
+    __syncthreads();
+    unsigned long long nc = 0, nt = 0;
+    {                                                                                            // filter
+      uint32_t n = SMX_A_LOAD(&bs.ctrl[BC_NFLAG + par]);
+      if (n > bs.flag_cap) n = bs.flag_cap;
+      for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        BatchPolicy pol(s, bs);
+        Sim<BatchPolicy> sim(s, sh, pol);
+        relax_filter(sim, bs, i < n ? bs.flagl[par][i] : 0u, i < n, epoch);
+        sim.flush_counters();
+        nc += pol.a_casc;
+      }
+    }
+    __syncthreads();
+    for (uint32_t q = 0; q < 9u; q++) {                                                          // the nine cascade colours
+      uint32_t n = SMX_A_LOAD(&bs.ctrl[BC_NCASC + 9u * par + q]);
+      if (n > bs.clist_cap) n = bs.clist_cap;
+      if (n == 0u) continue;                                                                     // (uniform: every thread reads the same count)
+      for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        BatchPolicy pol(s, bs);
+        Sim<BatchPolicy> sim(s, sh, pol);
+        relax_cascade(sim, bs.clist[par][(size_t)q * bs.clist_cap + i]);
+        sim.flush_counters(); pol.finish(s);
+        nc += pol.a_casc; nt += pol.a_tr;
+      }
+      __syncthreads();
+    }
+    relax_commit_cascade_counters(s, nc, nt);
+    {                                                                                            // floods
+      uint32_t n = SMX_A_LOAD(&bs.ctrl[BC_NFLOOD + par]);
+      if (n > bs.list_cap) n = bs.list_cap;
+      const bool due = relax_floods_due(epoch, n, SMX_A_LOAD(&bs.ctrl[BC_NRUN + par]));
+      for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool again = false; uint32_t slot = 0u;
+        if (i < n && !due) { slot = bs.flist[par][i]; again = true; }                            // not this epoch: the list moves on
+        else if (i < n) {
+          slot = bs.flist[par][i];
+          BatchPolicy pol(s, bs);
+          Sim<BatchPolicy> sim(s, sh, pol);
+          Frame st[MAX_FRAMES];
+          batch_water_epoch(sim, bs, slot, epoch, st);
+          sim.flush_counters(); pol.finish(s);
+          again = bs.water[slot].state != B_DONE;
+        }
+        relax_flood_later(bs, slot, par ^ 1u, again);
+      }
+    }
+    __syncthreads();
+  }
 }
 // how many particles share a wavefront: as few as fill `SMX_BATCH_WAVES` wavefronts (default 256 = one per CU; 0 = always 64;
 // measured in profiles/r02_batched_schedules.md, sweep 5). Which lane runs a slot has no influence on results.
@@ -696,6 +872,11 @@ struct smx_ctx {
   BChild* d_kids = nullptr; uint32_t kids_cap = 0;
   uint32_t* h_bctrl = nullptr;
   int batch_dilate = 0;
+  uint32_t relax_wind_min = 0xFFFFFFFFu;   // relaxed schedule: wind runs relaxed while more particles than this are running (default: never --
+                                      // measured, profiles/r03_relaxed.md: the exclusive schedule's 8-32 steps per launch serve wind better)
+  int relax_wind_steps = 4;           // ... taking up to this many steps per epoch (<= R_MAXSTEPS)
+  uint32_t relax_tag = 0;             // epoch tags of the cascade flags (unique over the context's life)
+  uint32_t relax_cap = 0;             // slots the relaxed schedule's buffers are sized for
   int strips_n = 1, strips_a = 16, strips_b = 48;
   int own_x0 = 0, own_x1 = -1;        // strips on several devices: the columns this context owns (-1: to the map's edge)
   // step-wise generation state (smx_d_*)
@@ -732,6 +913,7 @@ static void drain_events(smx_ctx* ctx) {
       case 6: ctx->timing.ms_kernel_classify += ms; ctx->timing.launches_kernel_classify += p.launches; break;
       case 7: ctx->timing.ms_kernel_gridtiles += ms; ctx->timing.launches_kernel_gridtiles += p.launches; break;
       case 8: ctx->timing.ms_kernel_mapfreq += ms; ctx->timing.launches_kernel_mapfreq += p.launches; break;
+      case 9: break;                                            // (k_relax_tail: part of its phase's time, no line of its own)
       default: ctx->timing.ms_freq += ms; ctx->timing.launches_freq++; break;
     }
     ctx->evpool.push_back(p.a); ctx->evpool.push_back(p.b);
@@ -802,6 +984,8 @@ int smx_create(const smx_config* cfg, smx_ctx** out) {
   const smx_soil air = {0, 0, 0, 0, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // surface.h:43-49
   if (smx_set_soils(ctx, &air, 1)) return -1;
   if (smx_srand(ctx, 1)) return -1;
+  if (const char* e = getenv("SMX_RELAX_WIND_MIN")) ctx->relax_wind_min = (uint32_t)atoll(e);   // (experiments)
+  if (const char* e = getenv("SMX_RELAX_WIND_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= R_MAXSTEPS) ctx->relax_wind_steps = v; }
   return 0;
 }
 
@@ -825,7 +1009,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(bs.rhead); hipFree(bs.cflag); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -860,6 +1044,11 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) {
     ctx->err = "smx_set_batch_dilate: reservations with this margin do not fit the seam zones of the column strips"; return -2;
   }
   ctx->batch_dilate = tiles;
+  return 0;
+}
+int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epoch) {
+  if (steps_per_epoch < 1 || steps_per_epoch > R_MAXSTEPS) { ctx->err = "smx_set_relax_wind: 1..8 steps per epoch"; return -2; }
+  ctx->relax_wind_min = min_running; ctx->relax_wind_steps = steps_per_epoch;
   return 0;
 }
 int smx_set_batch_strips(smx_ctx* ctx, int32_t nstrips, int32_t inset, int32_t seam_halfwidth) {
@@ -1333,6 +1522,25 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
     HIPCHK(hipMalloc(&bs.live, (size_t)cap * 4));
     ctx->batch_cap = cap;
   }
+  if (ctx->cfg.engine == SMX_ENGINE_RELAXED && ctx->relax_cap < ctx->batch_cap) {   // request entries (2 per step), per-epoch flood and cascade lists
+    hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]);
+    hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); bs.flagl[0] = bs.flagl[1] = nullptr;
+    bs.req = nullptr; bs.rnext = nullptr; bs.rcount = nullptr; bs.flist[0] = bs.flist[1] = bs.clist[0] = bs.clist[1] = nullptr; ctx->relax_cap = 0;
+    const uint32_t cap = ctx->batch_cap;
+    const size_t ent = (size_t)cap * 2 * R_MAXSTEPS;
+    HIPCHK(hipMalloc(&bs.req, ent * sizeof(RReq))); HIPCHK(hipMalloc(&bs.rnext, ent * 4)); HIPCHK(hipMalloc(&bs.rcount, (size_t)cap * 4));
+    HIPCHK(hipMemsetAsync(bs.rcount, 0, (size_t)cap * 4, ctx->stream));
+    bs.list_cap = cap; bs.flag_cap = (uint32_t)ent; bs.clist_cap = (uint32_t)std::max<size_t>(4096, ent / 2);
+    for (int k = 0; k < 2; k++) {
+      HIPCHK(hipMalloc(&bs.flist[k], (size_t)bs.list_cap * 4)); HIPCHK(hipMalloc(&bs.flagl[k], (size_t)bs.flag_cap * 4));
+      HIPCHK(hipMalloc(&bs.clist[k], (size_t)9 * bs.clist_cap * 4));
+    }
+    ctx->relax_cap = cap;
+  }
+  if (ctx->cfg.engine == SMX_ENGINE_RELAXED && !bs.rhead) {   // per-cell request lists and cascade flags (8 B / cell), empty between epochs
+    HIPCHK(hipMalloc(&bs.rhead, ctx->ncells * 4)); HIPCHK(hipMalloc(&bs.cflag, ctx->ncells * 4));
+    HIPCHK(hipMemsetAsync(bs.rhead, 0xFF, ctx->ncells * 4, ctx->stream)); HIPCHK(hipMemsetAsync(bs.cflag, 0, ctx->ncells * 4, ctx->stream));
+  }
   if (ctx->draws_cap < 2u * nslots) {
     hipFree(ctx->d_draws); if (ctx->h_draws) hipHostFree(ctx->h_draws); ctx->d_draws = nullptr; ctx->h_draws = nullptr; ctx->draws_cap = 0;
     const uint32_t cap = 2u * (nslots < 4096u ? 4096u : nslots);
@@ -1340,6 +1548,7 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
     ctx->draws_cap = cap;
   }
   bs.draws = ctx->d_draws; bs.dilate = ctx->batch_dilate; bs.maxsteps = 1;
+  bs.relaxed = 0;                                             // (set per generation by batch_generations)
   bs.strips = batch_make_strips(ctx->cfg.dimx, ctx->strips_n, ctx->strips_a, ctx->strips_b); bs.sphase = STRIP_INTERIOR;
   bs.own_x0 = ctx->own_x0; bs.own_x1 = ctx->own_x1 < 0 ? ctx->cfg.dimx : ctx->own_x1;
   (void)wind;
@@ -1364,6 +1573,9 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     }
     HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
     ctx->bs.tshift = -1;                                      // (the first chunk clears the planes and issues the first reservations)
+    const bool relax_gen = ctx->cfg.engine == SMX_ENGINE_RELAXED && ctx->bs.strips.n <= 1;
+    ctx->bs.relaxed = relax_gen ? 1 : 0;
+    if (relax_gen) HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // flood, flag and cascade lists start empty
     const BChild* dk = nullptr;
     if (!first) {
       if (ctx->kids_cap < nslots) { hipFree(ctx->d_kids); ctx->d_kids = nullptr; ctx->kids_cap = 0; HIPCHK(hipMalloc(&ctx->d_kids, (size_t)nslots * sizeof(BChild))); ctx->kids_cap = nslots; }
@@ -1393,7 +1605,11 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
         }
       }
       const bool strips = bs.strips.n > 1;
-      const bool regrain = sc.tshift != bs.tshift;             // first chunk, or the claim granularity changes
+      // relaxed schedule (SMX_ENGINE_RELAXED): water always; wind while many particles run -- its tail (a few thousand particles that
+      // fly on for up to ~13 000 steps) is better served by the exclusive schedule's 32 steps per launch. One switch per generation.
+      const bool relaxed_now = relax_gen && (!wind || nlive > ctx->relax_wind_min);
+      bool regrain = sc.tshift != bs.tshift;                   // first chunk, or the claim granularity changes
+      if (relax_gen && !relaxed_now && ctx->bs.relaxed) { ctx->bs.relaxed = 0; regrain = true; }   // hand the survivors to the exclusive schedule: fresh reservations
       batch_apply_schedule(ctx->bs, ctx->d, sc);               // (bs aliases ctx->bs: passed by value per launch)
       ctx->bs.sphase = strips ? (int)(chunk & 1u) : STRIP_INTERIOR;   // column strips: INTERIOR and SEAM chunks alternate
       if (strips && chunk > 0) epoch++;                        // (reservations of the previous chunk must not look current)
@@ -1406,7 +1622,39 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
       }
       const auto t_chunk = std::chrono::steady_clock::now();
       const uint32_t live_in = nlive;
-      {
+      int chunk_epochs = CHUNK;
+      if (relaxed_now) {
+        // relaxed schedule: per epoch one step of every running particle, the queued edits per cell, the nine cascade colours,
+        // then one flood epoch behind claim tiles. Nested generations live a few steps: shorter chunks there.
+        static const int RCHUNK_KIDS = [] { const char* e = getenv("SMX_RELAX_CHUNK_KIDS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+        chunk_epochs = first ? CHUNK : RCHUNK_KIDS;
+        const uint32_t lpw = batch_lanes_per_wave(nlive);
+        const unsigned nbl = (nlive + lpw - 1u) / lpw, nb64 = (nlive + 63u) / 64u;
+        ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : 2; ctx->bs.rsteps = wind ? ctx->relax_wind_steps : 1;
+        const unsigned ncb = (unsigned)(((size_t)nlive * (size_t)(wind ? ctx->bs.rstride : 1) + 63u) / 64u);   // worst case of the flagged / one cascade list
+        const unsigned nfb = std::max(1024u, (unsigned)((nlive + 63u) / 64u));   // floods: at least 1024 wavefronts to spread over
+        static const bool use_tail = [] { const char* e = getenv("SMX_RELAX_TAIL"); return e ? atoi(e) != 0 : true; }();
+        if (!wind && use_tail && nlive <= RELAX_TAIL) {        // few particles left: whole epochs inside one workgroup (k_relax_tail)
+          chunk_epochs = 64;
+          if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(bs.cflag, 0, ctx->ncells * 4, st)); }   // (tags never repeat)
+          PhaseTimer tk(ctx, 9, (uint32_t)chunk_epochs);
+          hipLaunchKernelGGL(k_relax_tail, dim3(1), dim3(256), 0, st, ctx->d, bs, nlive, epoch, (uint32_t)chunk_epochs, ctx->relax_tag + 1u);
+          ctx->relax_tag += (uint32_t)chunk_epochs; epoch += (uint32_t)chunk_epochs;
+        } else
+        for (int k = 0; k < chunk_epochs; k++, epoch++) {
+          if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(bs.cflag, 0, ctx->ncells * 4, st)); }   // (tags never repeat)
+          ctx->bs.rtag = ++ctx->relax_tag;
+          {
+            PhaseTimer tk(ctx, wind ? 5 : 4, 1u);             // every launch of the step kernel between its own pair of events
+            if (wind) hipLaunchKernelGGL(k_relax_step<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+            else hipLaunchKernelGGL(k_relax_step<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+          }
+          hipLaunchKernelGGL(k_relax_apply, dim3(nb64), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+          hipLaunchKernelGGL(k_relax_filter, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch);
+          for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch, col);
+          if (!wind) hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch);
+        }
+      } else {
         PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)CHUNK);   // CHUNK back-to-back launches of the epoch kernel, nothing else
         const uint32_t lpw = batch_lanes_per_wave(nlive);
         const unsigned nbl = (nlive + lpw - 1u) / lpw;
@@ -1429,9 +1677,9 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
       HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       nlive = ctx->h_bctrl[BC_NLIVE];
-      ctx->batch_epochs += CHUNK;
+      ctx->batch_epochs += chunk_epochs;
       if (trace) fprintf(stderr, "[soilmx] batched %s gen-slots %u epochs %u..%u live %u -> %u grain %d dilate %d maxsteps %d  %.3f ms\n", wind ? "wind " : "water", nslots,
-                         epoch - CHUNK, epoch, live_in, nlive, 1 << bs.tshift, bs.dilate, bs.maxsteps, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count());
+                         epoch - chunk_epochs, epoch, live_in, nlive, 1 << bs.tshift, bs.dilate, bs.maxsteps, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count());
     }
     if (wind) hipLaunchKernelGGL(k_batch_counters<true>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
     else hipLaunchKernelGGL(k_batch_counters<false>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
@@ -1440,6 +1688,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     uint32_t nc = ctx->h_bctrl[BC_NCHILD];
     if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
     if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
+    if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
     if (nc > bs.child_cap) nc = bs.child_cap;
     kids.resize(nc);
     if (nc) HIPCHK(hipMemcpyAsync(kids.data(), bs.children, (size_t)nc * sizeof(BChild), hipMemcpyDeviceToHost, st));
@@ -1722,11 +1971,12 @@ int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t tx_lo, int32_t tx_hi) 
 }
 }  // extern "C"
 
+static bool is_batched(const smx_ctx* ctx) { return ctx->cfg.engine == SMX_ENGINE_BATCHED || ctx->cfg.engine == SMX_ENGINE_RELAXED; }
 extern "C" {
 // ---------------- the hot path ----------------
 int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   PhaseTimer t(ctx, 0);
-  if (ctx->cfg.engine == SMX_ENGINE_BATCHED) return batch_generations(ctx, false, nwater > 0 ? (uint32_t)nwater : 0u, {});
+  if (is_batched(ctx)) return batch_generations(ctx, false, nwater > 0 ? (uint32_t)nwater : 0u, {});
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwater, false);
   PhaseTimer tk(ctx, 4);
   hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwater);
@@ -1735,7 +1985,7 @@ int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
 }
 int smx_grid_pass(smx_ctx* ctx) {
   PhaseTimer t(ctx, 1);
-  if (ctx->cfg.engine == SMX_ENGINE_BATCHED) return batch_grid(ctx);
+  if (is_batched(ctx)) return batch_grid(ctx);
   HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, ctx->stream));
   launch_classify(ctx);
@@ -1745,7 +1995,7 @@ int smx_grid_pass(smx_ctx* ctx) {
 }
 int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
   PhaseTimer t(ctx, 2);
-  if (ctx->cfg.engine == SMX_ENGINE_BATCHED) return batch_generations(ctx, true, nwind > 0 ? (uint32_t)nwind : 0u, {});
+  if (is_batched(ctx)) return batch_generations(ctx, true, nwind > 0 ? (uint32_t)nwind : 0u, {});
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwind, true);
   PhaseTimer tk(ctx, 5);
   hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwind);

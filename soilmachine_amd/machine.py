@@ -166,6 +166,10 @@ class Layermap:
     def set_batch_dilate(self, tiles: int):
         self._chk(self.L.smx_set_batch_dilate(self.h, int(tiles)))
 
+    def set_relax_wind(self, min_running: int = 0xFFFFFFFF, steps_per_epoch: int = 4):
+        """relaxed schedule: wind steps relaxed (up to `steps_per_epoch` steps per epoch) while more than `min_running` particles run"""
+        self._chk(self.L.smx_set_relax_wind(self.h, int(min_running), int(steps_per_epoch)))
+
     def set_batch_strips(self, nstrips: int, inset: int = 16, seam_halfwidth: int = 48):
         self._chk(self.L.smx_set_batch_strips(self.h, int(nstrips), int(inset), int(seam_halfwidth)))
 

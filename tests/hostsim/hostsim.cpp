@@ -19,6 +19,7 @@
 #include <type_traits>
 #include "../../soilmachine_amd/csrc/soil_coop.h"
 #include "../../soilmachine_amd/csrc/soil_batch.h"
+#include "../../soilmachine_amd/csrc/soil_relax.h"
 #include <pthread.h>
 #include <thread>
 #include <algorithm>
@@ -342,8 +343,15 @@ struct BatchBuffers {
   std::vector<BWater> water; std::vector<BWind> wind;
   std::vector<uint32_t> live, freed, ctrl, draws;
   std::vector<BChild> children;
+  std::vector<RReq> req; std::vector<uint32_t> rnext, rcount, rhead, cflag, flist0, flist1, clist0, clist1, flagl0, flagl1;   // relaxed schedule (soil_relax.h)
   BatchShared bs;
 };
+static int g_relaxed = 0;                                   // 1: particle phases run the relaxed schedule (SMX_ENGINE_RELAXED)
+static uint32_t g_relax_wind_min = 0xFFFFFFFFu;                   // wind: relaxed while more particles than this run ...
+static int g_relax_wind_steps = 4;                          // ... taking up to this many steps per epoch (smx_set_relax_wind)
+static uint32_t g_relax_tag = 0;
+extern "C" void hs_set_relaxed(int on) { g_relaxed = on; }
+extern "C" void hs_set_relax_wind(uint32_t n, int steps) { g_relax_wind_min = n; g_relax_wind_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
 static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) {
   const DevState& s = c->d;
   b.bs.tshift = -1; b.bs.ntx = s.dimx; b.bs.nty = s.dimy;
@@ -360,6 +368,18 @@ static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) 
   b.bs.strips = batch_make_strips(s.dimx, g_strips_n, g_strips_a, g_strips_b); b.bs.sphase = STRIP_INTERIOR;
   b.bs.dirty = c->dirty.data(); b.bs.own_x0 = c->own_x0; b.bs.own_x1 = c->own_x1 < 0 ? s.dimx : c->own_x1;
   b.bs.freed = b.freed.data(); b.bs.freed_cap = (uint32_t)b.freed.size(); b.bs.ctrl = b.ctrl.data(); b.bs.draws = b.draws.data();
+  b.bs.relaxed = (g_relaxed && b.bs.strips.n <= 1) ? 1 : 0;
+  b.bs.req = nullptr; b.bs.rnext = nullptr; b.bs.rcount = nullptr; b.bs.rhead = nullptr; b.bs.cflag = nullptr;
+  b.bs.flist[0] = b.bs.flist[1] = b.bs.clist[0] = b.bs.clist[1] = b.bs.flagl[0] = b.bs.flagl[1] = nullptr; b.bs.rstride = 2; b.bs.rsteps = 1; b.bs.rtag = 0;
+  if (b.bs.relaxed) {
+    const size_t ent = (size_t)(nslots ? nslots : 1) * 2 * R_MAXSTEPS;
+    b.req.resize(ent); b.rnext.assign(ent, NIL); b.rcount.assign(nslots ? nslots : 1, 0u); b.rhead.assign(nt, NIL); b.cflag.assign(nt, 0u);
+    b.bs.list_cap = nslots ? nslots : 1; b.bs.flag_cap = (uint32_t)ent; b.bs.clist_cap = (uint32_t)std::max<size_t>(4096, ent / 2);
+    b.flagl0.assign(ent, 0); b.flagl1.assign(ent, 0); b.bs.flagl[0] = b.flagl0.data(); b.bs.flagl[1] = b.flagl1.data();
+    b.flist0.assign(b.bs.list_cap, 0); b.flist1.assign(b.bs.list_cap, 0); b.clist0.assign((size_t)9 * b.bs.clist_cap, 0); b.clist1.assign((size_t)9 * b.bs.clist_cap, 0);
+    b.bs.req = b.req.data(); b.bs.rnext = b.rnext.data(); b.bs.rcount = b.rcount.data(); b.bs.rhead = b.rhead.data(); b.bs.cflag = b.cflag.data();
+    b.bs.flist[0] = b.flist0.data(); b.bs.flist[1] = b.flist1.data(); b.bs.clist[0] = b.clist0.data(); b.bs.clist[1] = b.clist1.data();
+  }
 }
 static void batch_draw(hs_ctx* c, BatchBuffers& b, uint32_t nslots) {   // the next 2*nslots rand() values (host-side generator)
   RandState& r = c->rnd;
@@ -394,11 +414,14 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
     }, shuffle ? shuffle + 7 : 0);
     for (uint32_t i = 0; i < nslots; i++) b.live[i] = i;
     uint32_t nlive = nslots, epoch = 0, chunk = 0;
+    const bool relax_gen = b.bs.relaxed != 0;
     while (nlive > 0) {
       BSched sc = batch_schedule(wind, nlive, g_batch_dilate, g_batch_cell_above);
       if (const char* e = getenv("HS_SCHED")) { int a, d, k; if (sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; } }   // exploration only
       const bool strips = b.bs.strips.n > 1;
-      const bool regrain = sc.tshift != b.bs.tshift;         // first chunk, or the claim granularity changes
+      const bool relaxed_now = relax_gen && (!wind || nlive > g_relax_wind_min);
+      bool regrain = sc.tshift != b.bs.tshift;               // first chunk, or the claim granularity changes
+      if (relax_gen && !relaxed_now && b.bs.relaxed) { b.bs.relaxed = 0; regrain = true; }   // survivors go on under the exclusive schedule
       batch_apply_schedule(b.bs, s, sc);
       b.bs.sphase = strips ? (int)(chunk & 1u) : STRIP_INTERIOR;   // column strips: INTERIOR and SEAM chunks alternate
       if (strips && chunk > 0) epoch++;                      // (reservations of the previous chunk must not look current)
@@ -412,6 +435,60 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       }
       static FILE* estats = getenv("HS_EPOCH_STATS") ? fopen(getenv("HS_EPOCH_STATS"), "w") : nullptr;   // analysis only
       std::vector<uint32_t> pc, ps; std::vector<uint32_t> pst;
+      int chunk_epochs = B_CHUNK;
+      if (relaxed_now) {                                     // mirrors soilmx.hip: step, apply, nine cascade colours, floods
+        chunk_epochs = first ? B_CHUNK : 8;
+        b.bs.rstride = wind ? 2 * g_relax_wind_steps : 2; b.bs.rsteps = wind ? g_relax_wind_steps : 1;
+        for (int k = 0; k < chunk_epochs; k++, epoch++) {
+          b.bs.rtag = ++g_relax_tag; if (b.bs.rtag == 0u) b.bs.rtag = ++g_relax_tag;
+          parallel_for(nlive, nthreads, [&](uint32_t i) {                                       // k_relax_step
+            BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+            if (wind) relax_wind_step(sim, bs, bs.live[i], epoch); else relax_water_step(sim, bs, bs.live[i], epoch);
+          }, shuffle ? shuffle + 11 + epoch : 0);
+          { const uint32_t par = (epoch + 1u) & 1u; b.ctrl[BC_NFLOOD + par] = 0u; b.ctrl[BC_NFLAG + par] = 0u; b.ctrl[BC_NRUN + par] = 0u; for (uint32_t q = 0; q < 9u; q++) b.ctrl[BC_NCASC + 9u * par + q] = 0u; }
+          parallel_for(nlive, nthreads, [&](uint32_t i) {                                       // k_relax_apply
+            BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+            relax_apply_slot(sim, bs, bs.live[i]);
+            sim.flush_counters(); pol.finish(s);
+          }, shuffle ? shuffle + 13 + epoch : 0);
+          {                                                                                     // k_relax_filter
+            const uint32_t par = epoch & 1u;
+            uint32_t nf = b.ctrl[BC_NFLAG + par]; if (nf > bs.flag_cap) nf = bs.flag_cap;
+            parallel_for(nf, nthreads, [&](uint32_t i) {
+              BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+              relax_filter(sim, bs, bs.flagl[par][i], true, epoch);
+              sim.flush_counters();
+              if (pol.a_casc) SMX_A_ADD64(&s.ctr[C_CASCADE_CALLS], (unsigned long long)pol.a_casc);
+            }, shuffle ? shuffle + 15 + epoch : 0);
+          }
+          for (uint32_t col = 0; col < 9u; col++) {                                            // k_relax_cascade(_small)
+            const uint32_t par = epoch & 1u;
+            uint32_t nc = b.ctrl[BC_NCASC + 9u * par + col]; if (nc > bs.clist_cap) nc = bs.clist_cap;
+            parallel_for(nc, nthreads, [&](uint32_t i) {
+              BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+              relax_cascade(sim, bs.clist[par][(size_t)col * bs.clist_cap + i]);
+              sim.flush_counters(); pol.finish(s);
+              if (pol.a_casc) SMX_A_ADD64(&s.ctr[C_CASCADE_CALLS], (unsigned long long)pol.a_casc);
+              if (pol.a_tr) SMX_A_ADD64(&s.ctr[C_CASCADE_TRANSFERS], (unsigned long long)pol.a_tr);
+            }, shuffle ? shuffle + 17 + epoch + col : 0);
+          }
+          if (!wind) {                                                                          // k_relax_floods
+            const uint32_t par = epoch & 1u;
+            uint32_t nf = b.ctrl[BC_NFLOOD + par]; if (nf > bs.list_cap) nf = bs.list_cap;
+            const bool due = relax_floods_due(epoch, nf, b.ctrl[BC_NRUN + par]);
+            parallel_for(nf, nthreads, [&](uint32_t i) {
+              const uint32_t slot = bs.flist[par][i];
+              if (!due) { relax_flood_later(bs, slot, par ^ 1u, true); return; }
+              BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+              Frame st[MAX_FRAMES];
+              batch_water_epoch(sim, bs, slot, epoch, st);
+              sim.flush_counters(); pol.finish(s);
+              relax_flood_later(bs, slot, par ^ 1u, b.water[slot].state != B_DONE);
+            }, shuffle ? shuffle + 19 + epoch : 0);
+          }
+        }
+        if (b.ctrl[BC_LIST_LOST]) { fprintf(stderr, "[hostsim] relaxed schedule: list overflow\n"); abort(); }
+      } else
       for (int k = 0; k < B_CHUNK; k++, epoch++) {
         if (estats && !wind) { pc.resize(nlive); ps.resize(nlive); pst.resize(nlive); for (uint32_t i = 0; i < nlive; i++) { const BWater& q = b.water[bs.live[i]]; pc[i] = q.c_casc; ps[i] = q.c_steps; pst[i] = q.state; } }
         parallel_for(nlive, nthreads, [&](uint32_t i) {
@@ -436,7 +513,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
         fprintf(stderr, "[hostsim] %s slots %u chunk %u live %u -> %u tshift %d maxsteps %d steps %llu maxsteps_slot %u\n", wind ? "wind" : "water", nslots, chunk, nlive, m, sc.tshift, sc.maxsteps, acc[0], mx);
       }
       nlive = m;
-      g_batch_stats[0] += B_CHUNK;
+      g_batch_stats[0] += (uint32_t)chunk_epochs;
     }
     g_batch_stats[1]++;
     if (getenv("HS_TRACE_BATCH")) fprintf(stderr, "[hostsim] batched %s generation: %u slots, %u epochs\n", wind ? "wind" : "water", nslots, epoch);

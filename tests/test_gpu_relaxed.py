@@ -1,0 +1,66 @@
+"""The RELAXED schedule (csrc/soil_relax.h, SMX_ENGINE_RELAXED) on the MI355X through the C-ABI: bit-identical to the same
+headers run by host threads (tests/hostsim) -- the schedule is deterministic, so device == host is an equality of full states --
+structurally sound at size, and inside the batched schedule's statistical envelope against the EXACT engine on the device."""
+import numpy as np
+import pytest
+
+from common import golden_snapshot, load_cfg
+from hostsim_lib import HostSim
+from soilmachine_amd import capi
+from soilmachine_amd.machine import Layermap, SoilMachine
+from soilmachine_amd.snapshot import compare
+from test_relaxed import CASES, column_invariants
+
+pytestmark = pytest.mark.gpu
+KEYS = ["steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls", "cascade_transfers",
+        "wcascade_calls", "rand_calls", "pool_free"]
+
+
+def machine(cfg, dimx, dimy, nw, nd, wind, engine, snap=None, wmin=0xFFFFFFFF, wsteps=4, size_seed=0):
+    m = Layermap(cfg, dimx, dimy, seed=size_seed, initialize=snap is None, engine=engine)
+    if snap is not None:
+        m.load(snap, rand_seed=0)
+    if engine == capi.ENGINE_RELAXED:
+        m.set_relax_wind(wmin, wsteps)
+    sm = SoilMachine.__new__(SoilMachine)
+    sm.cfg, sm.map, sm.nwater, sm.nwind, sm.dowater, sm.dowind = cfg, m, nw, nd, True, wind
+    return sm
+
+
+@pytest.mark.parametrize("soil,case,t0,nw,nd,wind,ticks,wmin,wsteps", CASES)
+def test_device_equals_host_threads(soil, case, t0, nw, nd, wind, ticks, wmin, wsteps):
+    cfg = load_cfg(soil)
+    g = golden_snapshot(case, t0)
+    sm = machine(cfg, g.dimx, g.dimy, nw, nd, wind, capi.ENGINE_RELAXED, snap=g, wmin=wmin, wsteps=wsteps)
+    h = HostSim(cfg, g.dimx, g.dimy, seed=0)
+    h.load(g, advance_rand=True)
+    for t in range(ticks):
+        sm.tick(1, sync=True)
+        h.relaxed_tick(nw, nd, True, wind, nthreads=4, shuffle=t + 1, wind_min=wmin, wind_steps=wsteps)
+        bad = compare(sm.map.snapshot(), h.snapshot())
+        assert not bad, f"{case} tick {t}: {bad}"
+    cd, ch = sm.map.counters(), h.counters()
+    assert {k: cd[k] for k in KEYS} == {k: ch[k] for k in KEYS}
+    assert sm.map.batch_stats()["children_lost"] == 0
+
+
+def test_1024_coupled_structure_and_envelope_against_the_exact_engine():
+    """BASELINE configs[2]-sized map with a soil the wind can move (rockgravelpebblessand), area-scaled counts, 6 ticks: relaxed and
+    batched against the exact engine from the same start -- the relaxed schedule's height RMSE stays within 1.5x the batched one's,
+    its step counts within 10 % of the exact engine's; columns well-formed."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n, nw, nd, ticks = 1024, 4000, 1000, 6
+    snaps, ctrs = {}, {}
+    for name, eng in (("exact", capi.ENGINE_SPECULATIVE), ("batched", capi.ENGINE_BATCHED), ("relaxed", capi.ENGINE_RELAXED)):
+        sm = machine(cfg, n, n, nw, nd, True, eng, wmin=256)
+        sm.tick(ticks, sync=True)
+        snaps[name], ctrs[name] = sm.map.snapshot(), sm.map.counters()
+        sm.map.close()
+    rm = lambda a, b: float(np.sqrt(np.mean((a.heights() - b.heights()) ** 2)))
+    r_rel, r_bat = rm(snaps["relaxed"], snaps["exact"]), rm(snaps["batched"], snaps["exact"])
+    assert r_rel < 1.5 * r_bat + 1e-6, (r_rel, r_bat)
+    for k in ("steps_water_all", "steps_wind"):
+        assert abs(ctrs["relaxed"][k] / ctrs["exact"][k] - 1) < 0.10, (k, ctrs["relaxed"][k], ctrs["exact"][k])
+    assert abs(snaps["relaxed"].nsec / snaps["exact"].nsec - 1) < 0.05
+    column_invariants(snaps["relaxed"])
+    assert ctrs["relaxed"]["pool_overflow"] == 0

@@ -29,6 +29,14 @@ for s in "$@"; do
     quick)     run quick 40 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu ;;
     parity)    run parity 60 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_depth.py tests/test_host_compat.py -x -q -m gpu ;;
     gpusuite)  run gpusuite 120 1500 python -m pytest tests -x -q -m gpu --durations=15 ;;
+    relaxtest) run relaxtest 60 600 python -m pytest tests/test_gpu_relaxed.py -x -q -m gpu --durations=8 ;;
+    headrelax) run headrelax 30 300 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
+    headrelax8) run headrelax8 30 300 env SMX_RELAX_WIND_STEPS=8 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
+    headrelaxw0) run headrelaxw0 30 300 env SMX_RELAX_WIND_MIN=4000000000 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
+    ktrace)    run ktrace 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 3 --warmup 2
+               python tools/kernel_stats.py $out/ktrace | tee $out/ktrace.summary ;;
+    headbatch) run headbatch 30 300 python bench.py --engine batched --no-lines --no-cpu-baseline --steps 3 --warmup 2 ;;
+    tracerelax) run tracerelax 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 5 ;;
     wet)       run wet 30 400 python tools/gpu_wet_exact.py --run ;;
     bench)     run bench 60 400 python bench.py; cp $out/bench.log $out/bench.json 2>/dev/null ;;
     benchfull) run benchfull 120 900 python bench.py --full; cp $out/benchfull.log $out/benchfull.json 2>/dev/null ;;
@@ -44,7 +52,7 @@ for s in "$@"; do
                  python tools/pmc_by_kernel.py $out/pmcwet$i | tee $out/pmcwet$i.summary
                done ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
-    envelope)  run envelope 60 900 python tools/p2_envelope.py --size 1024 --ticks 20 --streams 4 ;;
+    envelope)  run envelope 60 900 python tools/p2_envelope.py --size ${ESIZE:-1024} --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts ${ECOUNTS:-area} ;;
     relaxed)   run relaxed 60 600 python tools/relaxed_experiment.py ;;
     strips2)   run strips2 60 600 python tools/strips_shared_gpu.py ;;
     deep300)   run deep300 60 900 env SMX_DEEP=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k "300" ;;
