@@ -9,21 +9,21 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
   * value = particle-steps/s, whole job: a particle-step is one WaterParticle/WindParticle move()==true followed by its
     interact(), top-level AND nested particles. The unmodified reference can only count top-level steps,
     so the CPU baseline is top-level steps/s and the GPU line carries `value_top_level` next to `value` for that ratio.
-  * headline line: the BATCHED (throughput) engine with AREA-SCALED particle counts (NWATER = 250*(N/256)^2
-    = 64 000, NWIND = 16 000 at 4096^2). The batched engine is deterministic and bit-exact against its own CPU
-    restatement, but it is NOT the reference's particle order: parity tier P2 (statistical), never claimed bit-exact.
-    The EXACT engine (bit-identical to the reference, the parity anchor) is reported in the same JSON under "lines",
-    at the soil file's own counts (NWATER 1000 / NWIND 250: the round-1 headline) -- together with the batched engine at
-    those counts and the 1024^2 default.soil lines of BASELINE configs[1] and [2].
+  * headline line: the RELAXED schedule of the batched engine (SMX_ENGINE_RELAXED, csrc/soil_relax.h) with AREA-SCALED particle counts
+    (NWATER = 250*(N/256)^2 = 64 000, NWIND = 16 000 at 4096^2). Deterministic, but NOT the reference's particle order:
+    parity tier P2 (statistical) -- `parity_vs_exact` measures it on the device against the exact engine and against the exact engine's
+    own rand()-stream spread. The EXACT engine (bit-identical to the reference, the parity anchor) is reported under "lines" at the soil
+    file's own counts and under config.bit_exact_on_this_workload for the headline's counts, next to the batched schedule of round 2 and
+    the 1024^2 default.soil lines of BASELINE configs[1] and [2].
   * every line carries the state digest after its timed region (section count, type hash, sum of heights, rand() draws).
   * "roofline": algorithmic bytes of the dominant kernel / its HIP-event duration (events on the library's own stream,
     bracketing nothing but launches of that kernel) vs the 8 TB/s HBM peak; "phases" gives the same for the O(cells)
-    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r02_pmc.json), labelled as such.
+    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r03_pmc.json), labelled as such.
   * "cpu_baseline": the reference's own CPU loop (oracle/_ref/soil_ref_lean = the unmodified reference headers,
     render-only Layermap::update elided) timed on this box's host: 1 core on a bounded sample of the headline
     workload, and an all-cores line (independent processes, different SEEDs -- the reference has no threads).
-  * N > 1: one process per GPU. The batched engine (default) runs ONE map in N column strips (soilmachine_amd/strips.py: halo
-    columns + migrating particles point to point over RCCL, live count by all-reduce). Default "scaling": "weak" -- the map is
+  * N > 1: one process per GPU. The throughput engines run ONE map in N column strips, driven inside the library (smx_strips_*: halo
+    columns + migrating particles point to point with ncclSend/ncclRecv on device buffers, live count by ncclAllReduce). Default "scaling": "weak" -- the map is
     (N*size) x size, every GPU owns a size x size strip and its share of N x the particles, so per-GPU work is the N=1 line's;
     --strong splits the N=1 map instead ("strong"). The exact engines do not shard (sequential semantics): with --engine
     spec/serial the ranks run independent replicas (SEED = rank, "weak").
@@ -204,17 +204,17 @@ def parity_block(cfg, soil, n, nwater, nwind, pool, device, ticks, nstreams, eng
     return out
 
 
-def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dist, barrier, torch):
-    """ONE map sharded into world-size column strips (soilmachine_amd/strips.py): every rank holds a context with the
-    full-size map, initialises the terrain itself and keeps its strip + halo current; halo columns and migrating
-    particles travel point to point over RCCL (backend nccl), the live-particle count by all-reduce."""
-    from soilmachine_amd import capi
+def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dist, barrier, torch, engine):
+    """ONE map sharded into world-size column strips, driven INSIDE the library (csrc/soil_strips_host.h, smx_strips_*): halo columns
+    and migrating particles go from the pack kernel to the neighbour's unpack kernel over RCCL (ncclSend / ncclRecv on device buffers,
+    backend nccl) -- or through host callbacks on torch.distributed gloo when there is no RCCL (CPU-side tests)."""
     from soilmachine_amd.machine import Layermap
-    from soilmachine_amd.strips import DeviceStripBackend, StripGeometry, StripRank, TorchComm
+    from soilmachine_amd.strips import LibStripRank, StripGeometry, TorchComm
     world = dist.get_world_size()
-    m = Layermap(cfg, dimx, n, seed=0, pool=pool, device=device, engine=capi.ENGINE_BATCHED)
-    dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
-    rk = StripRank(DeviceStripBackend(m, buf_mb=256), TorchComm(dist, dev if dist.get_backend() == "nccl" else None), StripGeometry(dimx, world))
+    m = Layermap(cfg, dimx, n, seed=0, pool=pool, device=device, engine=engine)
+    nccl = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", device) if (torch.cuda.is_available() and nccl) else None
+    rk = LibStripRank(m, TorchComm(dist, dev), StripGeometry(dimx, world), transport="rccl" if nccl else "host")
     for _ in range(warmup):
         rk.tick(nwater, nwind, True, nwind > 0)
     m.sync()
@@ -231,7 +231,8 @@ def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dis
          "digest": {"note": "strips: each rank holds its own strip; no global digest in the timed run"},
          "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"],
          "nested": c1["nested_particles"] - c0["nested_particles"], "floods": c1["floods"] - c0["floods"], "pool_overflow": c1["pool_overflow"],
-         "engine_stats": dict({k: b1[k] - b0[k] for k in b1}, strip_stats=rk.stats, bytes_sent=rk.comm.bytes_sent, messages=rk.comm.messages)}
+         "engine_stats": dict({k: b1[k] - b0[k] for k in b1}, strip_stats=rk.stats, transport="rccl (ncclSend/ncclRecv, device buffers)" if nccl else "host callbacks (gloo)")}
+    rk.detach()
     m.close()
     return r
 
@@ -343,7 +344,7 @@ def main():
         if not args.strong:
             dimx, nwater, nwind = n * world, nwater * world, nwind * world
             pool = max(10_000_000, 3 * dimx * n)
-        r = measure_strips(cfg, dimx, n, nwater, nwind, pool, local_rank, args.steps, args.warmup, dist, barrier, torch)
+        r = measure_strips(cfg, dimx, n, nwater, nwind, pool, local_rank, args.steps, args.warmup, dist, barrier, torch, engine)
     else:
         r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier)
     steps = r["steps_w"] + r["steps_d"]
@@ -412,7 +413,8 @@ def main():
             extra = []   # name, cfg, soil, size, nwater, nwind, engine, pool, steps, warmup, workload, in the default run?
             if throughput:
                 # the bit-exact engine on the HEADLINE's workload (same map, same counts): what parity-green throughput is today
-                extra.append(("exact_area_scaled", cfg, soil, n, nwater, nwind, "spec", pool, 1, 1, workload, True))
+                # (82 s per tick at 4096^2 / 64 000 + 16 000: measured once, profiles/r03_exact_area_scaled_4096.json; --full or --only re-measures it)
+                extra.append(("exact_area_scaled", cfg, soil, n, nwater, nwind, "spec", pool, 1, 1, workload, False))
                 other = "batched" if eng_name == "relaxed" else "relaxed"
                 extra.append((f"{other}_area_scaled", cfg, soil, n, nwater, nwind, other, pool, k3, w3, workload, True))
                 extra.append(("exact_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, "spec", pool, k3, w3, fc + " (round-1 headline workload)", True))
@@ -441,11 +443,12 @@ def main():
                 lines.append(ln)
             if throughput and args.only is None:
                 # parity of the throughput schedules against the exact engine, ON THE DEVICE, next to the exact engine's own stream-to-stream
-                # spread: 1024^2 of the headline's soil at the headline's particle density (the 4096^2 version of the same table, 20 ticks and
-                # 4 control streams, is profiles/r03_p2_envelope.json: the exact engine needs minutes for it)
+                # spread: 512^2 of the headline's soil at the headline's particle density, measured in this run (the exact engine needs ~4 s per
+                # tick at 1024^2 and 82 s at 4096^2 with these counts: the 1024^2 table, 10 ticks, is profiles/r03_p2_envelope_1024.json)
                 try:
-                    parity = parity_block(cfg, soil, 1024, int(250 * 16), int(250 * 16 * cfg.NWIND / max(cfg.NWATER, 1)), 10_000_000, local_rank, 8, 2,
+                    parity = parity_block(cfg, soil, 512, int(250 * 4), int(250 * 4 * cfg.NWIND / max(cfg.NWATER, 1)), 10_000_000, local_rank, 10, 2,
                                           [("relaxed", capi.ENGINE_RELAXED), ("batched", capi.ENGINE_BATCHED)])
+                    parity["larger_maps"] = "profiles/r03_p2_envelope_1024.json (tools/p2_envelope.py on the MI355X)"
                 except Exception as e:
                     parity = {"error": str(e)}
         if args.only is not None:
@@ -475,7 +478,9 @@ def main():
                                         "weak: one (N*size) x size map, every GPU owns a size x size strip and 1/N of N x the particles "
                                         "(per-GPU work = the N=1 line)") if strips else "independent replicas (exact engines do not shard)"),
                        "parity": p2 if throughput else head["parity"],
-                       "bit_exact_line": "lines[exact_area_scaled]: the speculative engine (bit-identical to the reference) on this very workload"},
+                       "bit_exact_on_this_workload": {"engine": "speculative (bit-identical to the reference)", "value": 878861.5, "unit": "particle-steps/s", "ms_per_tick": 82287.6,
+                                                      "source": "profiles/r03_exact_area_scaled_4096.json (bench.py --only exact_area_scaled on the MI355X; 3 min per run, "
+                                                                "so not part of the default bench)"} if (throughput and n == 4096 and nwater == 64000 and soil == SOIL) else None},
             "value_top_level": head["value_top_level"] if world == 1 else None,
             "steps_definition": "value: move()==true + interact(), top-level AND nested particles; value_top_level: top-level only "
                                 "(what cpu_baseline can count)",

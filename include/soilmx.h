@@ -203,6 +203,30 @@ int smx_d_pack_particles(smx_ctx* ctx, int32_t x0, int32_t x1, void* buf, uint64
 int smx_d_unpack_particles(smx_ctx* ctx, const void* buf, uint64_t bytes);
 int smx_d_grid_begin(smx_ctx* ctx);                                            /* classification of the grid pass       */
 int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t tx_lo, int32_t tx_hi); /* nine colours over this rank's 4x4 tiles */
+/* ---- column strips driven INSIDE the library (csrc/soil_strips_host.h): the tick of SoilMachine.cpp:283-329 on this rank's strip of ONE
+ * map; halo columns and migrating particles go from the pack kernel to the unpack kernel of the neighbour without leaving device memory.
+ *   smx_strips_attach_rccl   transport = RCCL (ncclSend / ncclRecv / ncclAllReduce / ncclAllGather over xGMI) on this context's stream;
+ *                            rank 0 makes the 128-byte id with smx_strips_rccl_unique_id and hands it to the other ranks (any side channel)
+ *   smx_strips_attach        transport = the caller's callbacks on HOST buffers (loop-back threads, gloo, MPI ...; all calls block; send must
+ *                            not wait for the matching recv to be posted... recv returns 0 and *bytes, or 1 and the needed *bytes if cap is short)
+ *   smx_strips_tick          every rank calls it with the same arguments; requires the batched engine
+ * The result is a function of (world, inset, seam_halfwidth) only -- smx_set_batch_strips runs the same schedule in ONE context. */
+typedef struct smx_transport {
+  void* user;
+  int (*send)(void* user, int32_t dst, const void* buf, uint64_t bytes);
+  int (*recv)(void* user, int32_t src, void* buf, uint64_t cap, uint64_t* bytes);
+  int (*allreduce_sum_u64)(void* user, uint64_t* v);
+  int (*allreduce_max_u64)(void* user, uint64_t* v);
+  int (*allreduce_min_u32)(void* user, uint32_t* a, uint64_t n);
+  /* every rank contributes `bytes` (<= each) bytes; all = world blocks of `each` bytes in rank order, sizes[r] = rank r's bytes */
+  int (*allgather)(void* user, const void* mine, uint64_t bytes, void* all, uint64_t each, uint64_t* sizes);
+} smx_transport;
+int smx_strips_rccl_unique_id(void* out128);
+int smx_strips_attach_rccl(smx_ctx* ctx, const void* unique_id128, int32_t rank, int32_t world, int32_t inset, int32_t seam_halfwidth);
+int smx_strips_attach(smx_ctx* ctx, const smx_transport* t, int32_t rank, int32_t world, int32_t inset, int32_t seam_halfwidth);
+int smx_strips_detach(smx_ctx* ctx);
+int smx_strips_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater, int32_t dowind);
+int smx_strips_stats(smx_ctx* ctx, uint64_t* chunks, uint64_t* seam_chunks, uint64_t* generations, uint64_t* bytes_sent, uint64_t* messages);
 /* batched engine: epochs (kernel rounds), generations and dropped child particles since the context was created */
 int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost);
 void* smx_stream(smx_ctx* ctx);                          /* the hipStream_t all work is queued on */

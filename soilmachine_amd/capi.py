@@ -36,6 +36,19 @@ class Counters(C.Structure):
         return d
 
 
+# smx_transport (include/soilmx.h): callbacks on host buffers for smx_strips_attach
+SEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64)
+RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
+RED64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64))
+MIN32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("send", SEND_FN), ("recv", RECV_FN), ("allreduce_sum_u64", RED64_FN), ("allreduce_max_u64", RED64_FN),
+                ("allreduce_min_u32", MIN32_FN), ("allgather", GATHER_FN)]
+
+
 class Timing(C.Structure):
     _fields_ = [("ms_water", C.c_double), ("ms_grid", C.c_double), ("ms_wind", C.c_double), ("ms_freq", C.c_double),
                 ("launches_water", C.c_uint64), ("launches_grid", C.c_uint64), ("launches_wind", C.c_uint64),
@@ -56,7 +69,7 @@ SYMBOLS = [
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
     "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices", "smx_fill_vertices_cut",
-    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind",
+    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind", "smx_strips_rccl_unique_id", "smx_strips_attach_rccl", "smx_strips_attach", "smx_strips_detach", "smx_strips_tick", "smx_strips_stats",
     "smx_d_set_own", "smx_d_gen_begin", "smx_d_gen_spawn", "smx_d_next_phase", "smx_d_chunk", "smx_d_gen_end", "smx_d_pack_columns",
     "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep",
     "smx_lbm_create", "smx_lbm_destroy", "smx_lbm_last_error", "smx_lbm_set_boundary", "smx_lbm_boundary_from_map", "smx_lbm_initialize",
@@ -121,6 +134,12 @@ def load() -> C.CDLL:
     L.smx_set_batch_dilate.argtypes = [vp, i32]
     L.smx_set_batch_strips.argtypes = [vp, i32, i32, i32]
     L.smx_set_relax_wind.argtypes = [vp, u32, i32]
+    L.smx_strips_rccl_unique_id.argtypes = [vp]
+    L.smx_strips_attach_rccl.argtypes = [vp, vp, i32, i32, i32, i32]
+    L.smx_strips_attach.argtypes = [vp, C.POINTER(Transport), i32, i32, i32, i32]
+    L.smx_strips_detach.argtypes = [vp]
+    L.smx_strips_tick.argtypes = [vp, i32, i32, i32, i32]
+    L.smx_strips_stats.argtypes = [vp] + [C.POINTER(u64)] * 5
     L.smx_d_set_own.argtypes = [vp, i32, i32]
     L.smx_d_gen_begin.argtypes = [vp, i32, u32, vp, vp]
     L.smx_d_gen_spawn.argtypes = [vp, vp, C.POINTER(u32)]

@@ -119,13 +119,21 @@ SMX_D BRect bdilate(const BatchShared& bs, const BRect& r) {
   o.ty0 = r.ty0 - bs.dilate < 0 ? 0 : r.ty0 - bs.dilate; o.ty1 = r.ty1 + bs.dilate > bs.nty - 1 ? bs.nty - 1 : r.ty1 + bs.dilate;
   return o;
 }
+// may an action that touches the columns cx0 .. cx1 run in the current kind of chunk?
+SMX_D bool beligible_x(const DevState& s, const BatchShared& bs, int cx0, int cx1);
 // may a particle with this reservation act in the running kind of chunk?
 SMX_D bool beligible(const DevState& s, const BatchShared& bs, const BRect& r) {
-  const BStrips& st = bs.strips;
-  if (st.n <= 1) return true;
+  if (bs.strips.n <= 1) return true;
   if (brect_empty(r)) return false;
   const int cx0 = r.tx0 << bs.tshift;
   int cx1 = ((r.tx1 + 1) << bs.tshift) - 1; if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
+  return beligible_x(s, bs, cx0, cx1);
+}
+SMX_D bool beligible_x(const DevState& s, const BatchShared& bs, int cx0, int cx1) {
+  const BStrips& st = bs.strips;
+  if (st.n <= 1) return true;
+  if (cx0 < 0) cx0 = 0;
+  if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
   if (bs.sphase == STRIP_INTERIOR) {
     for (int g = 0; g < st.n; g++) {
       const int lo = st.x[g] + (g ? st.a : 0), hi = st.x[g + 1] - (g < st.n - 1 ? st.a : 0);
@@ -149,6 +157,15 @@ SMX_D void bmark_dirty(const DevState& s, const BatchShared& bs, const BRect& r)
   const int gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
   const int cx0 = r.tx0 << bs.tshift, cy0 = r.ty0 << bs.tshift;
   int cx1 = ((r.tx1 + 1) << bs.tshift) - 1, cy1 = ((r.ty1 + 1) << bs.tshift) - 1;
+  if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
+  if (cy1 > s.dimy - 1) cy1 = s.dimy - 1;
+  for (int gx = cx0 >> GRID_SHIFT; gx <= (cx1 >> GRID_SHIFT); gx++)
+    for (int gy = cy0 >> GRID_SHIFT; gy <= (cy1 >> GRID_SHIFT); gy++) bs.dirty[(size_t)gx * gty + gy] = 1;
+}
+SMX_D void bmark_dirty_cells(const DevState& s, const BatchShared& bs, int cx0, int cx1, int cy0, int cy1) {   // the same, for a rectangle of cells
+  if (bs.strips.n <= 1 || !bs.dirty) return;
+  const int gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+  if (cx0 < 0) cx0 = 0; if (cy0 < 0) cy0 = 0;
   if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
   if (cy1 > s.dimy - 1) cy1 = s.dimy - 1;
   for (int gx = cx0 >> GRID_SHIFT; gx <= (cx1 >> GRID_SHIFT); gx++)

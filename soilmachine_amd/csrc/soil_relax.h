@@ -71,7 +71,10 @@ SMX_D void relax_flood_later(const BatchShared& bs, uint32_t slot, uint32_t pari
 // Floods are long, branchy paths (~150 us each on a lane); while nearly everybody is still running, the few particles that ended
 // early wait for every fourth epoch. Once the ended ones are a sixteenth of the runners (or nobody runs), every epoch floods.
 // A function of the epoch's own counts: not of chunking, not of how the host drives the epochs.
-SMX_D bool relax_floods_due(uint32_t epoch, uint32_t nflood, uint32_t nrun) { return (epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun; }
+// (Under column strips the counts are one device's share, so every epoch floods there: the result must not depend on the partition.)
+SMX_D bool relax_floods_due(const BatchShared& bs, uint32_t epoch, uint32_t nflood, uint32_t nrun) {
+  return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun;
+}
 // after the epoch's edits are applied: which flagged cells can move anything at all? (Particle::cascade starts with the same
 // conservative test, Sim::cascade_precheck: the others are done) -- the rest go to their colour's cascade list
 template <class P>
@@ -99,18 +102,24 @@ template <class P>
 SMX_D void relax_water_step(Sim<P>& sim, const BatchShared& bs, uint32_t slot, uint32_t epoch) {
   BWater& q = bs.water[slot];
   uint32_t state = q.state;
-  (void)relax_append(&bs.ctrl[BC_NRUN + (epoch & 1u)], state == B_RUN || state == B_NEW);   // how many step in this epoch (relax_floods_due)
   if (state != B_RUN && state != B_NEW) { bs.rcount[slot] = 0u; return; }
   const DevState& s = sim.s;
   const SoilP* soils = sim.soils;
   Water w = q.w;
   Blk A;
   sim.template load_block<0>(w.ix, w.iy, A);
-  if (state == B_NEW) { w.contains = soils[Sim<P>::vsurf(A.v8)].transports; state = B_RUN; }   // WaterParticle(map) water.h:15-17
-  RReq r;
-  r.cell = (uint32_t)A.c0; r.vol = w.volume; r.amount = 0.0; r.type = 0u; r.kind = R_TRACK; r.casc = NIL;   // water.h:53 track[ipos] += volume
   Water t = w;
   const bool mv = sim.template water_move<true>(t, false, A);                                   // water.h:43-73, no side effects
+  if (bs.strips.n > 1) {                                      // column strips: the step (3x3 around ipos and around the new position) must lie
+    const int nx = mv ? (int)roundf(t.pos.x) : w.ix, ny = mv ? (int)roundf(t.pos.y) : w.iy;   // inside what this kind of chunk may touch
+    const int x0 = (w.ix < nx ? w.ix : nx) - 1, x1 = (w.ix > nx ? w.ix : nx) + 1;
+    if (!beligible_x(s, bs, x0, x1)) { bs.rcount[slot] = 0u; return; }                         // dormant until the other kind of chunk
+    bmark_dirty_cells(s, bs, x0, x1, (w.iy < ny ? w.iy : ny) - 1, (w.iy > ny ? w.iy : ny) + 1);
+  }
+  (void)relax_append(&bs.ctrl[BC_NRUN + (epoch & 1u)], true);                                   // how many step in this epoch (relax_floods_due)
+  if (state == B_NEW) { t.contains = soils[Sim<P>::vsurf(A.v8)].transports; state = B_RUN; }   // WaterParticle(map) water.h:15-17 (move() ignores it)
+  RReq r;
+  r.cell = (uint32_t)A.c0; r.vol = w.volume; r.amount = 0.0; r.type = 0u; r.kind = R_TRACK; r.casc = NIL;   // water.h:53 track[ipos] += volume
   w = t;
   if (mv) {
     q.c_steps++;
@@ -180,6 +189,12 @@ SMX_D void relax_wind_step(Sim<P>& sim, const BatchShared& bs, uint32_t slot, ui
     r1.cell = (uint32_t)A.c0; r1.kind = R_WINDFREQ;           // wind.h:49-52 frequency[ipos] = 0.5*frequency + 0.5
     Wind t = d;
     const bool mv = sim.template wind_move<true>(t, A);       // wind.h:54-92, no side effects
+    if (bs.strips.n > 1) {                                    // column strips: see relax_water_step
+      const int ex = mv ? (int)roundf(t.pos.x) : d.ix, ey = mv ? (int)roundf(t.pos.y) : d.iy;
+      const int x0 = (d.ix < ex ? d.ix : ex) - 1, x1 = (d.ix > ex ? d.ix : ex) + 1;
+      if (!beligible_x(s, bs, x0, x1)) break;                 // dormant until the other kind of chunk (this step has changed nothing yet)
+      bmark_dirty_cells(s, bs, x0, x1, (d.iy < ey ? d.iy : ey) - 1, (d.iy > ey ? d.iy : ey) + 1);
+    }
     d = t;
     if (mv) {
       q.c_steps++;

@@ -19,6 +19,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <sys/stat.h>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs,
   const uint32_t i = blockIdx.x * lpw + threadIdx.x;
   const bool act = threadIdx.x < lpw && i < n;
   bool again = false; uint32_t slot = 0u;
-  if (!relax_floods_due(epoch, n, bs.ctrl[BC_NRUN + par])) {  // not this epoch: the whole list moves on
+  if (!relax_floods_due(bs, epoch, n, bs.ctrl[BC_NRUN + par])) {  // not this epoch: the whole list moves on
     if (act) slot = bs.flist[par][i];
     relax_flood_later(bs, slot, par ^ 1u, act);
     return;
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs,
     Frame st[MAX_FRAMES];
     batch_water_epoch(sim, bs, slot, epoch, st);
     sim.flush_counters(); pol.finish(s);
-    again = bs.water[slot].state != B_DONE;
+    again = bs.water[slot].state == B_ENDED;
   }
   relax_flood_later(bs, slot, par ^ 1u, again);
 }
@@ -453,7 +454,7 @@ __global__ void __launch_bounds__(256) k_relax_tail(DevState s, BatchShared bs, 
     {                                                                                            // floods
       uint32_t n = SMX_A_LOAD(&bs.ctrl[BC_NFLOOD + par]);
       if (n > bs.list_cap) n = bs.list_cap;
-      const bool due = relax_floods_due(epoch, n, SMX_A_LOAD(&bs.ctrl[BC_NRUN + par]));
+      const bool due = relax_floods_due(bs, epoch, n, SMX_A_LOAD(&bs.ctrl[BC_NRUN + par]));
       for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
         const uint32_t i = i0 + threadIdx.x;
         bool again = false; uint32_t slot = 0u;
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(256) k_relax_tail(DevState s, BatchShared bs, 
           Frame st[MAX_FRAMES];
           batch_water_epoch(sim, bs, slot, epoch, st);
           sim.flush_counters(); pol.finish(s);
-          again = bs.water[slot].state != B_DONE;
+          again = bs.water[slot].state == B_ENDED;
         }
         relax_flood_later(bs, slot, par ^ 1u, again);
       }
@@ -590,12 +591,14 @@ __global__ void __launch_bounds__(64) k_strip_pack_columns(DevState s, BatchShar
     }
 }
 // one thread per received column: give the old chain back (deferred, like every free of a batched kernel), build the new one
-__global__ void __launch_bounds__(64) k_strip_unpack_columns(DevState s, BatchShared bs, const uint8_t* data, const uint32_t* offs, uint32_t nrec) {
+__global__ void __launch_bounds__(64) k_strip_unpack_columns(DevState s, BatchShared bs, const uint8_t* data, const uint32_t* offs, uint32_t nrec, uint32_t nbytes) {
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   if (i >= nrec) return;
+  if ((unsigned long long)offs[i] + 24ull > nbytes) return;  // (records must lie inside the message)
   const uint8_t* r = data + offs[i];
   const uint32_t* h = reinterpret_cast<const uint32_t*>(r);
   const uint32_t cc = h[0], count = h[1];
+  if (cc >= (unsigned long long)s.dimx * s.dimy || (unsigned long long)offs[i] + 24ull + 32ull * count > nbytes) return;
   const size_t x = cc / (size_t)s.dimy, y = cc % (size_t)s.dimy, fi = y * (size_t)s.dimx + x;
   s.wtrack[fi] = __uint_as_float(h[2]); s.windfreq[fi] = __uint_as_float(h[3]);
   BatchPolicy pol(s, bs);
@@ -607,9 +610,13 @@ __global__ void __launch_bounds__(64) k_strip_unpack_columns(DevState s, BatchSh
   for (uint32_t k = 0; k < count; k++) {
     const double* q = reinterpret_cast<const double*>(r + 24 + 32ull * k);
     Sec t; t.size = q[0]; t.floor = q[1]; t.sat = q[2]; t.type = reinterpret_cast<const uint32_t*>(q + 3)[0]; t.prev = pv;
-    if (k + 1 == count) cell = t;
-    else { const uint32_t nd = pol.node_alloc(s); if (nd == NIL) { atomicAdd(&s.ctr[C_POOL_OVERFLOW], 1ull); break; } s.pool[nd] = t; pv = nd; }
     live++;
+    if (k + 1 == count) cell = t;
+    else {
+      const uint32_t nd = pol.node_alloc(s);
+      if (nd == NIL) { atomicAdd(&s.ctr[C_POOL_OVERFLOW], 1ull); cell = t; break; }   // out of nodes: the column keeps what fits (reported, not silent)
+      s.pool[nd] = t; pv = nd;
+    }
   }
   c = cell; s.flags[cc] = (uint8_t)h[4];
   if (live) atomicAdd(&s.ctr[C_LIVE_SECTIONS], (unsigned long long)live);
@@ -844,6 +851,28 @@ __global__ void __launch_bounds__(64) k_point_op(DevState s, PointOp o, double* 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// roctx ranges per phase: resolved at run time, so the library does not depend on the profiler's marker library
+struct RoctxApi {
+  int (*push)(const char*) = nullptr; int (*pop)() = nullptr; bool tried = false;
+  void load() {
+    if (tried) return;
+    tried = true;
+    // only a marker library that is ALREADY in the process (a profiler preloads it; PyTorch links libroctx64): nothing is loaded for ranges
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA")); pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+      }
+    }
+    push = nullptr; pop = nullptr;
+  }
+};
+static RoctxApi g_roctx;
+struct roctx_range {
+  bool on;
+  explicit roctx_range(const char* name) { g_roctx.load(); on = g_roctx.push != nullptr; if (on) g_roctx.push(name); }
+  ~roctx_range() { if (on) g_roctx.pop(); }
+};
 struct EvPair { hipEvent_t a, b; int phase; uint32_t launches; };
 
 struct smx_ctx {
@@ -884,6 +913,8 @@ struct smx_ctx {
   uint32_t* d_contains = nullptr; uint32_t contains_cap = 0;
   uint8_t* d_xdata = nullptr; uint32_t* d_xoffs = nullptr; XCursor* d_xcur = nullptr;
   unsigned long long xdata_cap = 0; uint32_t xoffs_cap = 0;
+  uint8_t* d_rdata = nullptr; uint32_t* d_roffs = nullptr; uint8_t* d_xpart = nullptr; uint8_t* d_rpart = nullptr; unsigned long long xpart_cap = 0;   // strips in the library
+  struct StripState* strip = nullptr;
   uint64_t batch_epochs = 0, batch_generations = 0, batch_children_lost = 0;
 };
 
@@ -989,8 +1020,10 @@ int smx_create(const smx_config* cfg, smx_ctx** out) {
   return 0;
 }
 
+static void strips_free(smx_ctx* ctx);
 void smx_destroy(smx_ctx* ctx) {
   if (!ctx) return;
+  strips_free(ctx);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   drain_events(ctx);
   for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
@@ -1009,7 +1042,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(bs.rhead); hipFree(bs.cflag); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(bs.rhead); hipFree(bs.cflag); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1548,13 +1581,112 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
     ctx->draws_cap = cap;
   }
   bs.draws = ctx->d_draws; bs.dilate = ctx->batch_dilate; bs.maxsteps = 1;
-  bs.relaxed = 0;                                             // (set per generation by batch_generations)
   bs.strips = batch_make_strips(ctx->cfg.dimx, ctx->strips_n, ctx->strips_a, ctx->strips_b); bs.sphase = STRIP_INTERIOR;
   bs.own_x0 = ctx->own_x0; bs.own_x1 = ctx->own_x1 < 0 ? ctx->cfg.dimx : ctx->own_x1;
   (void)wind;
   return 0;
 }
 // generations of one phase: `kids` = children to start from (grid pass), else n top-level particles
+// every slot whose particle waits for its flood joins the flood list of `parity` (column strips: particles arrive and leave between chunks)
+__global__ void __launch_bounds__(256) k_relax_rebuild_floods(BatchShared bs, uint32_t nslots, uint32_t parity) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  relax_flood_later(bs, i, parity, i < nslots && bs.water[i].state == B_ENDED);
+}
+// One CHUNK of a particle phase on the context's current generation: the schedule for `nlive_sched` running particles (all strips
+// together), fresh reservations where the schedule asks for them, then the chunk's epochs over the `nlive` slots of bs.live.
+// Shared by the single-context driver (batch_generations) and the step-wise one of the column strips (smx_d_chunk).
+static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nlive, uint32_t nslots, bool first, bool relax_gen, uint32_t& epoch, uint32_t& chunk,
+                     int* epochs_run) {
+  hipStream_t st = ctx->stream;
+  const BatchShared& bs = ctx->bs;
+  static const int CHUNK = [] { const char* e = getenv("SMX_BATCH_CHUNK"); int v = e ? atoi(e) : B_CHUNK; return v < 1 ? 1 : v; }();
+  BSched sc = batch_schedule(wind, nlive_sched, ctx->batch_dilate);
+  {   // experiments only: SMX_BATCH_SCHED="tshift,dilate,maxsteps" (water) / SMX_BATCH_SCHED_WIND pins the schedule
+    static const char* ew = getenv("SMX_BATCH_SCHED"); static const char* ed = getenv("SMX_BATCH_SCHED_WIND");
+    const char* e = wind ? ed : ew; int a, d, k;
+    if (e && sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; }
+    static const char* et = getenv("SMX_BATCH_SCHED_TAIL");   // "thr:tshift,dilate,maxsteps[;thr2:...]" (ascending thr): first thr >= nlive wins
+    if (!wind && et) {
+      const char* q = et; unsigned thr;
+      while (q && sscanf(q, "%u:%d,%d,%d", &thr, &a, &d, &k) == 4) {
+        if (nlive_sched <= thr) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; break; }
+        q = strchr(q, ';'); if (q) q++;
+      }
+    }
+  }
+  const bool strips = bs.strips.n > 1;
+  // relaxed schedule (SMX_ENGINE_RELAXED): water always; wind while many particles run -- its tail (a few thousand particles that
+  // fly on for up to ~13 000 steps) is better served by the exclusive schedule's 32 steps per launch. One switch per generation.
+  const bool relaxed_now = relax_gen && (!wind || nlive_sched > ctx->relax_wind_min);
+  bool regrain = sc.tshift != bs.tshift;                   // first chunk, or the claim granularity changes
+  if (relax_gen && !relaxed_now && ctx->bs.relaxed) { ctx->bs.relaxed = 0; regrain = true; }   // hand the survivors to the exclusive schedule: fresh reservations
+  batch_apply_schedule(ctx->bs, ctx->d, sc);               // (bs aliases ctx->bs: passed by value per launch)
+  ctx->bs.sphase = strips ? (int)(chunk & 1u) : STRIP_INTERIOR;   // column strips: INTERIOR and SEAM chunks alternate
+  if (strips && chunk > 0) epoch++;                        // (reservations of the previous chunk must not look current)
+  chunk++;
+  if (regrain) { const size_t nt = (size_t)bs.ntx * bs.nty; HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st)); }
+  if ((regrain || strips) && nlive) {                      // under strips every chunk starts with fresh reservations
+    if (wind) hipLaunchKernelGGL(k_batch_reclaim<true>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+    else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+  }
+  int chunk_epochs = CHUNK;
+  if (relaxed_now) {
+    // relaxed schedule: per epoch one step of every running particle, the queued edits per cell, the nine cascade colours,
+    // then one flood epoch behind claim tiles. Nested generations live a few steps: shorter chunks there (without strips the
+    // result does not depend on where a generation is cut into chunks; with strips the chunk is the unit of the exchange).
+    static const int RCHUNK_KIDS = [] { const char* e = getenv("SMX_RELAX_CHUNK_KIDS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+    static const bool use_tail = [] { const char* e = getenv("SMX_RELAX_TAIL"); return e ? atoi(e) != 0 : true; }();
+    const bool tail = !wind && use_tail && nlive <= RELAX_TAIL;
+    chunk_epochs = strips ? B_CHUNK : (tail ? 64 : (first ? CHUNK : RCHUNK_KIDS));
+    ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : 2; ctx->bs.rsteps = wind ? ctx->relax_wind_steps : 1;
+    if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(bs.cflag, 0, ctx->ncells * 4, st)); }   // (tags never repeat)
+    if (strips) HIPCHK(hipMemsetAsync(bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
+    if (strips && !wind) {                                   // who waits for a flood on this device right now?
+      if (nslots) hipLaunchKernelGGL(k_relax_rebuild_floods, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots, epoch & 1u);
+    }
+    if (nlive == 0) { epoch += (uint32_t)chunk_epochs; ctx->relax_tag += (uint32_t)chunk_epochs; }   // (a strip with nobody home this chunk)
+    else if (tail) {                                         // few particles left: whole epochs inside one workgroup (k_relax_tail)
+      PhaseTimer tk(ctx, 9, (uint32_t)chunk_epochs);
+      hipLaunchKernelGGL(k_relax_tail, dim3(1), dim3(256), 0, st, ctx->d, bs, nlive, epoch, (uint32_t)chunk_epochs, ctx->relax_tag + 1u);
+      ctx->relax_tag += (uint32_t)chunk_epochs; epoch += (uint32_t)chunk_epochs;
+    } else {
+      const uint32_t lpw = batch_lanes_per_wave(nlive);
+      const unsigned nbl = (nlive + lpw - 1u) / lpw, nb64 = (nlive + 63u) / 64u;
+      const unsigned ncb = (unsigned)(((size_t)nlive * (size_t)(wind ? ctx->bs.rstride : 1) + 63u) / 64u);   // worst case of the flagged / one cascade list
+      const unsigned nfb = std::max(1024u, (unsigned)((nslots + 63u) / 64u));   // floods: at least 1024 wavefronts to spread over
+      for (int k = 0; k < chunk_epochs; k++, epoch++) {
+        ctx->bs.rtag = ++ctx->relax_tag;
+        {
+          PhaseTimer tk(ctx, wind ? 5 : 4, 1u);             // every launch of the step kernel between its own pair of events
+          if (wind) hipLaunchKernelGGL(k_relax_step<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+          else hipLaunchKernelGGL(k_relax_step<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+        }
+        hipLaunchKernelGGL(k_relax_apply, dim3(nb64), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
+        hipLaunchKernelGGL(k_relax_filter, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch);
+        for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch, col);
+        if (!wind) hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch);
+      }
+    }
+  } else if (nlive) {
+    PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)CHUNK);   // CHUNK back-to-back launches of the epoch kernel, nothing else
+    const uint32_t lpw = batch_lanes_per_wave(nlive);
+    const unsigned nbl = (nlive + lpw - 1u) / lpw;
+    // more wavefronts than SIMDs (> 65 536 running particles): the 256-register build, two wavefronts per SIMD -- +5 % at 16384^2,
+    // nothing below (profiles/r02_batched_schedules.md); results do not depend on it
+    static const uint32_t occ2_above = [] { const char* e = getenv("SMX_BATCH_OCC2_ABOVE"); return e ? (uint32_t)atoll(e) : 65536u; }();
+    const bool occ2 = nlive > occ2_above;
+    for (int k = 0; k < CHUNK; k++, epoch++) {
+      if (occ2) {
+        if (wind) hipLaunchKernelGGL(k_batch_epoch2<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+        else hipLaunchKernelGGL(k_batch_epoch2<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+      } else if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+      else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+    }
+  } else epoch += (uint32_t)CHUNK;
+  hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);   // frees of the chunk go back on the stack
+  if (epochs_run) *epochs_run = chunk_epochs;
+  return 0;
+}
 static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BChild> kids) {
   hipStream_t st = ctx->stream;
   bool first = kids.empty();
@@ -1573,7 +1705,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     }
     HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
     ctx->bs.tshift = -1;                                      // (the first chunk clears the planes and issues the first reservations)
-    const bool relax_gen = ctx->cfg.engine == SMX_ENGINE_RELAXED && ctx->bs.strips.n <= 1;
+    const bool relax_gen = ctx->cfg.engine == SMX_ENGINE_RELAXED;
     ctx->bs.relaxed = relax_gen ? 1 : 0;
     if (relax_gen) HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // flood, flag and cascade lists start empty
     const BChild* dk = nullptr;
@@ -1587,90 +1719,12 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     else hipLaunchKernelGGL(k_batch_spawn<false>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_batch_iota, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs.live, nslots);
     uint32_t nlive = nslots, epoch = 0, chunk = 0;
-    static const int CHUNK = [] { const char* e = getenv("SMX_BATCH_CHUNK"); int v = e ? atoi(e) : B_CHUNK; return v < 1 ? 1 : v; }();
     static const bool trace = [] { const char* e = getenv("SMX_TRACE_BATCH"); return e && atoi(e) != 0; }();
     while (nlive > 0) {
-      BSched sc = batch_schedule(wind, nlive, ctx->batch_dilate);
-      {   // experiments only: SMX_BATCH_SCHED="tshift,dilate,maxsteps" (water) / SMX_BATCH_SCHED_WIND pins the schedule
-        static const char* ew = getenv("SMX_BATCH_SCHED"); static const char* ed = getenv("SMX_BATCH_SCHED_WIND");
-        const char* e = wind ? ed : ew; int a, d, k;
-        if (e && sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; }
-        static const char* et = getenv("SMX_BATCH_SCHED_TAIL");   // "thr:tshift,dilate,maxsteps[;thr2:...]" (ascending thr): first thr >= nlive wins
-        if (!wind && et) {
-          const char* q = et; unsigned thr;
-          while (q && sscanf(q, "%u:%d,%d,%d", &thr, &a, &d, &k) == 4) {
-            if (nlive <= thr) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; break; }
-            q = strchr(q, ';'); if (q) q++;
-          }
-        }
-      }
-      const bool strips = bs.strips.n > 1;
-      // relaxed schedule (SMX_ENGINE_RELAXED): water always; wind while many particles run -- its tail (a few thousand particles that
-      // fly on for up to ~13 000 steps) is better served by the exclusive schedule's 32 steps per launch. One switch per generation.
-      const bool relaxed_now = relax_gen && (!wind || nlive > ctx->relax_wind_min);
-      bool regrain = sc.tshift != bs.tshift;                   // first chunk, or the claim granularity changes
-      if (relax_gen && !relaxed_now && ctx->bs.relaxed) { ctx->bs.relaxed = 0; regrain = true; }   // hand the survivors to the exclusive schedule: fresh reservations
-      batch_apply_schedule(ctx->bs, ctx->d, sc);               // (bs aliases ctx->bs: passed by value per launch)
-      ctx->bs.sphase = strips ? (int)(chunk & 1u) : STRIP_INTERIOR;   // column strips: INTERIOR and SEAM chunks alternate
-      if (strips && chunk > 0) epoch++;                        // (reservations of the previous chunk must not look current)
-      chunk++;
-      if (regrain || strips) {                                 // under strips every chunk starts with fresh reservations
-        const size_t nt = (size_t)bs.ntx * bs.nty;
-        if (regrain) { HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st)); }
-        if (wind) hipLaunchKernelGGL(k_batch_reclaim<true>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
-        else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
-      }
       const auto t_chunk = std::chrono::steady_clock::now();
       const uint32_t live_in = nlive;
-      int chunk_epochs = CHUNK;
-      if (relaxed_now) {
-        // relaxed schedule: per epoch one step of every running particle, the queued edits per cell, the nine cascade colours,
-        // then one flood epoch behind claim tiles. Nested generations live a few steps: shorter chunks there.
-        static const int RCHUNK_KIDS = [] { const char* e = getenv("SMX_RELAX_CHUNK_KIDS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
-        chunk_epochs = first ? CHUNK : RCHUNK_KIDS;
-        const uint32_t lpw = batch_lanes_per_wave(nlive);
-        const unsigned nbl = (nlive + lpw - 1u) / lpw, nb64 = (nlive + 63u) / 64u;
-        ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : 2; ctx->bs.rsteps = wind ? ctx->relax_wind_steps : 1;
-        const unsigned ncb = (unsigned)(((size_t)nlive * (size_t)(wind ? ctx->bs.rstride : 1) + 63u) / 64u);   // worst case of the flagged / one cascade list
-        const unsigned nfb = std::max(1024u, (unsigned)((nlive + 63u) / 64u));   // floods: at least 1024 wavefronts to spread over
-        static const bool use_tail = [] { const char* e = getenv("SMX_RELAX_TAIL"); return e ? atoi(e) != 0 : true; }();
-        if (!wind && use_tail && nlive <= RELAX_TAIL) {        // few particles left: whole epochs inside one workgroup (k_relax_tail)
-          chunk_epochs = 64;
-          if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(bs.cflag, 0, ctx->ncells * 4, st)); }   // (tags never repeat)
-          PhaseTimer tk(ctx, 9, (uint32_t)chunk_epochs);
-          hipLaunchKernelGGL(k_relax_tail, dim3(1), dim3(256), 0, st, ctx->d, bs, nlive, epoch, (uint32_t)chunk_epochs, ctx->relax_tag + 1u);
-          ctx->relax_tag += (uint32_t)chunk_epochs; epoch += (uint32_t)chunk_epochs;
-        } else
-        for (int k = 0; k < chunk_epochs; k++, epoch++) {
-          if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(bs.cflag, 0, ctx->ncells * 4, st)); }   // (tags never repeat)
-          ctx->bs.rtag = ++ctx->relax_tag;
-          {
-            PhaseTimer tk(ctx, wind ? 5 : 4, 1u);             // every launch of the step kernel between its own pair of events
-            if (wind) hipLaunchKernelGGL(k_relax_step<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
-            else hipLaunchKernelGGL(k_relax_step<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
-          }
-          hipLaunchKernelGGL(k_relax_apply, dim3(nb64), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
-          hipLaunchKernelGGL(k_relax_filter, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch);
-          for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch, col);
-          if (!wind) hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch);
-        }
-      } else {
-        PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)CHUNK);   // CHUNK back-to-back launches of the epoch kernel, nothing else
-        const uint32_t lpw = batch_lanes_per_wave(nlive);
-        const unsigned nbl = (nlive + lpw - 1u) / lpw;
-        // more wavefronts than SIMDs (> 65 536 running particles): the 256-register build, two wavefronts per SIMD -- +5 % at 16384^2,
-        // nothing below (profiles/r02_batched_schedules.md); results do not depend on it
-        static const uint32_t occ2_above = [] { const char* e = getenv("SMX_BATCH_OCC2_ABOVE"); return e ? (uint32_t)atoll(e) : 65536u; }();
-        const bool occ2 = nlive > occ2_above;
-        for (int k = 0; k < CHUNK; k++, epoch++) {
-          if (occ2) {
-            if (wind) hipLaunchKernelGGL(k_batch_epoch2<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
-            else hipLaunchKernelGGL(k_batch_epoch2<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
-          } else if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
-          else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
-        }
-      }
-      hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);   // frees of the chunk go back on the stack
+      int chunk_epochs = 0;
+      if (run_chunk(ctx, wind, nlive, nlive, nslots, first, relax_gen, epoch, chunk, &chunk_epochs)) return -1;
       HIPCHK(hipMemsetAsync(bs.ctrl + BC_NLIVE, 0, 4, st));
       if (wind) hipLaunchKernelGGL(k_batch_compact<true>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots);
       else hipLaunchKernelGGL(k_batch_compact<false>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots);
@@ -1776,6 +1830,8 @@ int smx_d_gen_begin(smx_ctx* ctx, int32_t wind, uint32_t nslots, const void* kid
   if (nslots) HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
   ctx->bs.tshift = -1;
   HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NCHILD, 0, 8, st));
+  ctx->bs.relaxed = ctx->cfg.engine == SMX_ENGINE_RELAXED ? 1 : 0;
+  if (ctx->bs.relaxed) HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // flood, flag and cascade lists start empty
   if (kids_host) {
     if (ctx->kids_cap < nslots) { hipFree(ctx->d_kids); ctx->d_kids = nullptr; ctx->kids_cap = 0; HIPCHK(hipMalloc(&ctx->d_kids, (size_t)nslots * sizeof(BChild))); ctx->kids_cap = nslots; }
     if (ctx->contains_cap < nslots) { hipFree(ctx->d_contains); ctx->d_contains = nullptr; ctx->contains_cap = 0; HIPCHK(hipMalloc(&ctx->d_contains, (size_t)nslots * 4)); ctx->contains_cap = nslots; }
@@ -1812,40 +1868,19 @@ int smx_d_gen_spawn(smx_ctx* ctx, const uint32_t* contains_host, uint32_t* nlive
 }
 int smx_d_next_phase(smx_ctx* ctx) { return ctx->strips_n > 1 ? (int)(ctx->d_chunk & 1u) : STRIP_INTERIOR; }
 int smx_d_chunk(smx_ctx* ctx, uint32_t nlive_global, uint32_t* nlive_local) {
-  hipStream_t st = ctx->stream; const BatchShared& bs = ctx->bs; const bool wind = ctx->d_wind;
   uint32_t nlive = 0;
   if (d_compact(ctx, &nlive)) return -1;                      // residents that run (particles may have arrived or left)
-  const BSched sc = batch_schedule(wind, nlive_global, ctx->batch_dilate);
-  const bool strips = bs.strips.n > 1, regrain = sc.tshift != bs.tshift;
-  batch_apply_schedule(ctx->bs, ctx->d, sc);
-  ctx->bs.sphase = strips ? (int)(ctx->d_chunk & 1u) : STRIP_INTERIOR;
-  if (strips && ctx->d_chunk > 0) ctx->d_epoch++;
-  ctx->d_chunk++;
-  if (regrain) { const size_t nt = (size_t)bs.ntx * bs.nty; HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st)); }
-  if (nlive) {
-    const unsigned nbl = (nlive + 63u) / 64u;
-    if (regrain || strips) {
-      if (wind) hipLaunchKernelGGL(k_batch_reclaim<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch);
-      else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch);
-    }
-    PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)B_CHUNK);
-    const uint32_t lpw = batch_lanes_per_wave(nlive);
-    const unsigned nbe = (nlive + lpw - 1u) / lpw;
-    for (int k = 0; k < B_CHUNK; k++) {
-      if (wind) hipLaunchKernelGGL(k_batch_epoch<true>, dim3(nbe), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k, lpw);
-      else hipLaunchKernelGGL(k_batch_epoch<false>, dim3(nbe), dim3(64), 0, st, ctx->d, bs, nlive, ctx->d_epoch + (uint32_t)k, lpw);
-    }
-  }
-  ctx->d_epoch += B_CHUNK;
-  hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
-  ctx->batch_epochs += B_CHUNK;
+  int epochs = 0;
+  if (run_chunk(ctx, ctx->d_wind, nlive_global, nlive, ctx->d_nslots, ctx->d_first, ctx->cfg.engine == SMX_ENGINE_RELAXED, ctx->d_epoch, ctx->d_chunk, &epochs)) return -1;
+  ctx->batch_epochs += (uint64_t)epochs;
   return d_compact(ctx, nlive_local);
 }
-int smx_d_gen_end(smx_ctx* ctx, void* children_out, uint32_t cap, uint32_t* n) {
+static int d_gen_end_impl(smx_ctx* ctx, void* children_out, uint32_t cap, uint32_t* n, std::vector<BChild>* vec) {
   hipStream_t st = ctx->stream; const BatchShared& bs = ctx->bs; const uint32_t nslots = ctx->d_nslots;
   if (nslots) {
     if (ctx->d_wind) hipLaunchKernelGGL(k_batch_counters<true>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
     else hipLaunchKernelGGL(k_batch_counters<false>, dim3(64), dim3(256), 0, st, ctx->d, bs, nslots);
+    ctx->d_nslots = 0;                                       // (the slots' counters are committed once, whatever happens below)
   }
   HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1853,15 +1888,16 @@ int smx_d_gen_end(smx_ctx* ctx, void* children_out, uint32_t cap, uint32_t* n) {
   if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
   if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
   if (nc > bs.child_cap) nc = bs.child_cap;
-  if (nc > cap) { ctx->err = "smx_d_gen_end: children buffer too small"; return -2; }
+  if (vec) { vec->resize(nc); children_out = vec->data(); cap = nc; }
+  if (nc > cap) { ctx->err = "smx_d_gen_end: children buffer too small (call again with room for *n records)"; *n = nc; return -2; }
   if (nc) HIPCHK(hipMemcpyAsync(children_out, bs.children, (size_t)nc * sizeof(BChild), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
   HIPCHK(hipStreamSynchronize(st));
   *n = nc;
   ctx->batch_generations++;
-  ctx->d_nslots = 0;
   return 0;
 }
+int smx_d_gen_end(smx_ctx* ctx, void* children_out, uint32_t cap, uint32_t* n) { return d_gen_end_impl(ctx, children_out, cap, n, nullptr); }
 // -> [u32 nrec][u32 data bytes][u32 offs[nrec]][records]   (record layout: k_strip_pack_columns)
 int smx_d_pack_columns(smx_ctx* ctx, int32_t x0, int32_t x1, void* host_buf, uint64_t cap, uint64_t* bytes) {
   hipStream_t st = ctx->stream;
@@ -1902,7 +1938,7 @@ int smx_d_unpack_columns(smx_ctx* ctx, const void* host_buf, uint64_t bytes) {
   }
   HIPCHK(hipMemcpyAsync(ctx->d_xoffs, hb + 8, 4ull * nrec, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->d_xdata, hb + 8 + 4ull * nrec, nb, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_strip_unpack_columns, dim3((nrec + 63u) / 64u), dim3(64), 0, st, ctx->d, ctx->bs, ctx->d_xdata, ctx->d_xoffs, nrec);
+  hipLaunchKernelGGL(k_strip_unpack_columns, dim3((nrec + 63u) / 64u), dim3(64), 0, st, ctx->d, ctx->bs, ctx->d_xdata, ctx->d_xoffs, nrec, nb);
   hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, ctx->bs);
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
@@ -1975,6 +2011,7 @@ static bool is_batched(const smx_ctx* ctx) { return ctx->cfg.engine == SMX_ENGIN
 extern "C" {
 // ---------------- the hot path ----------------
 int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
+  roctx_range rr("soilmx:water");
   PhaseTimer t(ctx, 0);
   if (is_batched(ctx)) return batch_generations(ctx, false, nwater > 0 ? (uint32_t)nwater : 0u, {});
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwater, false);
@@ -1984,6 +2021,7 @@ int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   return 0;
 }
 int smx_grid_pass(smx_ctx* ctx) {
+  roctx_range rr("soilmx:grid");
   PhaseTimer t(ctx, 1);
   if (is_batched(ctx)) return batch_grid(ctx);
   HIPCHK(hipMemsetAsync(ctx->d.active1, 0, (ctx->nw1 + 64) * 8, ctx->stream));
@@ -1994,6 +2032,7 @@ int smx_grid_pass(smx_ctx* ctx) {
   return 0;
 }
 int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
+  roctx_range rr("soilmx:wind");
   PhaseTimer t(ctx, 2);
   if (is_batched(ctx)) return batch_generations(ctx, true, nwind > 0 ? (uint32_t)nwind : 0u, {});
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwind, true);
@@ -2003,6 +2042,7 @@ int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
   return 0;
 }
 int smx_map_frequency(smx_ctx* ctx) {
+  roctx_range rr("soilmx:frequency");
   PhaseTimer t(ctx, 3);
   const size_t n = ctx->ncells, n4 = n / 4;
   unsigned nb = (unsigned)((n4 + 255) / 256);
@@ -2134,6 +2174,8 @@ int smx_timing_reset(smx_ctx* ctx) {
 }
 
 }  // extern "C"
+
+#include "soil_strips_host.h"
 
 // ---------------- LBM wind: lbmwind.h:75-197 + shader/LBM/*.cs, shader/move.cs -> soil_lbm.h ----------------
 #define LBMCHK(call)                                                                                  \

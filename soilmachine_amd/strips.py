@@ -205,6 +205,80 @@ class DeviceStripBackend:
     def reset_frequency(self): self._chk(self.L.smx_reset_frequency(self.h))
 
 
+# ------------------------------------------------------------------------------------------------ one rank, driven INSIDE libsoilmx
+class LibStripRank:
+    """The strip driver of the library (csrc/soil_strips_host.h, smx_strips_*): C++ runs the protocol; this class only attaches
+    a transport. transport="rccl": ncclSend/ncclRecv on device buffers (`comm` = a TorchComm or anything with rank/size/
+    allgather_bytes to hand the unique id around). Otherwise `comm` (ThreadComm, TorchComm on gloo) is wrapped in callbacks that
+    move HOST buffers -- the protocol above the transport is the same C++ either way."""
+
+    def __init__(self, lm, comm, geom: StripGeometry, transport: str = "host"):
+        import ctypes as C
+        from . import capi
+        self.C, self.capi, self.lm, self.L, self.h, self.comm, self.g = C, capi, lm, lm.L, lm.h, comm, geom
+        assert comm.size == geom.n
+        self.x0, self.x1 = geom.x[comm.rank], geom.x[comm.rank + 1]
+        if transport == "rccl":
+            uid = (C.c_uint8 * 128)()
+            if comm.rank == 0:
+                lm._chk(self.L.smx_strips_rccl_unique_id(uid))
+            uid_b = comm.allgather_bytes(bytes(uid))[0]              # rank 0's id reaches everybody
+            buf = (C.c_uint8 * 128).from_buffer_copy(uid_b)
+            lm._chk(self.L.smx_strips_attach_rccl(self.h, buf, comm.rank, comm.size, geom.a, geom.b))
+        else:
+            self._pending = {}                                        # src -> a message the library's buffer was too small for
+            self._t = self._make_transport()
+            lm._chk(self.L.smx_strips_attach(self.h, C.byref(self._t), comm.rank, comm.size, geom.a, geom.b))
+
+    def _make_transport(self):
+        C, capi, comm = self.C, self.capi, self.comm
+
+        def send(user, dst, buf, n):
+            comm.send(int(dst), C.string_at(buf, n)); return 0
+
+        def recv(user, src, buf, cap, out):
+            b = self._pending.pop(int(src), None)
+            if b is None:
+                b = comm.recv(int(src))
+            out[0] = len(b)
+            if len(b) > cap:
+                self._pending[int(src)] = b; return 1
+            C.memmove(buf, b, len(b)); return 0
+
+        def red_sum(user, v):
+            v[0] = comm.allreduce_sum(int(v[0])); return 0
+
+        def red_max(user, v):
+            v[0] = max(int.from_bytes(b, "little") for b in comm.allgather_bytes(int(v[0]).to_bytes(8, "little"))); return 0
+
+        def red_min(user, a, n):
+            arr = np.ctypeslib.as_array(a, shape=(int(n),))
+            arr[:] = comm.allreduce_min_u32(arr.copy()); return 0
+
+        def gather(user, mine, n, allp, each, sizes):
+            parts = comm.allgather_bytes(C.string_at(mine, n) if n else b"")
+            for r, b in enumerate(parts):
+                sizes[r] = len(b)
+                if len(b):
+                    C.memmove(allp + r * each, b, len(b))
+            return 0
+        self._cbs = (capi.SEND_FN(send), capi.RECV_FN(recv), capi.RED64_FN(red_sum), capi.RED64_FN(red_max), capi.MIN32_FN(red_min), capi.GATHER_FN(gather))
+        return capi.Transport(None, *self._cbs)
+
+    def tick(self, nwater: int, nwind: int, dowater: bool = True, dowind: bool = True):
+        self.lm._chk(self.L.smx_strips_tick(self.h, int(nwater), int(nwind), int(dowater), int(dowind)))
+
+    @property
+    def stats(self):
+        C = self.C
+        v = [C.c_uint64() for _ in range(5)]
+        self.lm._chk(self.L.smx_strips_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("chunks", "seam_chunks", "generations", "bytes_sent", "messages"), (int(x.value) for x in v)))
+
+    def detach(self):
+        self.lm._chk(self.L.smx_strips_detach(self.h))
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 class StripRank:
     """The tick of SoilMachine.cpp:283-329 on ONE strip. `backend` = DeviceStripBackend (libsoilmx) or the host-sim's."""

@@ -368,7 +368,7 @@ static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) 
   b.bs.strips = batch_make_strips(s.dimx, g_strips_n, g_strips_a, g_strips_b); b.bs.sphase = STRIP_INTERIOR;
   b.bs.dirty = c->dirty.data(); b.bs.own_x0 = c->own_x0; b.bs.own_x1 = c->own_x1 < 0 ? s.dimx : c->own_x1;
   b.bs.freed = b.freed.data(); b.bs.freed_cap = (uint32_t)b.freed.size(); b.bs.ctrl = b.ctrl.data(); b.bs.draws = b.draws.data();
-  b.bs.relaxed = (g_relaxed && b.bs.strips.n <= 1) ? 1 : 0;
+  b.bs.relaxed = g_relaxed ? 1 : 0;
   b.bs.req = nullptr; b.bs.rnext = nullptr; b.bs.rcount = nullptr; b.bs.rhead = nullptr; b.bs.cflag = nullptr;
   b.bs.flist[0] = b.bs.flist[1] = b.bs.clist[0] = b.bs.clist[1] = b.bs.flagl[0] = b.bs.flagl[1] = nullptr; b.bs.rstride = 2; b.bs.rsteps = 1; b.bs.rtag = 0;
   if (b.bs.relaxed) {
@@ -437,8 +437,12 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       std::vector<uint32_t> pc, ps; std::vector<uint32_t> pst;
       int chunk_epochs = B_CHUNK;
       if (relaxed_now) {                                     // mirrors soilmx.hip: step, apply, nine cascade colours, floods
-        chunk_epochs = first ? B_CHUNK : 8;
+        chunk_epochs = strips ? B_CHUNK : (first ? B_CHUNK : 8);   // (with strips the chunk is the unit of the exchange: soilmx.hip run_chunk)
         b.bs.rstride = wind ? 2 * g_relax_wind_steps : 2; b.bs.rsteps = wind ? g_relax_wind_steps : 1;
+        if (strips) for (uint32_t q = BC_NFLOOD; q < (uint32_t)BC_COUNT; q++) b.ctrl[q] = 0u;   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
+        if (strips && !wind) {                                // k_relax_rebuild_floods
+          for (uint32_t i = 0; i < nslots; i++) relax_flood_later(bs, i, epoch & 1u, b.water[i].state == B_ENDED);
+        }
         for (int k = 0; k < chunk_epochs; k++, epoch++) {
           b.bs.rtag = ++g_relax_tag; if (b.bs.rtag == 0u) b.bs.rtag = ++g_relax_tag;
           parallel_for(nlive, nthreads, [&](uint32_t i) {                                       // k_relax_step
@@ -475,7 +479,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
           if (!wind) {                                                                          // k_relax_floods
             const uint32_t par = epoch & 1u;
             uint32_t nf = b.ctrl[BC_NFLOOD + par]; if (nf > bs.list_cap) nf = bs.list_cap;
-            const bool due = relax_floods_due(epoch, nf, b.ctrl[BC_NRUN + par]);
+            const bool due = relax_floods_due(bs, epoch, nf, b.ctrl[BC_NRUN + par]);
             parallel_for(nf, nthreads, [&](uint32_t i) {
               const uint32_t slot = bs.flist[par][i];
               if (!due) { relax_flood_later(bs, slot, par ^ 1u, true); return; }
@@ -483,7 +487,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
               Frame st[MAX_FRAMES];
               batch_water_epoch(sim, bs, slot, epoch, st);
               sim.flush_counters(); pol.finish(s);
-              relax_flood_later(bs, slot, par ^ 1u, b.water[slot].state != B_DONE);
+              relax_flood_later(bs, slot, par ^ 1u, b.water[slot].state == B_ENDED);
             }, shuffle ? shuffle + 19 + epoch : 0);
           }
         }

@@ -64,3 +64,31 @@ def test_1024_coupled_structure_and_envelope_against_the_exact_engine():
     assert abs(snaps["relaxed"].nsec / snaps["exact"].nsec - 1) < 0.05
     column_invariants(snaps["relaxed"])
     assert ctrs["relaxed"]["pool_overflow"] == 0
+
+
+def test_relaxed_strip_schedule_device_equals_host_threads():
+    """the relaxed schedule under column strips (one context, two strips), device against the same headers on host threads"""
+    from hostsim_lib import lib
+    cfg = load_cfg("default.soil")
+    from oracle_lib import Oracle
+    o = Oracle(cfg, 256, 128, seed=0); o.initialize()
+    for _ in range(45):
+        o.tick(250, 0, True, False)
+    s0 = o.snapshot()
+    m = Layermap(cfg, 256, 128, seed=0, initialize=False, engine=capi.ENGINE_RELAXED)
+    m.load(s0, rand_seed=0)
+    m.set_batch_strips(2)
+    sm = SoilMachine.__new__(SoilMachine)
+    sm.cfg, sm.map, sm.nwater, sm.nwind, sm.dowater, sm.dowind = cfg, m, 150, 0, True, False
+    h = HostSim(cfg, 256, 128, seed=0); h.load(s0, advance_rand=True)
+    L = lib()
+    try:
+        L.hs_set_batch_strips(2, 16, 48)
+        for t in range(3):
+            sm.tick(1, sync=True)
+            h.relaxed_tick(150, 0, True, False, nthreads=4, shuffle=t + 2)
+            bad = compare(m.snapshot(), h.snapshot())
+            assert not bad, (t, bad)
+    finally:
+        L.hs_set_batch_strips(1, 16, 48)
+    assert m.counters()["floods"] == h.counters()["floods"] > 300

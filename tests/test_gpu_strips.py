@@ -1,7 +1,10 @@
 """Column strips on the MI355X. gpurun gives ONE device, so the strips run as several contexts on it:
 through the loop-back transport (threads) and through torch.distributed (gloo, two processes sharing cuda:0 -- RCCL
-refuses two ranks on one device; the nccl transport is the same code path with device tensors). Either way the result
-must equal ONE context running the same (nstrips, inset, seam) schedule, and that schedule must equal its CPU restatement."""
+refuses two ranks on one device). Either way the result must equal ONE context running the same (nstrips, inset, seam)
+schedule, and that schedule must equal its CPU restatement. Two drivers: the library's own (csrc/soil_strips_host.h,
+smx_strips_*: C++ protocol, device-resident messages; here over the host-callback transport -- the RCCL transport is the same
+protocol with ncclSend/ncclRecv in place of the callbacks and is exercised with the one rank a single device allows) and round 2's
+Python driver (soilmachine_amd/strips.py StripRank, the protocol's executable description, also run by the host-sim)."""
 import ctypes
 import os
 import sys
@@ -14,7 +17,7 @@ from oracle_lib import Oracle
 from soilmachine_amd import capi
 from soilmachine_amd.machine import Layermap, SoilMachine
 from soilmachine_amd.snapshot import Snapshot, compare
-from soilmachine_amd.strips import DeviceStripBackend, StripGeometry, StripRank, ThreadComm, TorchComm, merge_owned, run_threads
+from soilmachine_amd.strips import DeviceStripBackend, LibStripRank, StripGeometry, StripRank, ThreadComm, TorchComm, merge_owned, run_threads
 
 pytestmark = pytest.mark.gpu
 CK = ("steps_water_all", "steps_water_top", "steps_wind", "floods", "nested_particles", "cascade_calls", "cascade_transfers")
@@ -30,14 +33,14 @@ def start_state(kind, n):
     return cfg, Layermap(cfg, n, n, seed=0).snapshot()
 
 
-def device_ctx(cfg, s0, n):
-    m = Layermap(cfg, n, n, seed=0, initialize=False, engine=capi.ENGINE_BATCHED)
+def device_ctx(cfg, s0, n, engine=capi.ENGINE_BATCHED):
+    m = Layermap(cfg, n, n, seed=0, initialize=False, engine=engine)
     m.load(s0, rand_seed=0)
     return m
 
 
-def single_context(cfg, s0, n, G, nw, nd, ticks):
-    m = device_ctx(cfg, s0, n)
+def single_context(cfg, s0, n, G, nw, nd, ticks, engine=capi.ENGINE_BATCHED):
+    m = device_ctx(cfg, s0, n, engine)
     m.set_batch_strips(G)
     sm = SoilMachine.__new__(SoilMachine)
     sm.cfg, sm.map, sm.nwater, sm.nwind, sm.dowater, sm.dowind = cfg, m, nw, nd, True, nd > 0
@@ -75,7 +78,78 @@ def test_strip_schedule_on_device_equals_oracle_and_loopback(kind, G, n, nw, nd,
         assert cref["floods"] > 100 and cref["nested_particles"] > 300
 
 
-def _worker(rank, world, port, path, nw, nd, ticks, n, soil):
+@pytest.mark.parametrize("kind,G,n,nw,nd,ticks", [("dry", 2, 256, 500, 250, 2), ("wet", 2, 256, 250, 0, 3), ("dry", 3, 384, 700, 350, 2)])
+def test_library_strip_driver_over_loopback_equals_single_context(kind, G, n, nw, nd, ticks):
+    """smx_strips_attach + smx_strips_tick: the C++ driver, G contexts on the one device, messages handed over by thread queues"""
+    cfg, s0 = start_state(kind, n)
+    ref, cref = single_context(cfg, s0, n, G, nw, nd, ticks)
+    geom = StripGeometry(n, G)
+    ms = [device_ctx(cfg, s0, n) for _ in range(G)]
+    comms = ThreadComm.world(G)
+    ranks = [None] * G
+
+    def attach_and_run(r):
+        ranks[r] = LibStripRank(ms[r], comms[r], geom)
+        for _ in range(ticks):
+            ranks[r].tick(nw, nd, True, nd > 0)
+
+    class R:                                                      # (run_threads wants objects with .comm)
+        def __init__(self, r): self.r, self.comm = r, comms[r]
+    run_threads([R(r) for r in range(G)], lambda o: attach_and_run(o.r))
+    got = merge_owned(geom, [m.snapshot() for m in ms], n)
+    assert not compare(got, ref)
+    cs = [m.counters() for m in ms]
+    assert {k: sum(c[k] for c in cs) for k in CK} == {k: cref[k] for k in CK}
+    assert all(c["rand_calls"] == cref["rand_calls"] for c in cs)
+    st = ranks[0].stats
+    assert st["seam_chunks"] > 0 and st["bytes_sent"] > 0 and st["messages"] > 0
+
+
+@pytest.mark.parametrize("kind,G,n,nw,nd,ticks", [("dry", 2, 256, 500, 250, 2), ("wet", 2, 256, 250, 0, 3)])
+def test_relaxed_schedule_in_strips_library_driver_equals_single_context(kind, G, n, nw, nd, ticks):
+    """SMX_ENGINE_RELAXED under the strip schedule: a particle steps iff its step lies inside what the running kind of chunk may touch
+    (csrc/soil_relax.h); G contexts exchanging halos == ONE context running the same schedule, bit for bit."""
+    cfg, s0 = start_state(kind, n)
+    ref, cref = single_context(cfg, s0, n, G, nw, nd, ticks, capi.ENGINE_RELAXED)
+    geom = StripGeometry(n, G)
+    ms = [device_ctx(cfg, s0, n, capi.ENGINE_RELAXED) for _ in range(G)]
+    comms = ThreadComm.world(G)
+
+    class R:
+        def __init__(self, r): self.r, self.comm = r, comms[r]
+
+    def go(o):
+        rk = LibStripRank(ms[o.r], comms[o.r], geom)
+        for _ in range(ticks):
+            rk.tick(nw, nd, True, nd > 0)
+    run_threads([R(r) for r in range(G)], go)
+    got = merge_owned(geom, [m.snapshot() for m in ms], n)
+    assert not compare(got, ref)
+    cs = [m.counters() for m in ms]
+    assert {k: sum(c[k] for c in cs) for k in CK} == {k: cref[k] for k in CK}
+    if kind == "wet":
+        assert cref["floods"] > 100 and cref["nested_particles"] > 200
+
+
+def test_rccl_transport_with_the_one_rank_a_single_device_allows():
+    """librccl is loaded, the communicator is created, the strip driver ticks through it: with one rank there is no neighbour, so the
+    result must be the plain batched engine's. (Two ranks need two devices: RCCL refuses duplicates.)"""
+    cfg, s0 = start_state("dry", 256)
+    ref, cref = single_context(cfg, s0, 256, 1, 500, 250, 2)
+
+    class One:
+        rank, size = 0, 1
+        def allgather_bytes(self, b): return [b]
+    m = device_ctx(cfg, s0, 256)
+    rk = LibStripRank(m, One(), StripGeometry(256, 1), transport="rccl")
+    for _ in range(2):
+        rk.tick(500, 250, True, True)
+    assert not compare(m.snapshot(), ref)
+    assert {k: m.counters()[k] for k in CK} == {k: cref[k] for k in CK}
+    rk.detach()
+
+
+def _worker(rank, world, port, path, nw, nd, ticks, n, soil, lib_driver=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
@@ -86,7 +160,7 @@ def _worker(rank, world, port, path, nw, nd, ticks, n, soil):
     s0 = Snapshot(n, n, cfg.SCALE, len(cfg.soils), int(z["rand_calls"]), 0, z["count"], z["type"], z["size"], z["floor"], z["sat"],
                   z["wfreq"], z["wtrack"], z["windfreq"])
     m = device_ctx(cfg, s0, n)
-    rk = StripRank(DeviceStripBackend(m), TorchComm(dist), StripGeometry(n, world))
+    rk = LibStripRank(m, TorchComm(dist), StripGeometry(n, world)) if lib_driver else StripRank(DeviceStripBackend(m), TorchComm(dist), StripGeometry(n, world))
     for _ in range(ticks):
         rk.tick(nw, nd, True, nd > 0)
     s = m.snapshot()
@@ -97,7 +171,8 @@ def _worker(rank, world, port, path, nw, nd, ticks, n, soil):
     dist.destroy_process_group()
 
 
-def test_two_processes_torch_distributed_equal_single_context(tmp_path):
+@pytest.mark.parametrize("lib_driver", [False, True])
+def test_two_processes_torch_distributed_equal_single_context(tmp_path, lib_driver):
     import torch.multiprocessing as mp
     n, nw, nd, ticks, soil = 256, 400, 200, 2, "rockgravelpebblessand.soil"
     cfg, s0 = start_state("dry", n)
@@ -105,7 +180,7 @@ def test_two_processes_torch_distributed_equal_single_context(tmp_path):
     np.savez(path, count=s0.count, type=s0.type, size=s0.size, floor=s0.floor, sat=s0.sat, wfreq=s0.wfreq, wtrack=s0.wtrack,
              windfreq=s0.windfreq, rand_calls=s0.rand_calls)
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, path, nw, nd, ticks, n, soil), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, path, nw, nd, ticks, n, soil, lib_driver), nprocs=2, join=True)
     ref, cref = single_context(cfg, s0, n, 2, nw, nd, ticks)
     snaps, steps = [], 0
     for r in range(2):

@@ -79,3 +79,29 @@ def test_statistics_track_the_reference_like_the_batched_schedule_does():
     assert abs(cr["steps_water_all"] / ce["steps_water_all"] - 1) < 0.2
     assert abs(float(sr.heights().sum()) - float(se.heights().sum())) < 5.0
     column_invariants(sr)
+
+
+def test_relaxed_schedule_under_column_strips_is_deterministic_and_sound():
+    """The strip schedule (INTERIOR / SEAM chunks, csrc/soil_batch.h BStrips) with relaxed steps: a particle steps iff the cells of its
+    step lie inside what the running kind of chunk may touch. One context, two strips of a 256-wide map, lakes included."""
+    from hostsim_lib import lib
+    cfg = load_cfg("default.soil")
+    o = Oracle(cfg, 256, 128, seed=0); o.initialize()
+    for _ in range(45):
+        o.tick(250, 0, True, False)
+    s0 = o.snapshot()
+    L = lib()
+    runs = []
+    try:
+        L.hs_set_batch_strips(2, 16, 48)
+        for threads, shuffle in ((1, 0), (4, 9)):
+            h = HostSim(cfg, 256, 128, seed=0); h.load(s0, advance_rand=True)
+            for t in range(3):
+                h.relaxed_tick(150, 0, True, False, nthreads=threads, shuffle=shuffle + t if shuffle else 0)
+            runs.append((h.snapshot(), h.counters()))
+    finally:
+        L.hs_set_batch_strips(1, 16, 48)
+    assert not compare(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    column_invariants(runs[0][0])
+    c = runs[0][1]
+    assert c["pool_overflow"] == 0 and c["live_sections"] == runs[0][0].nsec and c["steps_water_all"] > 20000 and c["floods"] > 300

@@ -37,6 +37,8 @@ for s in "$@"; do
                python tools/kernel_stats.py $out/ktrace | tee $out/ktrace.summary ;;
     headbatch) run headbatch 30 300 python bench.py --engine batched --no-lines --no-cpu-baseline --steps 3 --warmup 2 ;;
     tracerelax) run tracerelax 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 5 ;;
+    stripstest) run stripstest 60 900 python -m pytest tests/test_gpu_strips.py -x -q -m gpu --durations=8 ;;
+    bench2gloo) run bench2gloo 60 600 env SMX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --size ${BSIZE:-2048} ;;
     wet)       run wet 30 400 python tools/gpu_wet_exact.py --run ;;
     bench)     run bench 60 400 python bench.py; cp $out/bench.log $out/bench.json 2>/dev/null ;;
     benchfull) run benchfull 120 900 python bench.py --full; cp $out/benchfull.log $out/benchfull.json 2>/dev/null ;;
