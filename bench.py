@@ -211,10 +211,14 @@ def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dis
     from soilmachine_amd.machine import Layermap
     from soilmachine_amd.strips import LibStripRank, StripGeometry, TorchComm
     world = dist.get_world_size()
-    m = Layermap(cfg, dimx, n, seed=0, pool=pool, device=device, engine=engine)
+    geom = StripGeometry(dimx, world)
+    held = geom.held(dist.get_rank(), n)                            # this rank's context holds its strip + halo only (smx_create_strip)
+    if held is not None:
+        pool = max(4_000_000, 3 * (held[1] - held[0]) * n)
+    m = Layermap(cfg, dimx, n, seed=0, pool=pool, device=device, engine=engine, x_range=held)
     nccl = dist.get_backend() == "nccl"
     dev = torch.device("cuda", device) if (torch.cuda.is_available() and nccl) else None
-    rk = LibStripRank(m, TorchComm(dist, dev), StripGeometry(dimx, world), transport="rccl" if nccl else "host")
+    rk = LibStripRank(m, TorchComm(dist, dev), geom, transport="rccl" if nccl else "host")
     for _ in range(warmup):
         rk.tick(nwater, nwind, True, nwind > 0)
     m.sync()
@@ -231,7 +235,7 @@ def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dis
          "digest": {"note": "strips: each rank holds its own strip; no global digest in the timed run"},
          "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"],
          "nested": c1["nested_particles"] - c0["nested_particles"], "floods": c1["floods"] - c0["floods"], "pool_overflow": c1["pool_overflow"],
-         "engine_stats": dict({k: b1[k] - b0[k] for k in b1}, strip_stats=rk.stats, transport="rccl (ncclSend/ncclRecv, device buffers)" if nccl else "host callbacks (gloo)")}
+         "engine_stats": dict({k: b1[k] - b0[k] for k in b1}, strip_stats=rk.stats, held_columns=list(held) if held else [0, dimx], pool_sections=pool, transport="rccl (ncclSend/ncclRecv, device buffers)" if nccl else "host callbacks (gloo)")}
     rk.detach()
     m.close()
     return r

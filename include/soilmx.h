@@ -90,6 +90,12 @@ typedef struct smx_timing {
 
 /* ---- life cycle: replaces Layermap::Layermap + secpool::reserve (layermap.h:64-119,218-226) ---- */
 int smx_create(const smx_config* cfg, smx_ctx** out);
+/* A context that HOLDS only the columns [x_lo, x_hi) of the dimx x dimy map -- one column strip with its halo, for smx_strips_*: cells,
+ * flags and the engines' per-cell planes are allocated for that range (indexing stays global), so per-device memory follows the strip,
+ * not the map (the frequency planes, 12 B/cell, stay full-size: their index y*dimx + x is not contiguous in x). x_lo * dimy must be a
+ * multiple of 64. Whole-map calls (exact engines, save/load, vertices, point operations) refuse such a context; import / export /
+ * read_heights / digest act on the held range. pool_capacity is this context's own. */
+int smx_create_strip(const smx_config* cfg, int32_t x_lo, int32_t x_hi, smx_ctx** out);
 void smx_destroy(smx_ctx* ctx);
 const char* smx_last_error(smx_ctx* ctx);
 

@@ -64,7 +64,7 @@ class Timing(C.Structure):
 
 # every symbol include/soilmx.h declares (tests/test_capi_symbols.py checks the library exports them all)
 SYMBOLS = [
-    "smx_create", "smx_destroy", "smx_last_error", "smx_set_soils", "smx_set_scale", "smx_srand", "smx_rand", "smx_rand_advance", "smx_get_rand_state", "smx_set_rand_state",
+    "smx_create", "smx_create_strip", "smx_destroy", "smx_last_error", "smx_set_soils", "smx_set_scale", "smx_srand", "smx_rand", "smx_rand_advance", "smx_get_rand_state", "smx_set_rand_state",
     "smx_initialize", "smx_import_columns", "smx_import_frequency", "smx_num_sections", "smx_export_columns",
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
@@ -134,6 +134,7 @@ def load() -> C.CDLL:
     L.smx_set_batch_dilate.argtypes = [vp, i32]
     L.smx_set_batch_strips.argtypes = [vp, i32, i32, i32]
     L.smx_set_relax_wind.argtypes = [vp, u32, i32]
+    L.smx_create_strip.argtypes = [C.POINTER(Config), i32, i32, C.POINTER(vp)]
     L.smx_strips_rccl_unique_id.argtypes = [vp]
     L.smx_strips_attach_rccl.argtypes = [vp, vp, i32, i32, i32, i32]
     L.smx_strips_attach.argtypes = [vp, C.POINTER(Transport), i32, i32, i32, i32]

@@ -70,6 +70,7 @@ constexpr int R_MAXSTEPS = 8;                 // relaxed schedule: steps one win
 struct BatchShared {
   unsigned long long* claim[2];               // sized for one word per CELL; indexed [tx * nty + ty] at the current granularity
   int tshift, ntx, nty;                       // claim granularity: tiles of 2^tshift x 2^tshift cells (0 = single cells)
+  int txb;                                    // first tile column the planes hold (DevState::x_lo >> tshift: a strip context holds its range only)
   BWater* water; BWind* wind;                 // slots of the current generation
   uint32_t* live;                             // indices of the slots that are not DONE (rebuilt by batch_compact)
   BChild* children; uint32_t child_cap;
@@ -173,12 +174,12 @@ SMX_D void bmark_dirty_cells(const DevState& s, const BatchShared& bs, int cx0, 
 }
 SMX_D void bclaim(const BatchShared& bs, int plane, const BRect& r, unsigned long long tag) {
   for (int tx = r.tx0; tx <= r.tx1; tx++)
-    for (int ty = r.ty0; ty <= r.ty1; ty++) (void)SMX_A_MAX64(&bs.claim[plane][(size_t)tx * bs.nty + ty], tag);
+    for (int ty = r.ty0; ty <= r.ty1; ty++) (void)SMX_A_MAX64(&bs.claim[plane][(size_t)(tx - bs.txb) * bs.nty + ty], tag);
 }
 SMX_D bool bholds(const BatchShared& bs, int plane, const BRect& r, unsigned long long tag) {
   bool ok = true;
   for (int tx = r.tx0; tx <= r.tx1; tx++)
-    for (int ty = r.ty0; ty <= r.ty1; ty++) ok &= (bs.claim[plane][(size_t)tx * bs.nty + ty] == tag);
+    for (int ty = r.ty0; ty <= r.ty1; ty++) ok &= (bs.claim[plane][(size_t)(tx - bs.txb) * bs.nty + ty] == tag);
   return ok;
 }
 
@@ -294,6 +295,10 @@ SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
     w.pos = {(float)rx, (float)ry}; w.speed = {0.f, 0.f};    // device -- its owner read `contains` for us (batch_child_contains)
     w.volume = 1.0; w.sediment = 0.0; w.evaprate = 0.001; w.spill = 3;
     w.ix = rx; w.iy = ry; w.surface = 0; w.friction = 0.f; w.contains = contains[slot];
+  } else if (rx < s.x_lo || rx >= s.x_hi) {                  // a strip context does not hold that column: the particle lives on another device (B_AWAY below)
+    w.pos = {(float)rx, (float)ry}; w.speed = {0.f, 0.f};
+    w.volume = 1.0; w.sediment = 0.0; w.evaprate = 0.001; w.spill = 3;
+    w.ix = rx; w.iy = ry; w.surface = 0; w.friction = 0.f; w.contains = 0;
   } else sim.water_init(w, rx, ry);
   q.toplevel = child ? 0u : 1u;
   if (child) {                                               // water.h:251-256: position, direction, volume, spill of a nested particle
@@ -329,7 +334,10 @@ SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
   BWind& q = bs.wind[slot];
   const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
   Wind d;
-  sim.wind_init(d, rx, ry);
+  if (rx < s.x_lo || rx >= s.x_hi) {                         // (not held by this strip context: lives on another device)
+    d.pos = {(float)rx, (float)ry}; d.speed = {-2.f, 0.f, 1.f}; d.sediment = 0.0; d.height = 0.0; d.sheight = 0.0;
+    d.ix = rx; d.iy = ry; d.surface = 0; d.contains = 0;
+  } else sim.wind_init(d, rx, ry);
   if (bs.rcount) bs.rcount[slot] = 0u;
   q.d = d; q.hint = 0; q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.pad2 = 0; q.pnx = -1; q.pny = -1;
   q.state = B_NEW;                                           // `contains` (wind.h:19-21) is read when the particle first acts
@@ -538,6 +546,7 @@ SMX_HD BStrips batch_make_strips(int dimx, int n, int a, int b) {
 SMX_HD void batch_apply_schedule(BatchShared& bs, const DevState& s, const BSched& k) {
   bs.tshift = k.tshift; bs.dilate = k.dilate; bs.maxsteps = k.maxsteps;
   bs.ntx = (s.dimx + (1 << k.tshift) - 1) >> k.tshift; bs.nty = (s.dimy + (1 << k.tshift) - 1) >> k.tshift;
+  bs.txb = s.x_lo >> k.tshift;
 }
 
 // ---------------- grid pass: one colour, one tile ----------------

@@ -87,6 +87,10 @@ struct DevState {
   unsigned long long* active1;// level 1: bit j set => level-0 word j may be non-zero
   unsigned long long* active2;// level 2: bit j set => level-1 word j may be non-zero
   uint64_t pool_capacity;    // max live sections (POOLSIZE semantics)
+  // Columns x_lo .. x_hi-1 are HELD by this context (a column strip + its halo; the whole map by default). cells / flags and the
+  // per-cell planes of the engines are allocated for that range only and addressed with the map's global index x*dimy + y (the
+  // pointers are biased by x_lo*dimy): nothing outside the range may be touched.
+  int x_lo, x_hi;
 };
 
 struct f2 { float x, y; };

@@ -341,6 +341,10 @@ static int strips_attach_common(smx_ctx* ctx, StripTransport* T, int rank, int w
   ctx->strip->T = T;
   ctx->strip->geo = batch_make_strips(ctx->cfg.dimx, world, inset, seam_halfwidth);
   ctx->strip->x0 = ctx->strip->geo.x[rank]; ctx->strip->x1 = ctx->strip->geo.x[rank + 1];
+  {   // a strip context (smx_create_strip) must hold its strip, the seam zone right of it and a few columns of slack on either side
+    const int need_lo = rank > 0 ? ctx->strip->x0 - 4 : 0, need_hi = rank < world - 1 ? std::min(ctx->cfg.dimx, ctx->strip->x1 + seam_halfwidth + 4) : ctx->cfg.dimx;
+    if (ctx->d.x_lo > need_lo || ctx->d.x_hi < need_hi) { ctx->err = "smx_strips_attach: the context does not hold its strip + halo (smx_create_strip range too small)"; strips_free(ctx); return -2; }
+  }
   return smx_d_set_own(ctx, ctx->strip->x0, ctx->strip->x1);
 }
 int smx_strips_rccl_unique_id(void* out128) {

@@ -87,15 +87,15 @@ __global__ void __launch_bounds__(64) k_wind_serial(DevState s, int n) {
 
 // One thread per cell, 256 consecutive cells (cell order) per block = 4 level-0 bitmap words.
 __global__ void __launch_bounds__(256) k_grid_classify(DevState s) {
-  const size_t n = (size_t)s.dimx * s.dimy;
-  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)s.x_hi * s.dimy;
+  const size_t c = (size_t)s.x_lo * s.dimy + (size_t)blockIdx.x * 256 + threadIdx.x;   // (x_lo*dimy is a multiple of 64: launch_classify)
   bool act = false;
   if (c < n) {
     const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
     uint8_t f = s.flags[c];
     act = (f & F_SAT) != 0;
     uint8_t any = f;
-    const bool xm = x > 0, xp = x < s.dimx - 1, ym = y > 0, yp = y < s.dimy - 1;
+    const bool xm = x > s.x_lo, xp = x < s.x_hi - 1, ym = y > 0, yp = y < s.dimy - 1;
     if (ym) any |= s.flags[c - 1];
     if (yp) any |= s.flags[c + 1];
     if (xm) { any |= s.flags[c - s.dimy]; if (ym) any |= s.flags[c - s.dimy - 1]; if (yp) any |= s.flags[c - s.dimy + 1]; }
@@ -118,12 +118,12 @@ __global__ void __launch_bounds__(256) k_grid_classify(DevState s) {
 // wave writes eight complete 64-bit words of the bitmap. 1 B/cell read, 1 bit/cell written: an HBM-streaming kernel.
 __global__ void __launch_bounds__(256) k_grid_classify8(DevState s) {
   __shared__ unsigned long long sm[32];                      // 256 threads x 8 bits
-  const size_t n = (size_t)s.dimx * s.dimy;
-  const size_t c = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  const size_t n = (size_t)s.x_hi * s.dimy, c_lo = (size_t)s.x_lo * s.dimy;   // (c_lo is a multiple of 64: launch_classify)
+  const size_t c = c_lo + ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
   uint32_t act = 0;
   if (c < n) {
     const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
-    const bool xm = x > 0, xp = x < s.dimx - 1, ym = y > 0, yp = y + 8 < s.dimy;
+    const bool xm = x > s.x_lo, xp = x < s.x_hi - 1, ym = y > 0, yp = y + 8 < s.dimy;
     const unsigned long long zero = 0ull;
     const unsigned long long r0 = *reinterpret_cast<const unsigned long long*>(s.flags + c);
     const unsigned long long rm = xm ? *reinterpret_cast<const unsigned long long*>(s.flags + c - s.dimy) : zero;
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) k_grid_classify8(DevState s) {
   reinterpret_cast<uint8_t*>(sm)[threadIdx.x] = (uint8_t)act;
   __syncthreads();
   if (threadIdx.x < 32) {
-    const size_t w0 = (size_t)blockIdx.x * 32 + threadIdx.x;   // 2048 cells per block = 32 bitmap words
+    const size_t w0 = (c_lo >> 6) + (size_t)blockIdx.x * 32 + threadIdx.x;   // 2048 cells per block = 32 bitmap words
     if (w0 * 64 < n) {
       const unsigned long long m = sm[threadIdx.x];
       s.active[w0] = m;
@@ -691,8 +691,8 @@ constexpr int MAX_LAYERS = 16;
 struct LayersDev { int n; LayerDev l[MAX_LAYERS]; };
 
 __global__ void __launch_bounds__(256) k_init_terrain(DevState s, LayersDev L) {
-  const size_t n = (size_t)s.dimx * s.dimy;
-  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)s.x_hi * s.dimy;
+  const size_t c = (size_t)s.x_lo * s.dimy + (size_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= n) return;
   const int i = (int)(c / s.dimy), j = (int)(c % s.dimy);
   double csize[MAX_LAYERS]; uint32_t ctype[MAX_LAYERS];
@@ -743,15 +743,15 @@ __global__ void __launch_bounds__(256) k_init_terrain(DevState s, LayersDev L) {
   s.flags[c] = flag;
 }
 
-__global__ void __launch_bounds__(256) k_heights(DevState s, double* __restrict__ out) {
-  const size_t n = (size_t)s.dimx * s.dimy;
-  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (c < n) out[c] = s.cells[c].floor + s.cells[c].size;
+__global__ void __launch_bounds__(256) k_heights(DevState s, double* __restrict__ out) {   // (out: the held range, first cell at out[0])
+  const size_t n = (size_t)s.x_hi * s.dimy, c_lo = (size_t)s.x_lo * s.dimy;
+  const size_t c = c_lo + (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < n) out[c - c_lo] = s.cells[c].floor + s.cells[c].size;
 }
 __global__ void __launch_bounds__(256) k_surface(DevState s, uint32_t* __restrict__ out) {
-  const size_t n = (size_t)s.dimx * s.dimy;
-  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (c < n) { uint32_t t = s.cells[c].type; out[c] = (t == EMPTY) ? 0u : t; }
+  const size_t n = (size_t)s.x_hi * s.dimy, c_lo = (size_t)s.x_lo * s.dimy;
+  const size_t c = c_lo + (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < n) { uint32_t t = s.cells[c].type; out[c - c_lo] = (t == EMPTY) ? 0u : t; }
 }
 __global__ void __launch_bounds__(256) k_normals(DevState s, float* __restrict__ out) {
   const size_t n = (size_t)s.dimx * s.dimy;
@@ -881,6 +881,9 @@ struct smx_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   size_t ncells = 0, nw0 = 0, nw1 = 0, nw2 = 0;
+  size_t c_lo = 0, c_hi = 0, lcells = 0;   // cells HELD by this context: [c_lo, c_hi) = columns [x_lo, x_hi) (the whole map unless smx_create_strip)
+  Sec* cells_alloc = nullptr; uint8_t* flags_alloc = nullptr; uint32_t* rhead_alloc = nullptr; uint32_t* cflag_alloc = nullptr;   // unbiased allocations
+  bool partial() const { return lcells != ncells; }
   SoilP* d_soils = nullptr;
   int nsoils = 0;
   double* d_scratch = nullptr;        // 1 double for point ops
@@ -973,8 +976,9 @@ extern "C" {
 
 const char* smx_last_error(smx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int smx_create(const smx_config* cfg, smx_ctx** out) {
+static int create_range(const smx_config* cfg, int x_lo, int x_hi, smx_ctx** out) {
   if (!cfg || !out || cfg->dimx <= 0 || cfg->dimy <= 0 || cfg->pool_capacity == 0 || cfg->pool_capacity >= 0x7FFFFFFFull) return -2;
+  if (x_lo < 0 || x_hi > cfg->dimx || x_lo >= x_hi) return -2;
   smx_ctx* ctx = new smx_ctx();
   ctx->cfg = *cfg;
   *out = ctx;   // handed out even on failure so the caller can read smx_last_error(); smx_destroy() is safe
@@ -989,11 +993,16 @@ int smx_create(const smx_config* cfg, smx_ctx** out) {
   DevState& d = ctx->d;
   memset(&d, 0, sizeof(d));
   d.dimx = cfg->dimx; d.dimy = cfg->dimy; d.scale = cfg->scale; d.pool_capacity = cfg->pool_capacity;
-  HIPCHK(hipMalloc(&d.cells, n * sizeof(Sec)));
+  d.x_lo = x_lo; d.x_hi = x_hi;
+  ctx->c_lo = (size_t)x_lo * cfg->dimy; ctx->c_hi = (size_t)x_hi * cfg->dimy; ctx->lcells = ctx->c_hi - ctx->c_lo;
+  const size_t ln = ctx->lcells;
+  HIPCHK(hipMalloc(&ctx->cells_alloc, ln * sizeof(Sec)));
+  d.cells = ctx->cells_alloc - ctx->c_lo;                     // global cell index, held range only (DevState::x_lo)
   HIPCHK(hipMalloc(&d.pool, cfg->pool_capacity * sizeof(Sec)));
   HIPCHK(hipMalloc(&d.freelist, cfg->pool_capacity * 4));
   HIPCHK(hipMalloc(&d.free_count, 64));
-  HIPCHK(hipMalloc(&d.flags, n + 8));   // (whole 32-bit words: SerialPolicy::set_flag)
+  HIPCHK(hipMalloc(&ctx->flags_alloc, ln + 8));   // (whole 32-bit words: SerialPolicy::set_flag; c_lo is a multiple of 4 or the context holds everything)
+  d.flags = ctx->flags_alloc - ctx->c_lo;
   HIPCHK(hipMalloc(&d.wfreq, n * 4)); HIPCHK(hipMalloc(&d.wtrack, n * 4)); HIPCHK(hipMalloc(&d.windfreq, n * 4));
   HIPCHK(hipMalloc(&d.rnd, sizeof(RandState)));
   HIPCHK(hipMalloc(&d.ctr, C_COUNT * 8));
@@ -1003,12 +1012,12 @@ int smx_create(const smx_config* cfg, smx_ctx** out) {
   d.soils = ctx->d_soils;
   HIPCHK(hipMemsetAsync(d.wfreq, 0, n * 4, ctx->stream)); HIPCHK(hipMemsetAsync(d.wtrack, 0, n * 4, ctx->stream));
   HIPCHK(hipMemsetAsync(d.windfreq, 0, n * 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(d.flags, 0, n, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->flags_alloc, 0, ln + 8, ctx->stream));
   HIPCHK(hipMemsetAsync(d.ctr, 0, C_COUNT * 8, ctx->stream));
   {   // all columns empty
-    std::vector<Sec> empty(n);
-    for (size_t i = 0; i < n; i++) { empty[i].size = 0; empty[i].floor = 0; empty[i].sat = 0; empty[i].type = EMPTY; empty[i].prev = NIL; }
-    HIPCHK(hipMemcpyAsync(d.cells, empty.data(), n * sizeof(Sec), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<Sec> empty(ln);
+    for (size_t i = 0; i < ln; i++) { empty[i].size = 0; empty[i].floor = 0; empty[i].sat = 0; empty[i].type = EMPTY; empty[i].prev = NIL; }
+    HIPCHK(hipMemcpyAsync(ctx->cells_alloc, empty.data(), ln * sizeof(Sec), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   if (reset_pool(ctx)) return -1;
@@ -1019,6 +1028,15 @@ int smx_create(const smx_config* cfg, smx_ctx** out) {
   if (const char* e = getenv("SMX_RELAX_WIND_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= R_MAXSTEPS) ctx->relax_wind_steps = v; }
   return 0;
 }
+int smx_create(const smx_config* cfg, smx_ctx** out) { return create_range(cfg, 0, cfg ? cfg->dimx : 0, out); }
+// A context that HOLDS only the columns [x_lo, x_hi) of a dimx x dimy map -- a column strip and its halo (smx_strips_*): cells, flags
+// and the engines' per-cell planes are allocated for that range, per-rank memory follows the strip. x_lo*dimy must be a multiple of 64.
+int smx_create_strip(const smx_config* cfg, int32_t x_lo, int32_t x_hi, smx_ctx** out) {
+  if (cfg && ((size_t)x_lo * (size_t)cfg->dimy) % 64 != 0) return -2;
+  return create_range(cfg, x_lo, x_hi, out);
+}
+#define FULLMAP(what)                                                                                                 \
+  if (ctx->partial()) { ctx->err = what ": not available on a strip context (smx_create_strip): it holds only a part of the map"; return -2; }
 
 static void strips_free(smx_ctx* ctx);
 void smx_destroy(smx_ctx* ctx) {
@@ -1028,7 +1046,7 @@ void smx_destroy(smx_ctx* ctx) {
   drain_events(ctx);
   for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
   DevState& d = ctx->d;
-  hipFree(d.cells); hipFree(d.pool); hipFree(d.freelist); hipFree(d.free_count); hipFree(d.flags);
+  hipFree(ctx->cells_alloc); hipFree(d.pool); hipFree(d.freelist); hipFree(d.free_count); hipFree(ctx->flags_alloc);
   hipFree(d.wfreq); hipFree(d.wtrack); hipFree(d.windfreq); hipFree(d.rnd); hipFree(d.ctr);
   hipFree(d.active); hipFree(d.active1); hipFree(d.active2); hipFree(ctx->d_scratch); hipFree(ctx->d_soils);
   hipFree(ctx->d_vtx); hipFree(ctx->d_vcol); hipFree(ctx->d_plane);
@@ -1042,7 +1060,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(bs.rhead); hipFree(bs.cflag); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1158,7 +1176,7 @@ int smx_initialize(smx_ctx* ctx, int32_t seed, const smx_layer* layers, int32_t 
   // Every (cell, layer) pair can become a section. The reference prints "Memory Pool Out-Of-Elements" and silently
   // drops the rest of the terrain (layermap.h:92-95,233); a device-parallel build cannot reproduce WHICH sections it
   // drops, so a pool that cannot hold the worst case is refused up front instead of producing a different map.
-  if ((uint64_t)ctx->ncells * (uint64_t)(nlayers > 0 ? nlayers : 1) > ctx->cfg.pool_capacity) {
+  if ((uint64_t)ctx->lcells * (uint64_t)(nlayers > 0 ? nlayers : 1) > ctx->cfg.pool_capacity) {
     ctx->err = "smx_initialize: pool_capacity < cells * layers (the reference's POOLSIZE would overflow during Layermap::initialize)";
     return -4;
   }
@@ -1179,7 +1197,7 @@ int smx_initialize(smx_ctx* ctx, int32_t seed, const smx_layer* layers, int32_t 
     d.noise.bounding = 1 / ampFractal;
     d.z = (float)(Z % MAXSEED) / 1.0f;                            // vec3(i,j,Z%MAXSEED)/vec3(dim.x,dim.y,1) (:191)
   }
-  const unsigned nb = (unsigned)((ctx->ncells + 255) / 256);
+  const unsigned nb = (unsigned)((ctx->lcells + 255) / 256);
   hipLaunchKernelGGL(k_init_terrain, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, L);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1188,27 +1206,28 @@ int smx_initialize(smx_ctx* ctx, int32_t seed, const smx_layer* layers, int32_t 
 
 int smx_import_columns(smx_ctx* ctx, const uint32_t* count, const uint32_t* type, const double* size,
                        const double* floor, const double* sat) {
-  const size_t n = ctx->ncells;
+  const size_t n = ctx->ncells, lo = ctx->c_lo, hi = ctx->c_hi, ln = ctx->lcells;   // (the arrays describe the WHOLE map; a strip context keeps its range)
   const uint64_t cap = ctx->cfg.pool_capacity;
-  std::vector<Sec> cells(n);
-  std::vector<uint8_t> flags(n, 0);
+  std::vector<Sec> cells(ln);
+  std::vector<uint8_t> flags(ln + 8, 0);
   std::vector<Sec> pool;
   size_t off = 0, total = 0;
-  for (size_t c = 0; c < n; c++) total += count[c];
+  for (size_t c = lo; c < hi; c++) total += count[c];
   if (total > cap) { ctx->err = "smx_import_columns: more sections than pool_capacity"; return -4; }
-  pool.reserve(total > n ? total - n + 1 : 1);
+  pool.reserve(total > ln ? total - ln + 1 : 1);
   for (size_t c = 0; c < n; c++) {
+    const uint32_t k = count[c];
+    if (c < lo || c >= hi) { off += k; continue; }
     Sec cell; cell.size = 0; cell.floor = 0; cell.sat = 0; cell.type = EMPTY; cell.prev = NIL;
     uint32_t pv = NIL;
-    const uint32_t k = count[c];
     for (uint32_t j = 0; j < k; j++, off++) {
       Sec r; r.size = size[off]; r.floor = floor[off]; r.sat = sat[off]; r.type = type[off]; r.prev = pv;
-      if (r.sat != 0.0) flags[c] |= F_SAT;
+      if (r.sat != 0.0) flags[c - lo] |= F_SAT;
       if (j == k - 1) cell = r;
       else { pv = (uint32_t)pool.size(); pool.push_back(r); }
     }
-    if (cell.type == AIR) flags[c] |= F_AIR;
-    cells[c] = cell;
+    if (cell.type == AIR) flags[c - lo] |= F_AIR;
+    cells[c - lo] = cell;
   }
   // node i of `pool` lives at pool index i; the free stack holds the remaining indices
   const uint64_t used = pool.size();
@@ -1217,11 +1236,11 @@ int smx_import_columns(smx_ctx* ctx, const uint32_t* count, const uint32_t* type
   for (uint64_t i = cap; i-- > used;) fl[nf++] = (uint32_t)i;
   uint32_t fc = (uint32_t)nf;
   unsigned long long live = total;
-  HIPCHK(hipMemcpyAsync(ctx->d.cells, cells.data(), n * sizeof(Sec), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->cells_alloc, cells.data(), ln * sizeof(Sec), hipMemcpyHostToDevice, ctx->stream));
   if (used) HIPCHK(hipMemcpyAsync(ctx->d.pool, pool.data(), used * sizeof(Sec), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d.freelist, fl.data(), cap * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d.free_count, &fc, 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d.flags, flags.data(), n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->flags_alloc, flags.data(), ln, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d.ctr + C_LIVE_SECTIONS, &live, 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -1245,18 +1264,19 @@ int smx_num_sections(smx_ctx* ctx, uint64_t* out) {
 }
 
 int smx_export_columns(smx_ctx* ctx, uint32_t* count, uint32_t* type, double* size, double* floor, double* sat) {
-  const size_t n = ctx->ncells;
+  const size_t n = ctx->ncells, lo = ctx->c_lo, hi = ctx->c_hi, ln = ctx->lcells;   // (a strip context reports empty columns outside its range)
   const uint64_t cap = ctx->cfg.pool_capacity;
-  std::vector<Sec> cells(n), pool(cap);
-  HIPCHK(hipMemcpyAsync(cells.data(), ctx->d.cells, n * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<Sec> cells(ln), pool(cap);
+  HIPCHK(hipMemcpyAsync(cells.data(), ctx->cells_alloc, ln * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(pool.data(), ctx->d.pool, cap * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   size_t off = 0;
   std::vector<const Sec*> col;
   for (size_t c = 0; c < n; c++) {
     col.clear();
-    if (cells[c].type != EMPTY) {
-      const Sec* t = &cells[c];
+    if (c < lo || c >= hi) { count[c] = 0; continue; }
+    if (cells[c - lo].type != EMPTY) {
+      const Sec* t = &cells[c - lo];
       while (true) {
         col.push_back(t);
         if (t->prev == NIL) break;
@@ -1276,6 +1296,7 @@ struct SnapHdr { char magic[8]; int32_t dimx, dimy, scale, nsoils; uint64_t ncel
 static_assert(sizeof(SnapHdr) == 64, "snapshot header");
 struct RandTrailer { char magic[8]; uint32_t ring[31]; uint32_t idx; uint64_t calls; };
 int smx_save(smx_ctx* ctx, const char* path) {
+  FULLMAP("smx_save")
   const size_t n = ctx->ncells;
   uint64_t ns = 0;
   if (smx_num_sections(ctx, &ns)) return -1;
@@ -1303,6 +1324,7 @@ int smx_save(smx_ctx* ctx, const char* path) {
   return 0;
 }
 int smx_load(smx_ctx* ctx, const char* path) {
+  FULLMAP("smx_load")
   FILE* f = fopen(path, "rb");
   if (!f) { ctx->err = std::string("smx_load: cannot open ") + path; return -7; }
   SnapHdr h;
@@ -1352,14 +1374,17 @@ int smx_read_frequency(smx_ctx* ctx, float* wfreq, float* wtrack, float* windfre
   return 0;
 }
 
-static int read_plane(smx_ctx* ctx, void* host, size_t bytes, int which) {
+static int read_plane(smx_ctx* ctx, void* host, size_t bytes, int which) {   // (a strip context fills its range; the rest of `host` reads 0)
+  if (which == 2) { FULLMAP("smx_normals") }
   if (ctx->plane_cap < bytes) { hipFree(ctx->d_plane); ctx->d_plane = nullptr; ctx->plane_cap = 0; HIPCHK(hipMalloc(&ctx->d_plane, bytes)); ctx->plane_cap = bytes; }
   void* tmp = ctx->d_plane;
-  const unsigned nb = (unsigned)((ctx->ncells + 255) / 256);
+  const unsigned nb = (unsigned)((ctx->lcells + 255) / 256);
+  const size_t el = which == 0 ? 8 : (which == 1 ? 4 : 12);
   if (which == 0) hipLaunchKernelGGL(k_heights, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (double*)tmp);
   else if (which == 1) hipLaunchKernelGGL(k_surface, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (uint32_t*)tmp);
   else hipLaunchKernelGGL(k_normals, dim3(nb), dim3(256), 0, ctx->stream, ctx->d, (float*)tmp);
-  hipError_t e = hipMemcpyAsync(host, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (ctx->partial()) memset(host, 0, bytes);
+  hipError_t e = hipMemcpyAsync((char*)host + ctx->c_lo * el, tmp, ctx->lcells * el, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return -1; }
   return 0;
@@ -1369,6 +1394,7 @@ int smx_read_surface(smx_ctx* ctx, uint32_t* out) { return read_plane(ctx, out, 
 int smx_normals(smx_ctx* ctx, float* out3) { return read_plane(ctx, out3, ctx->ncells * 12, 2); }
 
 static int fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44, VCut cut) {
+  FULLMAP("smx_fill_vertices")
   if (!colors4 || ncolors <= 0 || !out_vertices44) { ctx->err = "smx_fill_vertices: colors4/out must be given"; return -2; }
   const size_t bytes = ctx->ncells * 44;
   if (!ctx->d_vtx) {                                        // scratch kept for the context's lifetime (738 MB at 4096^2)
@@ -1395,6 +1421,7 @@ int smx_fill_vertices_cut(smx_ctx* ctx, const float* colors4, int32_t ncolors, i
 }
 
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out) {
+  FULLMAP("smx_heights_bilinear")
   float* dpos = nullptr; double* dout = nullptr;
   HIPCHK(hipMalloc(&dpos, (size_t)n * 8)); HIPCHK(hipMalloc(&dout, (size_t)n * 8));
   HIPCHK(hipMemcpyAsync(dpos, pos2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1408,6 +1435,7 @@ int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out
 
 // ---------------- speculative engine: host driver ----------------
 static int spec_alloc(smx_ctx* ctx, uint32_t n) {          // n = particles of the phase; it owns n + SPEC_MAXNEST slots
+  FULLMAP("the speculative engine")
   if (ctx->spec_cap >= n) return 0;
   SpecShared& sh = ctx->sh;
   if (ctx->spec_cap) {
@@ -1534,14 +1562,14 @@ static void launch_classify(smx_ctx* ctx);
 static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
   BatchShared& bs = ctx->bs;
   if (!bs.ctrl) {
-    bs.tshift = -1; bs.ntx = ctx->cfg.dimx; bs.nty = ctx->cfg.dimy;
-    const size_t nt = ctx->ncells;                          // one claim word per cell: enough for every granularity
+    bs.tshift = -1; bs.ntx = ctx->cfg.dimx; bs.nty = ctx->cfg.dimy; bs.txb = 0;
+    const size_t nt = ctx->lcells + 2 * (size_t)ctx->cfg.dimy;   // one claim word per held cell (+ a row of slack for tiles cut by the range's edges): enough for every granularity
     HIPCHK(hipMalloc(&bs.claim[0], nt * 8)); HIPCHK(hipMalloc(&bs.claim[1], nt * 8));
     HIPCHK(hipMalloc(&bs.ctrl, BC_COUNT * 4)); HIPCHK(hipMemsetAsync(bs.ctrl, 0, BC_COUNT * 4, ctx->stream));
     // nested particles of one generation / pool nodes released in one chunk: sized by the map (a grid pass over a map full
     // of lakes emits children for a sizeable part of its cells); running out is counted (children_lost) / an error (freed)
-    bs.child_cap = (uint32_t)std::max<size_t>((size_t)1 << 20, ctx->ncells / 2); HIPCHK(hipMalloc(&bs.children, (size_t)bs.child_cap * sizeof(BChild)));
-    bs.freed_cap = (uint32_t)std::max<size_t>((size_t)1 << 22, ctx->ncells / 2); HIPCHK(hipMalloc(&bs.freed, (size_t)bs.freed_cap * 4));
+    bs.child_cap = (uint32_t)std::max<size_t>((size_t)1 << 20, ctx->lcells / 2); HIPCHK(hipMalloc(&bs.children, (size_t)bs.child_cap * sizeof(BChild)));
+    bs.freed_cap = (uint32_t)std::max<size_t>((size_t)1 << 22, ctx->lcells / 2); HIPCHK(hipMalloc(&bs.freed, (size_t)bs.freed_cap * 4));
     {
       const size_t ngt = (size_t)((ctx->cfg.dimx + 3) >> 2) * ((ctx->cfg.dimy + 3) >> 2);
       HIPCHK(hipMalloc(&bs.dirty, ngt)); HIPCHK(hipMemsetAsync(bs.dirty, 0, ngt, ctx->stream));
@@ -1571,8 +1599,9 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
     ctx->relax_cap = cap;
   }
   if (ctx->cfg.engine == SMX_ENGINE_RELAXED && !bs.rhead) {   // per-cell request lists and cascade flags (8 B / cell), empty between epochs
-    HIPCHK(hipMalloc(&bs.rhead, ctx->ncells * 4)); HIPCHK(hipMalloc(&bs.cflag, ctx->ncells * 4));
-    HIPCHK(hipMemsetAsync(bs.rhead, 0xFF, ctx->ncells * 4, ctx->stream)); HIPCHK(hipMemsetAsync(bs.cflag, 0, ctx->ncells * 4, ctx->stream));
+    HIPCHK(hipMalloc(&ctx->rhead_alloc, ctx->lcells * 4)); HIPCHK(hipMalloc(&ctx->cflag_alloc, ctx->lcells * 4));
+    HIPCHK(hipMemsetAsync(ctx->rhead_alloc, 0xFF, ctx->lcells * 4, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->cflag_alloc, 0, ctx->lcells * 4, ctx->stream));
+    bs.rhead = ctx->rhead_alloc - ctx->c_lo; bs.cflag = ctx->cflag_alloc - ctx->c_lo;   // (global cell index, held range only)
   }
   if (ctx->draws_cap < 2u * nslots) {
     hipFree(ctx->d_draws); if (ctx->h_draws) hipHostFree(ctx->h_draws); ctx->d_draws = nullptr; ctx->h_draws = nullptr; ctx->draws_cap = 0;
@@ -1624,7 +1653,10 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
   ctx->bs.sphase = strips ? (int)(chunk & 1u) : STRIP_INTERIOR;   // column strips: INTERIOR and SEAM chunks alternate
   if (strips && chunk > 0) epoch++;                        // (reservations of the previous chunk must not look current)
   chunk++;
-  if (regrain) { const size_t nt = (size_t)bs.ntx * bs.nty; HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st)); }
+  if (regrain) {                                           // (the planes hold the tile columns of the context's range)
+    const size_t nt = (size_t)(((ctx->d.x_hi - 1) >> bs.tshift) - (ctx->d.x_lo >> bs.tshift) + 1) * bs.nty;
+    HIPCHK(hipMemsetAsync(bs.claim[0], 0, nt * 8, st)); HIPCHK(hipMemsetAsync(bs.claim[1], 0, nt * 8, st));
+  }
   if ((regrain || strips) && nlive) {                      // under strips every chunk starts with fresh reservations
     if (wind) hipLaunchKernelGGL(k_batch_reclaim<true>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
     else hipLaunchKernelGGL(k_batch_reclaim<false>, dim3((nlive + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
@@ -1639,7 +1671,7 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     const bool tail = !wind && use_tail && nlive <= RELAX_TAIL;
     chunk_epochs = strips ? B_CHUNK : (tail ? 64 : (first ? CHUNK : RCHUNK_KIDS));
     ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : 2; ctx->bs.rsteps = wind ? ctx->relax_wind_steps : 1;
-    if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(bs.cflag, 0, ctx->ncells * 4, st)); }   // (tags never repeat)
+    if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(ctx->cflag_alloc, 0, ctx->lcells * 4, st)); }   // (tags never repeat)
     if (strips) HIPCHK(hipMemsetAsync(bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
     if (strips && !wind) {                                   // who waits for a flood on this device right now?
       if (nslots) hipLaunchKernelGGL(k_relax_rebuild_floods, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots, epoch & 1u);
@@ -1797,10 +1829,10 @@ static int batch_grid(smx_ctx* ctx) {
 static void launch_classify(smx_ctx* ctx) {                  // which cells can the grid pass change at all? (one flag byte per cell in, one bit out)
   PhaseTimer tk(ctx, 6);
   static const bool scalar = [] { const char* e = getenv("SMX_CLASSIFY_SCALAR"); return e && atoi(e) != 0; }();
-  if (ctx->cfg.dimy % 8 == 0 && ctx->ncells % 64 == 0 && !scalar)
-    hipLaunchKernelGGL(k_grid_classify8, dim3((unsigned)((ctx->ncells / 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d);
+  if (ctx->cfg.dimy % 8 == 0 && ctx->lcells % 64 == 0 && ctx->c_lo % 64 == 0 && !scalar)
+    hipLaunchKernelGGL(k_grid_classify8, dim3((unsigned)((ctx->lcells / 8 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d);
   else
-    hipLaunchKernelGGL(k_grid_classify, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d);
+    hipLaunchKernelGGL(k_grid_classify, dim3((unsigned)((ctx->lcells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d);
 }
 
 }  // extern "C"
@@ -2011,6 +2043,7 @@ static bool is_batched(const smx_ctx* ctx) { return ctx->cfg.engine == SMX_ENGIN
 extern "C" {
 // ---------------- the hot path ----------------
 int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
+  FULLMAP("smx_tick_water (a strip ticks with smx_strips_tick)")
   roctx_range rr("soilmx:water");
   PhaseTimer t(ctx, 0);
   if (is_batched(ctx)) return batch_generations(ctx, false, nwater > 0 ? (uint32_t)nwater : 0u, {});
@@ -2021,6 +2054,7 @@ int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   return 0;
 }
 int smx_grid_pass(smx_ctx* ctx) {
+  FULLMAP("smx_grid_pass (a strip ticks with smx_strips_tick)")
   roctx_range rr("soilmx:grid");
   PhaseTimer t(ctx, 1);
   if (is_batched(ctx)) return batch_grid(ctx);
@@ -2032,6 +2066,7 @@ int smx_grid_pass(smx_ctx* ctx) {
   return 0;
 }
 int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
+  FULLMAP("smx_tick_wind (a strip ticks with smx_strips_tick)")
   roctx_range rr("soilmx:wind");
   PhaseTimer t(ctx, 2);
   if (is_batched(ctx)) return batch_generations(ctx, true, nwind > 0 ? (uint32_t)nwind : 0u, {});
@@ -2078,6 +2113,7 @@ static int point_op(smx_ctx* ctx, const PointOp& o, double* out) {
 }
 static bool inb(smx_ctx* ctx, int x, int y) {
   if (x < 0 || y < 0 || x >= ctx->cfg.dimx || y >= ctx->cfg.dimy) { ctx->err = "cell out of bounds"; return false; }
+  if (ctx->partial()) { ctx->err = "point operations are not available on a strip context (smx_create_strip)"; return false; }
   return true;
 }
 int smx_add(smx_ctx* ctx, int32_t x, int32_t y, double size, uint32_t type) {
@@ -2089,6 +2125,7 @@ int smx_remove(smx_ctx* ctx, int32_t x, int32_t y, double h, double* remainder) 
   PointOp o{}; o.op = 1; o.x = x; o.y = y; o.a = h; double r = 0; int rc = point_op(ctx, o, &r); if (remainder) *remainder = r; return rc;
 }
 int smx_particle_cascade(smx_ctx* ctx, float px, float py, int32_t transferloop) {
+  FULLMAP("smx_particle_cascade")
   if (!(px == px) || !(py == py) || !inb(ctx, (int)roundf(px), (int)roundf(py))) { ctx->err = "cell out of bounds"; return -2; }
   PointOp o{}; o.op = 2; o.px = px; o.py = py; o.k = transferloop; return point_op(ctx, o, nullptr);
 }
@@ -2116,11 +2153,11 @@ int smx_top(smx_ctx* ctx, int32_t x, int32_t y, uint32_t* type, double* size, do
 }
 
 // ---------------- observability ----------------
-int smx_digest(smx_ctx* ctx, double* sumh, uint64_t* nsec, uint64_t* typehash) {
-  const size_t n = ctx->ncells;
+int smx_digest(smx_ctx* ctx, double* sumh, uint64_t* nsec, uint64_t* typehash) {   // (a strip context digests the range it holds)
+  const size_t n = ctx->lcells;
   const uint64_t cap = ctx->cfg.pool_capacity;
   std::vector<Sec> cells(n);
-  HIPCHK(hipMemcpyAsync(cells.data(), ctx->d.cells, n * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(cells.data(), ctx->cells_alloc, n * sizeof(Sec), hipMemcpyDeviceToHost, ctx->stream));
   // {type, prev} = the last 8 bytes of every 32-byte pool record: one strided 2D copy instead of the whole pool
   std::vector<uint64_t> tp(cap);
   HIPCHK(hipMemcpy2DAsync(tp.data(), 8, reinterpret_cast<const char*>(ctx->d.pool) + 24, sizeof(Sec), 8, cap, hipMemcpyDeviceToHost, ctx->stream));
@@ -2223,6 +2260,7 @@ int smx_lbm_set_boundary(smx_lbm* l, const float* b) {
 }
 int smx_lbm_boundary_from_map(smx_lbm* l, smx_ctx* ctx, float sx, float sy, float sz) {
   if (!ctx) { l->err = "smx_lbm_boundary_from_map: no map"; return -2; }
+  if (ctx->partial()) { l->err = "smx_lbm_boundary_from_map: the map context holds only a strip"; return -2; }
   if (ctx->cfg.device != l->device) { l->err = "smx_lbm_boundary_from_map: map and lattice live on different devices"; return -2; }
   if ((int)(sx * (float)(l->d.nx - 1)) >= ctx->cfg.dimx || (int)(sz * (float)(l->d.nz - 1)) >= ctx->cfg.dimy || sx < 0.f || sz < 0.f) {
     l->err = "smx_lbm_boundary_from_map: the scaled lattice does not fit the map"; return -2;

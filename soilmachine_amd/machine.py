@@ -33,7 +33,8 @@ class Layermap:
     """Device-resident layermap (cells + section pool + frequency planes) behind the C-ABI."""
 
     def __init__(self, cfg: SoilConfig, dimx: int | None = None, dimy: int | None = None, *, seed: int = 0,
-                 pool: int | None = None, device: int = 0, engine: int = capi.ENGINE_SERIAL, initialize: bool = True):
+                 pool: int | None = None, device: int = 0, engine: int = capi.ENGINE_SERIAL, initialize: bool = True,
+                 x_range: tuple | None = None):
         self.L = capi.load()
         self.cfg = cfg
         self.dimx = int(dimx if dimx is not None else cfg.SIZEX)
@@ -42,7 +43,8 @@ class Layermap:
         self.pool = int(pool if pool is not None else default_pool(self.dimx, self.dimy))
         c = capi.Config(self.dimx, self.dimy, cfg.SCALE, device, self.pool, engine, 0)
         h = C.c_void_p()
-        rc = self.L.smx_create(C.byref(c), C.byref(h))
+        self.x_range = x_range                                    # (lo, hi): a STRIP context holding only these columns (smx_create_strip)
+        rc = self.L.smx_create(C.byref(c), C.byref(h)) if x_range is None else self.L.smx_create_strip(C.byref(c), int(x_range[0]), int(x_range[1]), C.byref(h))
         self.h = h
         if rc != 0:
             msg = self.L.smx_last_error(h).decode() if h else "smx_create failed"

@@ -46,6 +46,13 @@ class StripGeometry:
         self.n, self.a, self.b, self.dimx = n, a, b, dimx
         self.x = [dimx if g == n else (dimx * g // n) // 16 * 16 for g in range(n + 1)]
 
+    def held(self, rank: int, dimy: int):
+        """the columns a STRIP context of `rank` must hold (Layermap(x_range=...), smx_create_strip): its strip, the seam zone right of
+        it and 16 columns of slack -- or None (hold everything) when that range cannot start on a 64-cell boundary"""
+        lo = max(0, self.x[rank] - 16) if rank > 0 else 0
+        hi = min(self.dimx, self.x[rank + 1] + self.b + 16) if rank < self.n - 1 else self.dimx
+        return (lo, hi) if (lo * dimy) % 64 == 0 else None
+
 
 # ------------------------------------------------------------------------------------------------ transports
 class ThreadComm:

@@ -57,7 +57,7 @@ extern "C" {
 hs_ctx* hs_create(int dimx, int dimy, int scale, uint64_t cap) {
   hs_ctx* c = new hs_ctx();
   memset(&c->d, 0, sizeof(c->d));
-  c->d.dimx = dimx; c->d.dimy = dimy; c->d.scale = scale; c->d.pool_capacity = cap;
+  c->d.dimx = dimx; c->d.dimy = dimy; c->d.scale = scale; c->d.pool_capacity = cap; c->d.x_lo = 0; c->d.x_hi = dimx;
   c->n = (size_t)dimx * dimy;
   c->cells.resize(c->n); c->pool.resize(cap); c->freelist.resize(cap); c->flags.assign(c->n + 8, 0);   // (whole 32-bit words: SerialPolicy::set_flag)
   for (size_t i = 0; i < c->n; i++) { Sec& s = c->cells[i]; s.size = s.floor = s.sat = 0; s.type = EMPTY; s.prev = NIL; }
@@ -354,7 +354,7 @@ extern "C" void hs_set_relaxed(int on) { g_relaxed = on; }
 extern "C" void hs_set_relax_wind(uint32_t n, int steps) { g_relax_wind_min = n; g_relax_wind_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
 static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) {
   const DevState& s = c->d;
-  b.bs.tshift = -1; b.bs.ntx = s.dimx; b.bs.nty = s.dimy;
+  b.bs.tshift = -1; b.bs.ntx = s.dimx; b.bs.nty = s.dimy; b.bs.txb = 0;
   const size_t nt = (size_t)s.dimx * s.dimy;                // one claim word per cell: enough for every granularity
   b.claim0.assign(nt, 0); b.claim1.assign(nt, 0);
   if (wind) b.wind.resize(nslots); else b.water.resize(nslots);

@@ -33,8 +33,9 @@ def start_state(kind, n):
     return cfg, Layermap(cfg, n, n, seed=0).snapshot()
 
 
-def device_ctx(cfg, s0, n, engine=capi.ENGINE_BATCHED):
-    m = Layermap(cfg, n, n, seed=0, initialize=False, engine=engine)
+def device_ctx(cfg, s0, n, engine=capi.ENGINE_BATCHED, x_range=None):
+    """x_range = (lo, hi): a STRIP context that holds only these columns of the map (smx_create_strip): memory follows the strip"""
+    m = Layermap(cfg, n, n, seed=0, initialize=False, engine=engine, x_range=x_range)
     m.load(s0, rand_seed=0)
     return m
 
@@ -84,7 +85,8 @@ def test_library_strip_driver_over_loopback_equals_single_context(kind, G, n, nw
     cfg, s0 = start_state(kind, n)
     ref, cref = single_context(cfg, s0, n, G, nw, nd, ticks)
     geom = StripGeometry(n, G)
-    ms = [device_ctx(cfg, s0, n) for _ in range(G)]
+    ms = [device_ctx(cfg, s0, n, x_range=geom.held(r, n)) for r in range(G)]      # every context holds its strip + halo only
+    assert all(m.x_range is not None for m in ms)
     comms = ThreadComm.world(G)
     ranks = [None] * G
 
@@ -112,7 +114,7 @@ def test_relaxed_schedule_in_strips_library_driver_equals_single_context(kind, G
     cfg, s0 = start_state(kind, n)
     ref, cref = single_context(cfg, s0, n, G, nw, nd, ticks, capi.ENGINE_RELAXED)
     geom = StripGeometry(n, G)
-    ms = [device_ctx(cfg, s0, n, capi.ENGINE_RELAXED) for _ in range(G)]
+    ms = [device_ctx(cfg, s0, n, capi.ENGINE_RELAXED, x_range=geom.held(r, n)) for r in range(G)]
     comms = ThreadComm.world(G)
 
     class R:
