@@ -354,12 +354,25 @@ def main():
     steps = r["steps_w"] + r["steps_d"]
     dev = torch.device("cuda", local_rank) if (torch.cuda.is_available() and (dist is None or dist.get_backend() == "nccl")) else torch.device("cpu")
     tmax, total_steps = distrib.aggregate(dist, r["dt"], steps, dev)
+    strips4 = None
+    if strips and not args.no_lines and not args.strong and args.size == 4096 and args.only is None:
+        # BASELINE configs[4] as the config text states it: ONE 8192^2 rockgravelpebbles_big map split into N column strips (a STRONG split of a
+        # fixed map, next to the weak headline), area-scaled NWATER, 2 timed ticks after 1. Every rank takes part; rank 0 reports it in `lines`.
+        bcfg4 = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", "rockgravelpebbles_big.soil"))
+        n4, nw4 = 8192, int(250 * (8192 / 256.0) ** 2)
+        r4 = measure_strips(bcfg4, n4, n4, nw4, 0, max(10_000_000, 3 * n4 * n4), local_rank, 2, 1, dist, barrier, torch, engine)
+        t4, s4 = distrib.aggregate(dist, r4["dt"], r4["steps_w"] + r4["steps_d"], dev)
+        strips4 = {"name": f"configs4_8192_rockgravelpebbles_big_{world}_strips", "engine": eng_name, "scaling": "strong",
+                   "workload": f"8192x8192, soil/rockgravelpebbles_big.soil, area-scaled NWATER={nw4} / NWIND=0, ONE map in {world} column strips of {n4 // world}x{n4} (BASELINE configs[4])",
+                   "value": s4 / t4, "unit": "particle-steps/s", "ms_per_tick": 1e3 * t4 / 2, "steps": 2, "warmup": 1, "n_gpus": world,
+                   "engine_stats_rank0": r4["engine_stats"], "single_gpu_reference": "lines[configs4_8192_rockgravelpebbles_big_relaxed] of the N=1 run (profiles/r03_bench.json: 356 M steps/s, 316 ms/tick)"}
 
     if rank == 0:
         tm = r["tm"]
         kname = {"serial": ("k_water_serial", "k_wind_serial"), "spec": ("k_spec_exec_coop<water>", "k_spec_exec_coop<wind>"),
                  "batched": ("k_batch_epoch<water>", "k_batch_epoch<wind>"),
-                 "relaxed": ("k_relax_step<water>", "k_relax_step<wind> (+ k_batch_epoch<wind> for the exclusive tail)")}[eng_name]
+                 "relaxed": ("k_relax_step<water>", "k_relax_step<wind> (+ k_batch_epoch<wind> for the exclusive tail)" if os.environ.get("SMX_RELAX_WIND_MIN")
+                             else "k_batch_epoch<wind> (the relaxed engine runs wind on the exclusive schedule by default: profiles/r03_relaxed.md)")}[eng_name]
         kernels = {"water": (tm["ms_kernel_water"], tm["launches_kernel_water"], r["steps_w"] * B_WATER_STEP, kname[0]),
                    "wind": (tm["ms_kernel_wind"], tm["launches_kernel_wind"], r["steps_d"] * B_WIND_STEP, kname[1])}
         dom = max(kernels, key=lambda k: kernels[k][0])
@@ -407,7 +420,7 @@ def main():
                     f"{' (area-scaled, SURVEY 8d)' if throughput and args.nwater is None else ''}, "
                     f"tick = water + grid pass + wind + frequency")
         head = line_of(r, "headline", workload, eng_name, args.steps)
-        lines = []
+        lines = [strips4] if strips4 else []
         parity = None
         if not args.no_lines and world == 1:
             k3, w3 = max(2, min(args.steps, 3)), max(1, min(args.warmup, 2))

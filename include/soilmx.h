@@ -10,9 +10,11 @@
  * buffers are caller-allocated; "cell order" is the Layermap index x*dimy + y (source/layermap.h:151),
  * "frequency order" is y*dimx + x (source/particle/water.h:53,349).
  *
- * Exactness contract: smx_tick* executes the reference's sequential semantics (SoilMachine.cpp:283-329)
- * -- results are bit-identical to the reference CPU path for the same soil table, terrain, SCALE and
- * libc rand() stream, whichever execution engine (SMX_ENGINE_*) runs them.
+ * Exactness contract: under SMX_ENGINE_SERIAL and SMX_ENGINE_SPECULATIVE smx_tick* executes the reference's sequential
+ * semantics (SoilMachine.cpp:283-329) -- results are bit-identical to the reference CPU path for the same soil table,
+ * terrain, SCALE and libc rand() stream. SMX_ENGINE_BATCHED / SMX_ENGINE_RELAXED are deterministic throughput schedules that
+ * do NOT keep the reference's particle order: statistical parity only, measured against the reference's own sensitivity to
+ * its rand() stream.
  */
 #ifndef SOILMX_H
 #define SOILMX_H

@@ -65,8 +65,10 @@ struct RcclTransport : StripTransport {
   int send_bundle(smx_ctx* ctx, int peer, const XBundle& b) override {
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemcpyAsync(&d_hdr[0], &b, sizeof(b), hipMemcpyHostToDevice, st));
-    NCCLCHK(g_rccl.GroupStart());
+    // same shape on both sides: the header as an operation of its own (the receiver needs it before it can post the rest),
+    // then ONE group with the payloads -- point-to-point operations between two ranks pair up in the order they were issued
     NCCLCHK(g_rccl.Send(&d_hdr[0], sizeof(XBundle), ncclUint8, peer, comm, st));
+    NCCLCHK(g_rccl.GroupStart());
     if (b.nrec) { NCCLCHK(g_rccl.Send(ctx->d_xoffs, 4ull * b.nrec, ncclUint8, peer, comm, st)); NCCLCHK(g_rccl.Send(ctx->d_xdata, b.nbytes, ncclUint8, peer, comm, st)); }
     if (b.npart) NCCLCHK(g_rccl.Send(ctx->d_xpart, (size_t)b.npart * b.rs, ncclUint8, peer, comm, st));
     NCCLCHK(g_rccl.GroupEnd());

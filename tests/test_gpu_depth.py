@@ -74,6 +74,60 @@ def test_appendix_e_default256_deep(case):
     run_case(case, capi.ENGINE_SPECULATIVE)
 
 
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("SMX_DEEP10K"), reason="opt-in (SMX_DEEP10K=1): ~10 GPU-minutes; this round's run is recorded in profiles/r03_deep_10k.json")
+def test_ten_thousand_ticks_height_rmse_vs_reference():
+    """north_star's long-run bar ("CPU-vs-GPU height RMSE < 1e-4 after 10k ticks"): 64^2 default.soil, SEED 0, 16 water particles
+    per tick (250 scaled by area from configs[0]), 10 000 ticks. The exact engine must stay BIT-identical to the CPU path (RMSE 0)
+    at every checkpoint; the throughput schedules are recorded next to the reference's own chaos (the CPU path with one rand()
+    draw burnt after initialisation). soil_ref (the reference's own headers) pins the oracle's final digest when it is there."""
+    import json, time
+    from oracle_lib import have_ref, run_ref
+    from common import soil_path
+    n, nw, marks = 64, 16, [100, 1000, 3000, 10000]
+    out_path = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "deep_10k.json")
+    if os.environ.get("SMX_DEEP10K_TICKS"):
+        marks = [t for t in marks if t <= int(os.environ["SMX_DEEP10K_TICKS"])]
+    cfg = load_cfg("default.soil")
+    o = Oracle(cfg, n, n, seed=0); o.initialize()
+    ctl = Oracle(cfg, n, n, seed=0); ctl.initialize(); ctl.L.so_rand(ctl.h)
+    eng = {"exact": capi.ENGINE_SPECULATIVE, "relaxed": capi.ENGINE_RELAXED, "batched": capi.ENGINE_BATCHED}
+    sms = {k: SoilMachine(cfg, n, seed=0, nwater=nw, nwind=0, dowind=False, engine=e) for k, e in eng.items()}
+    rec, t_prev, t_dev = {"size": n, "nwater": nw, "soil": "default.soil", "checkpoints": []}, 0, {k: 0.0 for k in eng}
+    for t in marks:
+        for _ in range(t - t_prev):
+            o.tick(nw, 0, True, False); ctl.tick(nw, 0, True, False)
+        want, hw = o.snapshot(), o.heights()
+        row = {"ticks": t, "mean_height": float(hw.mean()), "nsec_ref": int(want.count.sum()),
+               "control_cpu_other_rand_stream": {"height_rmse": float(np.sqrt(np.mean((ctl.heights() - hw) ** 2))),
+                                                 "nsec_rel": float(ctl.snapshot().count.sum() / want.count.sum() - 1)}}
+        for k, sm in sms.items():
+            t0 = time.time(); sm.tick(t - t_prev, sync=True); t_dev[k] += time.time() - t0
+            hg = sm.map.heights()
+            row[k] = {"height_rmse": float(np.sqrt(np.mean((hg - hw) ** 2))), "max_abs": float(np.abs(hg - hw).max()),
+                      "nsec_rel": float(sm.map.digest()["nsec"] / want.count.sum() - 1), "device_seconds_so_far": round(t_dev[k], 1)}
+            if k == "exact":
+                row[k]["bit_identical"] = not compare(sm.map.snapshot(), want)
+        rec["checkpoints"].append(row)
+        t_prev = t
+        os.makedirs(os.path.dirname(out_path), exist_ok=True)
+        with open(out_path, "w") as f:                             # after every checkpoint: a cut-off run still leaves its record
+            json.dump(rec, f, indent=1)
+    if have_ref() and t_prev == 10000:
+        r = run_ref(soil_path("default.soil"), seed=0, size=n, ticks=t_prev, nwater=nw, wind=False, lean=True)
+        g = sms["exact"].map.digest()
+        rec["soil_ref_digest_equal"] = (g["nsec"], g["typehash"], g["sumh"], g["rand_calls"]) == (r["nsec"], r["typehash"], r["sumh"], r["rand_calls"])
+    with open(out_path, "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps(rec))
+    for row in rec["checkpoints"]:
+        assert row["exact"]["bit_identical"] and row["exact"]["height_rmse"] == 0.0, row
+    assert rec.get("soil_ref_digest_equal", True)
+    last = rec["checkpoints"][-1]
+    for k in ("relaxed", "batched"):                               # inside 2x the reference's own one-draw chaos
+        assert last[k]["height_rmse"] <= 2.0 * max(last["control_cpu_other_rand_stream"]["height_rmse"], 1e-4), (k, last)
+
+
 # ---------------------------------------------------------------- entry points that had no test in round 1
 def test_smx_top_matches_oracle_columns():
     cfg = load_cfg("rockgravelpebblessand.soil")

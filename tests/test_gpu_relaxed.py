@@ -66,6 +66,23 @@ def test_1024_coupled_structure_and_envelope_against_the_exact_engine():
     assert ctrs["relaxed"]["pool_overflow"] == 0
 
 
+def test_relaxed_stays_inside_the_exact_engines_own_rand_stream_envelope():
+    """VERDICT r2 item 2's gate, on the device: the relaxed schedule against the EXACT engine from the same terrain, next to the exact
+    engine under other rand() streams (the reference's own chaos). 512^2 rockgravelpebblessand, area-scaled counts, 12 ticks, 2 control
+    streams (the 1024^2 x 10 record of the same comparison: profiles/r03_p2_envelope_1024.json; larger sizes: tools/p2_envelope.py).
+    Fails if the relaxed engine leaves 1.25 x the control's spread on height RMSE, section count, sum of heights or water steps."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    out = bench.parity_block(cfg, "rockgravelpebblessand.soil", 512, 1000, 250, 4_000_000, 0, 12, 2, [("relaxed", capi.ENGINE_RELAXED)])
+    ctl = out["control_exact_other_rand_stream"]
+    floor = {"height_rmse": 0.0, "nsec_rel": 0.02, "sumh_rel": 2e-5, "steps_water_rel": 0.03}   # (two streams can happen to agree closely)
+    for k in ("height_rmse", "nsec_rel", "sumh_rel", "steps_water_rel"):
+        bound = max(1.25 * max(abs(c[k]) for c in ctl), floor[k])
+        assert abs(out["relaxed"][k]) <= bound, (k, out["relaxed"][k], [c[k] for c in ctl])
+
+
 def test_relaxed_strip_schedule_device_equals_host_threads():
     """the relaxed schedule under column strips (one context, two strips), device against the same headers on host threads"""
     from hostsim_lib import lib

@@ -3,7 +3,8 @@
 #   gpurun --timeout T -- 'tools/gpu_run.sh <tag> <budget-seconds> step [step ...]'
 # Every step has its own timeout, writes gpurun_out/<tag>/<step>.{log,err} and leaves a line in status.txt; steps that no
 # longer fit the budget are skipped and say so. Steps (most are thin wrappers around tools/*.py, tests/ and bench.py):
-#   smoke | quick | parity | gpusuite | wet | bench | benchfull | trace | pmc | exact4096 | envelope | relaxed | strips2 | deep300 | deep1000 | rmse10k
+#   smoke quick parity gpusuite relaxtest stripstest headrelax* headbatch ktrace tracerelax bench2gloo wet bench benchfull trace pmc pmcwet
+#   exact4096 envelope deep300 deep1000 deep10k
 set -u
 tag=$1; budget=$2; shift 2
 root="${GRAFT_REPO_ROOT:-/root/repo}"
@@ -35,6 +36,10 @@ for s in "$@"; do
     headrelaxw0) run headrelaxw0 30 300 env SMX_RELAX_WIND_MIN=4000000000 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     ktrace)    run ktrace 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 3 --warmup 2
                python tools/kernel_stats.py $out/ktrace | tee $out/ktrace.summary ;;
+    ktracew)   run ktracew 30 300 env SMX_RELAX_WIND_MIN=${WMIN:-4096} SMX_RELAX_WIND_STEPS=${WSTEPS:-8} rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktracew -o t -- python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 3 --warmup 2
+               python tools/kernel_stats.py $out/ktracew | tee $out/ktracew.summary ;;
+    tracew)    run tracew 30 300 env SMX_TRACE_BATCH=1 SMX_RELAX_WIND_MIN=${WMIN:-4096} SMX_RELAX_WIND_STEPS=${WSTEPS:-8} python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 3 ;;
+    tracex)    run tracex 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 3 ;;
     headbatch) run headbatch 30 300 python bench.py --engine batched --no-lines --no-cpu-baseline --steps 3 --warmup 2 ;;
     tracerelax) run tracerelax 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 5 ;;
     stripstest) run stripstest 60 900 python -m pytest tests/test_gpu_strips.py -x -q -m gpu --durations=8 ;;
@@ -43,10 +48,11 @@ for s in "$@"; do
     bench)     run bench 60 400 python bench.py; cp $out/bench.log $out/bench.json 2>/dev/null ;;
     benchfull) run benchfull 120 900 python bench.py --full; cp $out/benchfull.log $out/benchfull.json 2>/dev/null ;;
     trace)     run trace 60 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
-    pmc)       for set in "FETCH_SIZE WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
-                 n=$(echo $set | tr ' ' '_' | cut -c1-24)
-                 run pmc_$n 60 300 rocprofv3 --pmc $set --output-format csv -d $out/pmc_$n -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
-               done ;;
+    pmc)       PB="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-lines"
+               run pmc_FETCH_SIZE 60 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_FETCH_SIZE -o p -- $PB
+               run pmc_WRITE_SIZE 60 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_WRITE_SIZE -o p -- $PB
+               run pmc_SQ 60 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM --output-format csv -d $out/pmc_SQ -o p -- $PB
+               python tools/make_pmc_json.py $out "4096/64000/16000/relaxed" "$PB" | tee $out/pmc.summary ;;
     pmcwet)    i=0; for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM" \
                                   "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_BRANCH"; do
                  i=$((i+1))
@@ -55,11 +61,9 @@ for s in "$@"; do
                done ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
     envelope)  run envelope 60 900 python tools/p2_envelope.py --size ${ESIZE:-1024} --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts ${ECOUNTS:-area} ;;
-    relaxed)   run relaxed 60 600 python tools/relaxed_experiment.py ;;
-    strips2)   run strips2 60 600 python tools/strips_shared_gpu.py ;;
     deep300)   run deep300 60 900 env SMX_DEEP=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k "300" ;;
     deep1000)  run deep1000 120 2400 env SMX_DEEP=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k "1000" ;;
-    rmse10k)   run rmse10k 120 2400 python tools/rmse_10k.py ;;
+    deep10k)   run deep10k 120 ${DEEPTO:-1500} env SMX_DEEP10K=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k ten_thousand -s ;;
     *)         note "unknown step $s" ;;
   esac
 done
