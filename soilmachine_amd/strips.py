@@ -188,8 +188,13 @@ class DeviceStripBackend:
         return int(n.value)
 
     def gen_end(self):
-        out = np.zeros(1 << 20, CHILD_DT); n = self.C.c_uint32()
-        self._chk(self.L.smx_d_gen_end(self.h, self.capi.ptr(out), len(out), self.C.byref(n)))
+        out = np.zeros(1 << 16, CHILD_DT); n = self.C.c_uint32()
+        rc = self.L.smx_d_gen_end(self.h, self.capi.ptr(out), len(out), self.C.byref(n))
+        if rc != 0:
+            if int(n.value) <= len(out):
+                self._chk(rc)
+            out = np.zeros(int(n.value), CHILD_DT)                # "buffer too small": *n says how many records wait (the call is repeatable)
+            self._chk(self.L.smx_d_gen_end(self.h, self.capi.ptr(out), len(out), self.C.byref(n)))
         return out[:int(n.value)].copy()
 
     def _pack(self, fn, x0, x1):

@@ -52,7 +52,8 @@ for s in "$@"; do
                run pmc_FETCH_SIZE 60 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_FETCH_SIZE -o p -- $PB
                run pmc_WRITE_SIZE 60 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_WRITE_SIZE -o p -- $PB
                run pmc_SQ 60 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM --output-format csv -d $out/pmc_SQ -o p -- $PB
-               python tools/make_pmc_json.py $out "4096/64000/16000/relaxed" "$PB" | tee $out/pmc.summary ;;
+               python tools/make_pmc_json.py $out "4096/64000/16000/relaxed" "$PB" | tee $out/pmc.summary
+               rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ ;;   # (raw per-dispatch CSVs: > 64 MiB, more than gpurun brings back)
     pmcwet)    i=0; for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM" \
                                   "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_BRANCH"; do
                  i=$((i+1))
