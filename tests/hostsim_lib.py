@@ -15,7 +15,7 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libhostsim.so")
 SRC = [os.path.join(HERE, "hostsim.cpp")] + [os.path.join(ROOT, "soilmachine_amd", "csrc", f)
-                                              for f in ("soil_core.h", "soil_serial.h", "soil_spec.h", "soil_coop.h", "soil_batch.h")]
+                                              for f in ("soil_core.h", "soil_serial.h", "soil_spec.h", "soil_coop.h", "soil_batch.h", "soil_relax.h")]
 _lib = None
 
 
