@@ -1816,6 +1816,7 @@ static int batch_grid(smx_ctx* ctx) {
   uint32_t nc = ctx->h_bctrl[BC_NCHILD];
   if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
   if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
+  if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
   if (nc > bs.child_cap) nc = bs.child_cap;
   std::vector<BChild> kids(nc);
   if (nc) HIPCHK(hipMemcpyAsync(kids.data(), bs.children, (size_t)nc * sizeof(BChild), hipMemcpyDeviceToHost, st));
