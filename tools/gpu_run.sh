@@ -63,6 +63,7 @@ for s in "$@"; do
                done ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
     envelope)  run envelope 60 900 python tools/p2_envelope.py --size ${ESIZE:-1024} --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts ${ECOUNTS:-area} ;;
+    envelope4096) run envelope4096 60 600 python tools/p2_envelope.py --size 4096 --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts file ;;
     deep300)   run deep300 60 900 env SMX_DEEP=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k "300" ;;
     deep1000)  run deep1000 120 2400 env SMX_DEEP=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k "1000" ;;
     deep10k)   run deep10k 120 ${DEEPTO:-1500} env SMX_DEEP10K=1 python -m pytest tests/test_gpu_depth.py -x -q -m gpu -k ten_thousand -s ;;
