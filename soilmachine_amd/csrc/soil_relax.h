@@ -106,59 +106,65 @@ SMX_D void relax_water_step(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
   const DevState& s = sim.s;
   const SoilP* soils = sim.soils;
   Water w = q.w;
-  Blk A;
-  sim.template load_block<0>(w.ix, w.iy, A);
-  Water t = w;
-  const bool mv = sim.template water_move<true>(t, false, A);                                   // water.h:43-73, no side effects
-  if (bs.strips.n > 1) {                                      // column strips: the step (3x3 around ipos and around the new position) must lie
-    const int nx = mv ? (int)roundf(t.pos.x) : w.ix, ny = mv ? (int)roundf(t.pos.y) : w.iy;   // inside what this kind of chunk may touch
-    const int x0 = (w.ix < nx ? w.ix : nx) - 1, x1 = (w.ix > nx ? w.ix : nx) + 1;
-    if (!beligible_x(s, bs, x0, x1)) { bs.rcount[slot] = 0u; return; }                         // dormant until the other kind of chunk
-    bmark_dirty_cells(s, bs, x0, x1, (w.iy < ny ? w.iy : ny) - 1, (w.iy > ny ? w.iy : ny) + 1);
-  }
-  (void)relax_append(&bs.ctrl[BC_NRUN + (epoch & 1u)], true);                                   // how many step in this epoch (relax_floods_due)
-  if (state == B_NEW) { t.contains = soils[Sim<P>::vsurf(A.v8)].transports; state = B_RUN; }   // WaterParticle(map) water.h:15-17 (move() ignores it)
-  RReq r;
-  r.cell = (uint32_t)A.c0; r.vol = w.volume; r.amount = 0.0; r.type = 0u; r.kind = R_TRACK; r.casc = NIL;   // water.h:53 track[ipos] += volume
-  w = t;
-  if (mv) {
-    q.c_steps++;
-    const View cv = A.v8;
-    const float fr = A.fr;
-    const int nx = (int)roundf(w.pos.x), ny = (int)roundf(w.pos.y);
-    Blk B;
-    sim.template load_block<2>(nx, ny, B);
-    // the arithmetic of WaterParticle::interact (water.h:75-121), statement by statement as in Sim::water_interact
-    const SoilP& param = soils[w.surface];
-    const double hb = sim.bilinear_blk(w.pos, nx, ny, B);
-    double c_eq = param.solubility * (Sim<P>::vh(cv) - hb) * (double)s.scale / 80.0;
-    if (c_eq < 0.0) c_eq = 0.0;
-    if (c_eq > 1.0) c_eq = 1.0;
-    if ((double)(soils[w.contains].erosionrate) < fr) w.contains = soils[w.contains].erodes;
-    const double cdiff = c_eq - w.sediment;
-    if (cdiff > 0) {
-      w.sediment += param.equrate * cdiff;
-      w.contains = soils[Sim<P>::vsurf(cv)].transports;
-      r.amount = param.equrate * cdiff * w.volume; r.kind |= R_ERODE;
-    } else if (cdiff < 0) {
-      w.sediment += soils[w.contains].equrate * cdiff;
-      r.amount = -soils[w.contains].equrate * cdiff * w.volume; r.type = w.contains; r.kind |= R_DEPOSIT;
+  uint32_t nent = 0;
+  const uint32_t base = (uint32_t)bs.rstride * slot;
+  const int nsteps = bs.rsteps < 1 ? 1 : bs.rsteps;         // steps per epoch (smx_set_relax_water; 1 = every step sees the previous one's edits applied)
+  for (int step = 0; step < nsteps && (state == B_RUN || state == B_NEW); step++) {
+    Blk A;
+    sim.template load_block<0>(w.ix, w.iy, A);
+    Water t = w;
+    const bool mv = sim.template water_move<true>(t, false, A);                                 // water.h:43-73, no side effects
+    if (bs.strips.n > 1) {                                    // column strips: the step (3x3 around ipos and around the new position) must lie
+      const int nx = mv ? (int)roundf(t.pos.x) : w.ix, ny = mv ? (int)roundf(t.pos.y) : w.iy; // inside what this kind of chunk may touch
+      const int x0 = (w.ix < nx ? w.ix : nx) - 1, x1 = (w.ix > nx ? w.ix : nx) + 1;
+      if (!beligible_x(s, bs, x0, x1)) break;                 // dormant until the other kind of chunk (this step has changed nothing yet)
+      bmark_dirty_cells(s, bs, x0, x1, (w.iy < ny ? w.iy : ny) - 1, (w.iy > ny ? w.iy : ny) + 1);
     }
-    r.casc = (uint32_t)B.c0;                                  // Particle::cascade(pos, .., 0) (:113)
-    w.sediment /= (1.0 - w.evaprate);
-    if (w.sediment > 1.0) w.sediment = 1.0;
-    w.volume *= (1.0 - w.evaprate);
-    w.ix = nx; w.iy = ny;
-    if (!(w.volume > 0.01)) state = B_ENDED;
-  } else state = B_ENDED;
+    if (step == 0) (void)relax_append(&bs.ctrl[BC_NRUN + (epoch & 1u)], true);                 // how many step in this epoch (relax_floods_due)
+    if (state == B_NEW) { t.contains = soils[Sim<P>::vsurf(A.v8)].transports; state = B_RUN; } // WaterParticle(map) water.h:15-17 (move() ignores it)
+    RReq r;
+    r.cell = (uint32_t)A.c0; r.vol = w.volume; r.amount = 0.0; r.type = 0u; r.kind = R_TRACK; r.casc = NIL;   // water.h:53 track[ipos] += volume
+    w = t;
+    if (mv) {
+      q.c_steps++;
+      const View cv = A.v8;
+      const float fr = A.fr;
+      const int nx = (int)roundf(w.pos.x), ny = (int)roundf(w.pos.y);
+      Blk B;
+      sim.template load_block<2>(nx, ny, B);
+      // the arithmetic of WaterParticle::interact (water.h:75-121), statement by statement as in Sim::water_interact
+      const SoilP& param = soils[w.surface];
+      const double hb = sim.bilinear_blk(w.pos, nx, ny, B);
+      double c_eq = param.solubility * (Sim<P>::vh(cv) - hb) * (double)s.scale / 80.0;
+      if (c_eq < 0.0) c_eq = 0.0;
+      if (c_eq > 1.0) c_eq = 1.0;
+      if ((double)(soils[w.contains].erosionrate) < fr) w.contains = soils[w.contains].erodes;
+      const double cdiff = c_eq - w.sediment;
+      if (cdiff > 0) {
+        w.sediment += param.equrate * cdiff;
+        w.contains = soils[Sim<P>::vsurf(cv)].transports;
+        r.amount = param.equrate * cdiff * w.volume; r.kind |= R_ERODE;
+      } else if (cdiff < 0) {
+        w.sediment += soils[w.contains].equrate * cdiff;
+        r.amount = -soils[w.contains].equrate * cdiff * w.volume; r.type = w.contains; r.kind |= R_DEPOSIT;
+      }
+      r.casc = (uint32_t)B.c0;                                // Particle::cascade(pos, .., 0) (:113)
+      w.sediment /= (1.0 - w.evaprate);
+      if (w.sediment > 1.0) w.sediment = 1.0;
+      w.volume *= (1.0 - w.evaprate);
+      w.ix = nx; w.iy = ny;
+      if (!(w.volume > 0.01)) state = B_ENDED;
+    } else state = B_ENDED;
+    relax_push(s, bs, base + nent, r, epoch);
+    nent++;
+  }
   if (state == B_ENDED) {                                     // flood() or nothing (water.h:125): behind claim tiles, from this epoch on
     q.rect = BRect{0, -1, 0, -1}; q.hint = 0;
     if (!water_floods(w)) state = B_DONE;
   }
   relax_flood_later(bs, slot, epoch & 1u, state == B_ENDED);
   q.w = w; q.state = state;
-  bs.rcount[slot] = 1u;
-  relax_push(s, bs, (uint32_t)bs.rstride * slot, r, epoch);
+  bs.rcount[slot] = nent;
 }
 
 // WindParticle (wind.h:54-136), the same way; up to bs.rsteps steps per epoch (a wind particle flies for thousands of steps and

@@ -907,6 +907,7 @@ struct smx_ctx {
   uint32_t relax_wind_min = 0xFFFFFFFFu;   // relaxed schedule: wind runs relaxed while more particles than this are running (default: never --
                                       // measured, profiles/r03_relaxed.md: the exclusive schedule's 8-32 steps per launch serve wind better)
   int relax_wind_steps = 4;           // ... taking up to this many steps per epoch (<= R_MAXSTEPS)
+  int relax_water_steps = 1;          // relaxed water: steps per epoch (1 = an edit is visible to everybody's next step)
   uint32_t relax_tag = 0;             // epoch tags of the cascade flags (unique over the context's life)
   uint32_t relax_cap = 0;             // slots the relaxed schedule's buffers are sized for
   int strips_n = 1, strips_a = 16, strips_b = 48;
@@ -1025,6 +1026,7 @@ static int create_range(const smx_config* cfg, int x_lo, int x_hi, smx_ctx** out
   if (smx_set_soils(ctx, &air, 1)) return -1;
   if (smx_srand(ctx, 1)) return -1;
   if (const char* e = getenv("SMX_RELAX_WIND_MIN")) ctx->relax_wind_min = (uint32_t)atoll(e);   // (experiments)
+  if (const char* e = getenv("SMX_RELAX_WATER_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= R_MAXSTEPS) ctx->relax_water_steps = v; }   // (experiment)
   if (const char* e = getenv("SMX_RELAX_WIND_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= R_MAXSTEPS) ctx->relax_wind_steps = v; }
   return 0;
 }
@@ -1670,7 +1672,7 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     static const bool use_tail = [] { const char* e = getenv("SMX_RELAX_TAIL"); return e ? atoi(e) != 0 : true; }();
     const bool tail = !wind && use_tail && nlive <= RELAX_TAIL;
     chunk_epochs = strips ? B_CHUNK : (tail ? 64 : (first ? CHUNK : RCHUNK_KIDS));
-    ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : 2; ctx->bs.rsteps = wind ? ctx->relax_wind_steps : 1;
+    ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : std::max(2, ctx->relax_water_steps); ctx->bs.rsteps = wind ? ctx->relax_wind_steps : ctx->relax_water_steps;
     if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(ctx->cflag_alloc, 0, ctx->lcells * 4, st)); }   // (tags never repeat)
     if (strips) HIPCHK(hipMemsetAsync(bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
     if (strips && !wind) {                                   // who waits for a flood on this device right now?
@@ -1684,7 +1686,7 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     } else {
       const uint32_t lpw = batch_lanes_per_wave(nlive);
       const unsigned nbl = (nlive + lpw - 1u) / lpw, nb64 = (nlive + 63u) / 64u;
-      const unsigned ncb = (unsigned)(((size_t)nlive * (size_t)(wind ? ctx->bs.rstride : 1) + 63u) / 64u);   // worst case of the flagged / one cascade list
+      const unsigned ncb = (unsigned)(((size_t)nlive * (size_t)(wind ? ctx->bs.rstride : ctx->bs.rsteps) + 63u) / 64u);   // worst case of the flagged / one cascade list
       const unsigned nfb = std::max(1024u, (unsigned)((nslots + 63u) / 64u));   // floods: at least 1024 wavefronts to spread over
       for (int k = 0; k < chunk_epochs; k++, epoch++) {
         ctx->bs.rtag = ++ctx->relax_tag;

@@ -351,6 +351,8 @@ static uint32_t g_relax_wind_min = 0xFFFFFFFFu;                   // wind: relax
 static int g_relax_wind_steps = 4;                          // ... taking up to this many steps per epoch (smx_set_relax_wind)
 static uint32_t g_relax_tag = 0;
 extern "C" void hs_set_relaxed(int on) { g_relaxed = on; }
+static int g_relax_water_steps = 1;                         // relaxed water: steps per epoch (smx_set_relax_water)
+extern "C" void hs_set_relax_water(int steps) { g_relax_water_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
 extern "C" void hs_set_relax_wind(uint32_t n, int steps) { g_relax_wind_min = n; g_relax_wind_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
 static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) {
   const DevState& s = c->d;
@@ -438,7 +440,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       int chunk_epochs = B_CHUNK;
       if (relaxed_now) {                                     // mirrors soilmx.hip: step, apply, nine cascade colours, floods
         chunk_epochs = strips ? B_CHUNK : (first ? B_CHUNK : 8);   // (with strips the chunk is the unit of the exchange: soilmx.hip run_chunk)
-        b.bs.rstride = wind ? 2 * g_relax_wind_steps : 2; b.bs.rsteps = wind ? g_relax_wind_steps : 1;
+        b.bs.rstride = wind ? 2 * g_relax_wind_steps : (g_relax_water_steps > 2 ? g_relax_water_steps : 2); b.bs.rsteps = wind ? g_relax_wind_steps : g_relax_water_steps;
         if (strips) for (uint32_t q = BC_NFLOOD; q < (uint32_t)BC_COUNT; q++) b.ctrl[q] = 0u;   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
         if (strips && !wind) {                                // k_relax_rebuild_floods
           for (uint32_t i = 0; i < nslots; i++) relax_flood_later(bs, i, epoch & 1u, b.water[i].state == B_ENDED);

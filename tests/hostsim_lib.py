@@ -55,6 +55,7 @@ def lib():
         L.hs_batch_stats.argtypes = [vp]
         L.hs_set_relaxed.argtypes = [C.c_int]
         L.hs_set_relax_wind.argtypes = [C.c_uint32, C.c_int]
+        L.hs_set_relax_water.argtypes = [C.c_int]
         L.hs_set_batch_strips.argtypes = [C.c_int] * 3
         L.hs_d_set_own.argtypes = [vp, C.c_int, C.c_int]
         L.hs_d_gen_begin.argtypes = [vp, C.c_int, C.c_uint32, vp, vp]
@@ -125,14 +126,14 @@ class HostSim:
         `shuffle` != 0 permutes the order in which the particles of a kernel are run (the result must not depend on it)."""
         self.L.hs_batched_tick(self.h, nwater, nwind, int(dowater), int(dowind), nthreads, shuffle)
 
-    def relaxed_tick(self, nwater, nwind, dowater=True, dowind=True, nthreads=1, shuffle=0, wind_min=0xFFFFFFFF, wind_steps=4):
+    def relaxed_tick(self, nwater, nwind, dowater=True, dowind=True, nthreads=1, shuffle=0, wind_min=0xFFFFFFFF, wind_steps=4, water_steps=1):
         """One tick of the RELAXED schedule (soil_relax.h) emulated on the host; wind runs relaxed (up to `wind_steps` steps per
         epoch) while more than `wind_min` particles are running (smx_set_relax_wind), then goes on under the exclusive schedule."""
-        self.L.hs_set_relaxed(1); self.L.hs_set_relax_wind(int(wind_min), int(wind_steps))
+        self.L.hs_set_relaxed(1); self.L.hs_set_relax_wind(int(wind_min), int(wind_steps)); self.L.hs_set_relax_water(int(water_steps))
         try:
             self.L.hs_batched_tick(self.h, nwater, nwind, int(dowater), int(dowind), nthreads, shuffle)
         finally:
-            self.L.hs_set_relaxed(0); self.L.hs_set_relax_wind(0xFFFFFFFF, 4)
+            self.L.hs_set_relaxed(0); self.L.hs_set_relax_wind(0xFFFFFFFF, 4); self.L.hs_set_relax_water(1)
 
     def batch_stats(self):
         st = np.zeros(8, np.uint32)

@@ -41,6 +41,7 @@ for s in "$@"; do
     tracew)    run tracew 30 300 env SMX_TRACE_BATCH=1 SMX_RELAX_WIND_MIN=${WMIN:-4096} SMX_RELAX_WIND_STEPS=${WSTEPS:-8} python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 3 ;;
     tracex)    run tracex 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 3 ;;
     headwaves) for w in ${WAVES_LIST:-512 1024}; do run headwaves_$w 30 300 env SMX_BATCH_WAVES=$w python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
+    headwsteps) for w in ${WSTEPS_LIST:-1 2}; do run headwsteps_$w 30 300 env SMX_RELAX_WATER_STEPS=$w python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
     headbatch) run headbatch 30 300 python bench.py --engine batched --no-lines --no-cpu-baseline --steps 3 --warmup 2 ;;
     tracerelax) run tracerelax 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 5 ;;
     stripstest) run stripstest 60 900 python -m pytest tests/test_gpu_strips.py -x -q -m gpu --durations=8 ;;
