@@ -810,6 +810,7 @@ struct so_ctx {
       b_children.clear();
       int grain = -1;
       uint32_t chunk = 0;
+      if (!wind && b_relaxed) { r_water_generation(sl); nlive = 0; }   // SMX_ENGINE_RELAXED: the water generations follow soil_relax.h
       while (nlive > 0) {
         int tshift;
         b_schedule(wind, nlive, b_base_dilate, tshift, dilate, maxsteps);
@@ -883,6 +884,143 @@ struct so_ctx {
       nslots = wind ? 0u : (uint32_t)kids.size();
     }
   }
+  // =====================================================================================================
+  // RELAXED SCHEDULE -- CPU restatement of soilmachine_amd/csrc/soil_relax.h (SMX_ENGINE_RELAXED), written from its
+  // definition, not from its code: one generation of water particles (wind keeps the exclusive schedule above; the
+  // grid pass is batched_grid(), whose nested particles come back here as generations). Per epoch:
+  //   step     every running particle, in any order, takes ONE step of the reference -- move() (water.h:43-73) and the
+  //            arithmetic of interact() (water.h:75-121) -- on the map as the epoch found it; what it would have written
+  //            (the visit of the track plane, the erosion or the deposit at the cell it leaves, the cascade at the cell
+  //            it arrives at) becomes a request;
+  //   apply    the requests, per cell in slot order (cells are independent, so: all of them in slot order), with the
+  //            reference's Layermap::remove / add;
+  //   cascade  every cell that was asked for, ONCE, if the engine's conservative pre-check (soil_core.h cascade_precheck:
+  //            some neighbour within 0.01 % of its slope limit) holds on the map after the edits -- colour by colour
+  //            (x mod 3, y mod 3), Particle::cascade(.., 0);
+  //   floods   particles that ended: behind 4x4-cell claim tiles without margin, lowest slot wins, a claim issued in one flood
+  //            epoch is good for the next epoch only; flood epochs are every fourth epoch and every epoch in which at least
+  //            a sixteenth as many particles wait as ran (relax_floods_due); nested particles -> children of this generation.
+  // =====================================================================================================
+  bool b_relaxed = false;
+  struct RReq { int x, y; double vol, amount; uint32_t type; int kind; int cx, cy; };   // kind 1: erode, 2: deposit
+  uint32_t r_surf(int x, int y) const { const uint32_t t = top[cidx(x, y)]; return t == NIL ? 0u : type[t]; }
+  bool r_precheck(int x, int y) const {
+    const double sc = (double)(float)SCALE, hC = height(x, y);
+    bool any = false;
+    for (const i2& nn : NEIGH) {
+      const int nx = x + nn.x, ny = y + nn.y;
+      if (nx >= dimx || ny >= dimy || nx < 0 || ny < 0) continue;
+      const double dh = hC - height(nx, ny);
+      const uint32_t ty = dh > 0 ? r_surf(x, y) : r_surf(nx, ny);
+      const double lim = (double)soils[ty].maxdiff * 0.9999;
+      if (!(std::fabs(dh) * sc * 0.0125 < lim)) any = true;
+    }
+    return any;
+  }
+  void r_water_generation(std::vector<BSlot>& sl) {
+    const uint32_t nslots = (uint32_t)sl.size();
+    B_TILE = 2;                                               // floods claim 4x4-cell tiles (b_schedule, water)
+    const int nty = b_nty();
+    std::vector<uint32_t> tilemin((size_t)b_ntx() * nty, 0xFFFFFFFFu), claim_for(nslots, 0xFFFFFFFFu), waiting;
+    std::vector<RReq> reqs;
+    std::vector<std::pair<int, int>> lists[9];
+    std::vector<uint32_t> stamp((size_t)dimx * dimy, 0u);     // epoch + 1 of the last cascade request of a cell
+    uint32_t epoch = 0;
+    auto running = [&] { for (const BSlot& q : sl) if (q.state != B_DONE) return true; return false; };
+    while (running()) {
+      // ---- step
+      reqs.clear();
+      uint32_t nrun = 0;
+      for (uint32_t i = 0; i < nslots; i++) {
+        BSlot& q = sl[i];
+        if (q.state != B_RUN && q.state != B_NEW) continue;
+        nrun++;
+        Water t = q.w;
+        const double vol0 = t.volume;
+        const bool mv = water_move(t, true);                  // sets t.ix/t.iy = the cell it starts from; no side effects
+        const int ix = t.ix, iy = t.iy;
+        if (q.state == B_NEW) { t.contains = soils[r_surf(ix, iy)].transports; q.state = B_RUN; }   // WaterParticle(map), water.h:15-17
+        RReq r{ix, iy, vol0, 0.0, 0u, 0, -1, -1};
+        if (mv) {
+          ctr.steps_water_all++; if (q.toplevel) ctr.steps_water_top++;
+          const int nx = (int)std::round(t.pos.x), ny = (int)std::round(t.pos.y);
+          double c_eq = t.param.solubility * (height(ix, iy) - height_bilinear(t.pos)) * (double)SCALE / 80.0;
+          if (c_eq < 0.0) c_eq = 0.0;
+          if (c_eq > 1.0) c_eq = 1.0;
+          if ((double)(soils[t.contains].erosionrate) < wfreq[fidx(ix, iy)]) t.contains = soils[t.contains].erodes;
+          const double cdiff = c_eq - t.sediment;
+          if (cdiff > 0) {
+            t.sediment += t.param.equrate * cdiff;
+            t.contains = soils[r_surf(ix, iy)].transports;
+            r.amount = t.param.equrate * cdiff * t.volume; r.kind = 1;
+          } else if (cdiff < 0) {
+            t.sediment += soils[t.contains].equrate * cdiff;
+            r.amount = -soils[t.contains].equrate * cdiff * t.volume; r.type = t.contains; r.kind = 2;
+          }
+          r.cx = nx; r.cy = ny;
+          t.sediment /= (1.0 - t.evaprate);
+          if (t.sediment > 1.0) t.sediment = 1.0;
+          t.volume *= (1.0 - t.evaprate);
+          t.ix = nx; t.iy = ny;
+          if (!(t.volume > minvol)) q.state = B_ENDED;
+        } else q.state = B_ENDED;
+        if (q.state == B_ENDED) {
+          q.rect = {0, -1, 0, -1};
+          if (!b_water_floods(t)) q.state = B_DONE; else waiting.push_back(i);
+        }
+        q.w = t;
+        reqs.push_back(r);
+      }
+      // ---- apply (slot order)
+      for (const RReq& r : reqs) {
+        const size_t fi = fidx(r.x, r.y);
+        wtrack[fi] = (float)((double)wtrack[fi] + r.vol);     // water.h:53,348-351
+        if (r.kind == 1) { double diff = remove(r.x, r.y, r.amount); while (std::fabs(diff) > 1E-8) diff = remove(r.x, r.y, diff); }
+        else if (r.kind == 2) add(r.x, r.y, get(r.amount, r.type));
+      }
+      // ---- which requested cells can cascade at all? (on the map after the edits, before any cascade)
+      for (auto& l : lists) l.clear();
+      for (const RReq& r : reqs) {
+        if (r.cx < 0) continue;
+        uint32_t& st = stamp[cidx(r.cx, r.cy)];
+        if (st == epoch + 1u) continue;                       // once per cell and epoch
+        st = epoch + 1u;
+        if (r_precheck(r.cx, r.cy)) lists[(r.cx % 3) * 3 + (r.cy % 3)].push_back({r.cx, r.cy});
+        else ctr.cascade_calls++;                             // (the engine counts the dismissed cell as a call, as Particle::cascade would be)
+      }
+      for (auto& l : lists)
+        for (const auto& c : l) particle_cascade(f2{(float)c.first, (float)c.second}, 0);
+      // ---- floods
+      const uint32_t nflood = (uint32_t)waiting.size();
+      if ((epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun) {
+        std::vector<uint32_t> cand, win, rest;
+        for (uint32_t i : waiting) if (claim_for[i] == epoch) cand.push_back(i);
+        for (uint32_t i : cand) { const BRect& r = sl[i].rect; for (int tx = r.tx0; tx <= r.tx1; tx++) for (int ty = r.ty0; ty <= r.ty1; ty++) { uint32_t& m = tilemin[(size_t)tx * nty + ty]; if (i < m) m = i; } }
+        std::vector<char> won(nslots, 0);
+        for (uint32_t i : cand) {
+          const BRect& r = sl[i].rect; bool ok = true;
+          for (int tx = r.tx0; tx <= r.tx1 && ok; tx++) for (int ty = r.ty0; ty <= r.ty1; ty++) if (tilemin[(size_t)tx * nty + ty] != i) { ok = false; break; }
+          if (ok) { won[i] = 1; win.push_back(i); }
+        }
+        for (uint32_t i : cand) { const BRect& r = sl[i].rect; for (int tx = r.tx0; tx <= r.tx1; tx++) for (int ty = r.ty0; ty <= r.ty1; ty++) tilemin[(size_t)tx * nty + ty] = 0xFFFFFFFFu; }
+        std::sort(win.begin(), win.end());
+        for (uint32_t i : win) {                              // winners own disjoint tiles: any order
+          BSlot& q = sl[i];
+          const BRect held = q.rect;
+          b_guard = &held; b_ctx = "relaxed-flood";
+          b_defer = true; b_parent = i; b_seq = 0;
+          water_flood(q.w);
+          b_defer = false; b_guard = nullptr;
+          q.state = B_DONE; q.rect = {0, -1, 0, -1};
+        }
+        for (uint32_t i : waiting) if (!won[i]) { sl[i].rect = b_water_need_flood(sl[i].w); claim_for[i] = epoch + 1u; rest.push_back(i); }
+        waiting.swap(rest);
+      }
+      epoch++;
+    }
+    b_epochs += epoch;
+  }
+
   void batched_grid() {
     const size_t n = (size_t)dimx * dimy;
     std::vector<char> act(n, 0);                              // fixed at the start of the pass (soilmx.hip k_grid_classify)
@@ -1093,6 +1231,7 @@ void so_batched_tick(so_ctx* c, int nwater, int nwind, int dowater, int dowind) 
   if (dowind) so_batched_wind(c, nwind);
   if (dowater) { c->map_frequency(); c->reset_frequency(); }
 }
+void so_set_relaxed(so_ctx* c, int on) { c->b_relaxed = on != 0; }   // water generations of so_batched_* follow the relaxed schedule
 void so_batched_set_dilate(so_ctx* c, int tiles) { c->b_base_dilate = tiles < 0 ? 0 : tiles; }
 void so_batched_set_cell_above(so_ctx* c, uint32_t n) { c->b_cell_above = n; }
 void so_batched_set_strips(so_ctx* c, int n, int a, int b) { c->bs_n = n < 1 ? 1 : n; c->bs_a = a; c->bs_b = b; }

@@ -69,6 +69,8 @@ double so_remove(so_ctx*, int x, int y, double h);
 void so_particle_cascade(so_ctx*, float px, float py, int transferloop);
 void so_water_cascade(so_ctx*, int x, int y, int spill);
 void so_seep(so_ctx*, int x, int y);
+// so_set_relaxed(1): the water generations of so_batched_* follow the RELAXED schedule (soilmachine_amd/csrc/soil_relax.h) restated from
+// its definition (soil_oracle.cpp r_water_generation) -- checker of SMX_ENGINE_RELAXED, bit-exact.
 // The BATCHED schedule (throughput engine, soilmachine_amd/csrc/soil_batch.h) restated on the CPU: same per-step
 // functions, the engine's own definition of who acts when. Checker for the batched HIP path (bit-exact); NOT a model of
 // the reference's particle order. stats: {epochs, generations, cells touched outside the acting particle's tiles (must be 0)}
@@ -76,6 +78,7 @@ void so_batched_water(so_ctx*, int n);
 void so_batched_grid(so_ctx*);
 void so_batched_wind(so_ctx*, int n);
 void so_batched_tick(so_ctx*, int nwater, int nwind, int dowater, int dowind);
+void so_set_relaxed(so_ctx*, int on);   // SMX_ENGINE_RELAXED restated (csrc/soil_relax.h): water generations step / apply / cascade colours / floods per epoch
 void so_batched_set_dilate(so_ctx*, int tiles);
 void so_batched_set_cell_above(so_ctx*, uint32_t nlive);   // schedule knob: per-cell reservations while more particles run
 void so_batched_set_strips(so_ctx*, int nstrips, int inset, int seam_halfwidth);   // column-strip schedule (INTERIOR / SEAM chunks)

@@ -233,7 +233,8 @@ class Layermap {
     }
     cfg.dimx = _dim.x; cfg.dimy = _dim.y; cfg.scale = SCALE; cfg.device = 0; cfg.pool_capacity = cap;
     const char* e = getenv("SMX_ENGINE");
-    cfg.engine = (e && std::string(e) == "serial") ? SMX_ENGINE_SERIAL : (e && std::string(e) == "batched") ? SMX_ENGINE_BATCHED : SMX_ENGINE_SPECULATIVE;
+    cfg.engine = (e && std::string(e) == "serial") ? SMX_ENGINE_SERIAL : (e && std::string(e) == "batched") ? SMX_ENGINE_BATCHED
+               : (e && std::string(e) == "relaxed") ? SMX_ENGINE_RELAXED : SMX_ENGINE_SPECULATIVE;
     cfg.reserved = 0;
     int rc = smx_create(&cfg, &ctx);
     if (rc != 0) { cout << "soilmx: smx_create failed: " << (ctx ? smx_last_error(ctx) : "") << endl; exit(1); }

@@ -83,6 +83,7 @@ def lib():
             getattr(L, f).argtypes = [vp, C.c_int]
         L.so_batched_grid.argtypes = [vp]
         L.so_batched_set_dilate.argtypes = [vp, C.c_int]
+        L.so_set_relaxed.argtypes = [vp, C.c_int]
         L.so_batched_stats.argtypes = [vp, vp]
         L.so_noise_fbm.argtypes = [C.c_float] * 3 + [C.c_int] + [C.c_float] * 3
         L.so_noise_fbm.restype = C.c_float
@@ -153,6 +154,14 @@ class Oracle:
     # ---- the BATCHED schedule restated (checker of the batched HIP engine; see oracle/soil_oracle.h)
     def batched_tick(self, nwater: int, nwind: int, dowater: bool = True, dowind: bool = True):
         self.L.so_batched_tick(self.h, nwater, nwind, int(dowater), int(dowind))
+
+    def relaxed_tick(self, nwater: int, nwind: int, dowater: bool = True, dowind: bool = True):
+        """one tick of the RELAXED schedule restated (oracle/soil_oracle.cpp r_water_generation; wind and grid pass as in the batched one)"""
+        self.L.so_set_relaxed(self.h, 1)
+        try:
+            self.L.so_batched_tick(self.h, nwater, nwind, int(dowater), int(dowind))
+        finally:
+            self.L.so_set_relaxed(self.h, 0)
 
     def batched_set_dilate(self, tiles: int):
         self.L.so_batched_set_dilate(self.h, int(tiles))

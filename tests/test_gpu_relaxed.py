@@ -6,10 +6,11 @@ import pytest
 
 from common import golden_snapshot, load_cfg
 from hostsim_lib import HostSim
+from oracle_lib import Oracle
 from soilmachine_amd import capi
 from soilmachine_amd.machine import Layermap, SoilMachine
 from soilmachine_amd.snapshot import compare
-from test_relaxed import CASES, column_invariants
+from test_relaxed import CASES, RESTATED, RKEYS, column_invariants
 
 pytestmark = pytest.mark.gpu
 KEYS = ["steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls", "cascade_transfers",
@@ -42,6 +43,24 @@ def test_device_equals_host_threads(soil, case, t0, nw, nd, wind, ticks, wmin, w
     cd, ch = sm.map.counters(), h.counters()
     assert {k: cd[k] for k in KEYS} == {k: ch[k] for k in KEYS}
     assert sm.map.batch_stats()["children_lost"] == 0
+
+
+@pytest.mark.parametrize("soil,case,t0,nw,nd,wind,ticks", RESTATED)
+def test_device_equals_the_independent_restatement(soil, case, t0, nw, nd, wind, ticks):
+    """the relaxed engine through the C-ABI against oracle/soil_oracle.cpp r_water_generation (the schedule restated from its
+    definition with the oracle's own step functions): full state every tick, counters at the end"""
+    cfg = load_cfg(soil)
+    g = golden_snapshot(case, t0)
+    sm = machine(cfg, g.dimx, g.dimy, nw, nd, wind, capi.ENGINE_RELAXED, snap=g)
+    o = Oracle(cfg, g.dimx, g.dimy, seed=0); o.load(g)
+    for t in range(ticks):
+        sm.tick(1, sync=True)
+        o.relaxed_tick(nw, nd, True, wind)
+        bad = compare(sm.map.snapshot(), o.snapshot())
+        assert not bad, f"{case} tick {t}: {bad}"
+    cd, co = sm.map.counters(), o.counters()
+    assert {k: cd[k] for k in RKEYS} == {k: co[k] for k in RKEYS}
+    assert o.batched_stats()["guard_violations"] == 0
 
 
 def test_1024_coupled_structure_and_envelope_against_the_exact_engine():

@@ -4,14 +4,14 @@ headers compiled for the host, tests/hostsim) next to the oracle, check exactnes
 [rounds, aborts, kills, fell_back, executions, critical-path steps] -- the last one (sum over rounds of the longest
 advance of any particle) is the proxy for the phase's GPU time (x the per-step latency, + rounds x the per-round overhead).
 
-  tools/dbg/hostsim_proxy.py --size 4096 --ticks 3                       # the bench workload
-  tools/dbg/hostsim_proxy.py --size 256 --ticks 8 --boundary-threads 7   # dense lake regime, boundary as a team
-  tools/dbg/hostsim_proxy.py --size 1024 --nwater 6000 --nwind 0         # more particles than the boundary window
-  tools/dbg/hostsim_proxy.py --deps --size 4096 --nwater 4000            # oracle dependency analysis (DAG depth, critical path)
+  tools/hostsim_proxy.py --size 4096 --ticks 3                       # the bench workload
+  tools/hostsim_proxy.py --size 256 --ticks 8 --boundary-threads 7   # dense lake regime, boundary as a team
+  tools/hostsim_proxy.py --size 1024 --nwater 6000 --nwind 0         # more particles than the boundary window
+  tools/hostsim_proxy.py --deps --size 4096 --nwater 4000            # oracle dependency analysis (DAG depth, critical path)
 Engine modes: bit0 blocked-particle filter, bit1 suspend/resume, bit2 wave-loop structure of soil_coop.h.
 """
 import argparse, ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from common import load_cfg                                    # noqa: E402
 from hostsim_lib import HostSim                                # noqa: E402
