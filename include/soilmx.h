@@ -131,7 +131,11 @@ int smx_read_surface(smx_ctx* ctx, uint32_t* out);      /* Layermap::surface(ive
 /* ---- checkpoint / resume on disk (the reference has none: SURVEY.md 5; io.h:232 "Should be able to also WRITE to file").
  * File = the snapshot layout of soilmachine_amd/snapshot.py (64-byte header "SMXSNAP1", per-cell section counts, sections
  * bottom -> top, the three frequency planes) followed by a trailer "SMXRAND1" with the rand() generator's 31-word ring, its
- * index and the number of draws -- a loaded context continues the libc stream exactly where the saved one stopped. ---- */
+ * index and the number of draws -- a loaded context continues the libc stream exactly where the saved one stopped.
+ * The exact engines continue bit-identically. The throughput engines (BATCHED / RELAXED) fix the active set of their grid pass at
+ * its start from a per-column "has held a saturation" bit that is context state, not part of the file (import and load re-derive
+ * it from the saturations present): a throughput run resumed from a file is a valid result of the schedule, but it can differ from
+ * the uninterrupted run in columns whose saturation had returned to zero. ---- */
 int smx_save(smx_ctx* ctx, const char* path);
 int smx_load(smx_ctx* ctx, const char* path);           /* dims must match the context; SCALE and soils are the caller's */
 
