@@ -249,7 +249,7 @@ template <class F> static void parallel_for(uint32_t n, int nthreads, F f, unsig
   std::vector<uint32_t> order(n);
   for (uint32_t i = 0; i < n; i++) order[i] = i;
   if (shuffle_seed) { std::mt19937 g(shuffle_seed); std::shuffle(order.begin(), order.end(), g); }
-  if (nthreads <= 1) { for (uint32_t i : order) f(i); return; }
+  if (nthreads <= 1 || n < 4u * (uint32_t)nthreads) { for (uint32_t i : order) f(i); return; }   // (a handful of items: not worth the threads -- the shuffle still varies the order)
   std::vector<std::thread> th;
   for (int t = 0; t < nthreads; t++)
     th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nthreads) f(order[i]); });
