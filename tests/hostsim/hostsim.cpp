@@ -21,7 +21,12 @@
 #include "../../soilmachine_amd/csrc/soil_batch.h"
 #include "../../soilmachine_amd/csrc/soil_relax.h"
 #include <pthread.h>
+#include <atomic>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <sched.h>
 #include <algorithm>
 #include <random>
 #include <map>
@@ -245,15 +250,52 @@ static void spec_setup(hs_ctx* c, SpecBuffers& b, uint32_t nparticles) {
   sh.scout_cells = b.scout_cells_raw; sh.scout_len = b.scout_len.data();
   b.ckpt.resize(n); sh.ckpt = b.ckpt.data(); sh.mode = 2u;
 }
+// The workers of one calling thread (a "kernel launch" = one job for every worker): kept alive between launches -- a tick is
+// thousands of launches, and creating the threads anew each time was most of the suite's system time. thread_local: ranks that run
+// as threads of one process (loop-back strips) each have their own workers.
+struct WorkerPool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_start, cv_done;
+  const std::function<void(int)>* job = nullptr;
+  uint64_t gen = 0;
+  int active = 0, pending = 0;
+  bool stop = false;
+  void worker(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* j;
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv_start.wait(l, [&] { return stop || (gen != seen && t < active); });
+        if (stop) return;
+        seen = gen; j = job;
+      }
+      (*j)(t);
+      { std::lock_guard<std::mutex> l(m); if (--pending == 0) cv_done.notify_one(); }
+    }
+  }
+  void run(int n, const std::function<void(int)>& f) {
+    std::unique_lock<std::mutex> l(m);
+    while ((int)th.size() < n) { const int t = (int)th.size(); th.emplace_back([this, t] { worker(t); }); }
+    job = &f; active = n; pending = n; gen++;
+    cv_start.notify_all();
+    cv_done.wait(l, [&] { return pending == 0; });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> l(m); stop = true; }
+    cv_start.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
 template <class F> static void parallel_for(uint32_t n, int nthreads, F f, unsigned shuffle_seed) {
   std::vector<uint32_t> order(n);
   for (uint32_t i = 0; i < n; i++) order[i] = i;
   if (shuffle_seed) { std::mt19937 g(shuffle_seed); std::shuffle(order.begin(), order.end(), g); }
   if (nthreads <= 1 || n < 4u * (uint32_t)nthreads) { for (uint32_t i : order) f(i); return; }   // (a handful of items: not worth the threads -- the shuffle still varies the order)
-  std::vector<std::thread> th;
-  for (int t = 0; t < nthreads; t++)
-    th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nthreads) f(order[i]); });
-  for (auto& t : th) t.join();
+  static thread_local WorkerPool pool;
+  const std::function<void(int)> job = [&](int t) { for (uint32_t i = (uint32_t)t; i < n; i += (uint32_t)nthreads) f(order[i]); };
+  pool.run(nthreads, job);
 }
 static int g_boundary_threads = 1;
 extern "C" void hs_set_boundary_threads(int n) { g_boundary_threads = n < 1 ? 1 : n; }
@@ -285,12 +327,20 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
       const int bt = g_boundary_threads;                     // >1: the boundary runs as a TEAM (threads + barrier), as on the device
       if (bt <= 1) spec_boundary_team(s, sh, *w, 0u, 1u, []() {});
       else {
-        pthread_barrier_t bar; pthread_barrier_init(&bar, nullptr, (unsigned)bt);
+        // a team of threads with a barrier between the stages of the boundary, as on the device. The stages are tiny: a spinning
+        // barrier (yielding when the machine is oversubscribed) instead of pthread_barrier's futex sleep per stage
+        struct SpinBarrier {
+          std::atomic<int> count{0}, gen{0}; int n;
+          void wait() {
+            const int g = gen.load(std::memory_order_acquire);
+            if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { count.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release); }
+            else { int spins = 0; while (gen.load(std::memory_order_acquire) == g) if (++spins > 4000) sched_yield(); }
+          }
+        } bar; bar.n = bt;
         std::vector<std::thread> th;
         for (int t = 0; t < bt; t++)
-          th.emplace_back([&, t]() { spec_boundary_team(s, sh, *w, (uint32_t)t, (uint32_t)bt, [&]() { pthread_barrier_wait(&bar); }); });
+          th.emplace_back([&, t]() { spec_boundary_team(s, sh, *w, (uint32_t)t, (uint32_t)bt, [&]() { bar.wait(); }); });
         for (auto& t : th) t.join();
-        pthread_barrier_destroy(&bar);
       }
     }
     if (sh.ctrl[SC_TOP] == n) break;
