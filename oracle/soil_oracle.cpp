@@ -729,7 +729,11 @@ struct so_ctx {
   bool b_eligible(const BRect& r) const {
     if (bs_n <= 1) return true;
     if (r.empty()) return false;
-    const int cx0 = r.tx0 << B_TILE, cx1 = std::min(((r.tx1 + 1) << B_TILE) - 1, dimx - 1);
+    return b_eligible_x(r.tx0 << B_TILE, std::min(((r.tx1 + 1) << B_TILE) - 1, dimx - 1));
+  }
+  bool b_eligible_x(int cx0, int cx1) const {               // may an action that touches the columns cx0 .. cx1 run in this kind of chunk?
+    if (bs_n <= 1) return true;
+    cx0 = std::max(cx0, 0); cx1 = std::min(cx1, dimx - 1);
     if (bs_phase == 0) {
       for (int g = 0; g < bs_n; g++) { const int lo = bs_x(g) + (g ? bs_a : 0), hi = bs_x(g + 1) - (g < bs_n - 1 ? bs_a : 0); if (cx0 >= lo && cx1 < hi) return true; }
     } else {
@@ -900,6 +904,9 @@ struct so_ctx {
   //   floods   particles that ended: behind 4x4-cell claim tiles without margin, lowest slot wins, a claim issued in one flood
   //            epoch is good for the next epoch only; flood epochs are every fourth epoch and every epoch in which at least
   //            a sixteenth as many particles wait as ran (relax_floods_due); nested particles -> children of this generation.
+  //   strips   (so_batched_set_strips) INTERIOR / SEAM chunks of 32 epochs: a particle steps iff the columns its step touches are eligible
+  //            in the running kind of chunk, a flood reservation is issued iff eligible, every chunk starts with fresh reservations of
+  //            the waiting particles, every epoch is a flood epoch (the rule above counts one device's particles: not partition-invariant).
   // =====================================================================================================
   bool b_relaxed = false;
   struct RReq { int x, y; double vol, amount; uint32_t type; int kind; int cx, cy; };   // kind 1: erode, 2: deposit
@@ -925,9 +932,24 @@ struct so_ctx {
     std::vector<RReq> reqs;
     std::vector<std::pair<int, int>> lists[9];
     std::vector<uint32_t> stamp((size_t)dimx * dimy, 0u);     // epoch + 1 of the last cascade request of a cell
-    uint32_t epoch = 0;
+    uint32_t epoch = 0, chunk = 0;
     auto running = [&] { for (const BSlot& q : sl) if (q.state != B_DONE) return true; return false; };
     while (running()) {
+     // column strips: INTERIOR and SEAM chunks of 32 epochs alternate; an epoch number is skipped between two chunks, and every chunk
+     // starts with fresh reservations of the particles that wait for their flood (without strips chunking has no meaning: one epoch per turn)
+     bs_phase = bs_n > 1 ? (int)(chunk & 1u) : 0;
+     if (bs_n > 1 && chunk > 0) epoch++;
+     chunk++;
+     if (bs_n > 1) {
+       waiting.clear();
+       for (uint32_t i = 0; i < nslots; i++) {
+         if (sl[i].state != B_ENDED) continue;
+         sl[i].rect = b_water_need_flood(sl[i].w);
+         claim_for[i] = b_eligible(sl[i].rect) ? epoch : 0xFFFFFFFFu;
+         waiting.push_back(i);
+       }
+     }
+     for (int k = 0; k < (bs_n > 1 ? B_CHUNK : 1); k++) {
       // ---- step
       reqs.clear();
       uint32_t nrun = 0;
@@ -939,6 +961,10 @@ struct so_ctx {
         const double vol0 = t.volume;
         const bool mv = water_move(t, true);                  // sets t.ix/t.iy = the cell it starts from; no side effects
         const int ix = t.ix, iy = t.iy;
+        if (bs_n > 1) {                                       // the step must lie inside what this kind of chunk may touch: dormant otherwise
+          const int ex = mv ? (int)std::round(t.pos.x) : ix;
+          if (!b_eligible_x(std::min(ix, ex) - 1, std::max(ix, ex) + 1)) { nrun--; continue; }
+        }
         if (q.state == B_NEW) { t.contains = soils[r_surf(ix, iy)].transports; q.state = B_RUN; }   // WaterParticle(map), water.h:15-17
         RReq r{ix, iy, vol0, 0.0, 0u, 0, -1, -1};
         if (mv) {
@@ -992,7 +1018,7 @@ struct so_ctx {
         for (const auto& c : l) particle_cascade(f2{(float)c.first, (float)c.second}, 0);
       // ---- floods
       const uint32_t nflood = (uint32_t)waiting.size();
-      if ((epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun) {
+      if (bs_n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun) {   // (strips: every epoch)
         std::vector<uint32_t> cand, win, rest;
         for (uint32_t i : waiting) if (claim_for[i] == epoch) cand.push_back(i);
         for (uint32_t i : cand) { const BRect& r = sl[i].rect; for (int tx = r.tx0; tx <= r.tx1; tx++) for (int ty = r.ty0; ty <= r.ty1; ty++) { uint32_t& m = tilemin[(size_t)tx * nty + ty]; if (i < m) m = i; } }
@@ -1013,10 +1039,11 @@ struct so_ctx {
           b_defer = false; b_guard = nullptr;
           q.state = B_DONE; q.rect = {0, -1, 0, -1};
         }
-        for (uint32_t i : waiting) if (!won[i]) { sl[i].rect = b_water_need_flood(sl[i].w); claim_for[i] = epoch + 1u; rest.push_back(i); }
+        for (uint32_t i : waiting) if (!won[i]) { sl[i].rect = b_water_need_flood(sl[i].w); claim_for[i] = b_eligible(sl[i].rect) ? epoch + 1u : 0xFFFFFFFFu; rest.push_back(i); }
         waiting.swap(rest);
       }
       epoch++;
+     }
     }
     b_epochs += epoch;
   }

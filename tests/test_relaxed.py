@@ -104,6 +104,36 @@ def test_forty_ticks_into_the_lakes_equal_the_independent_restatement():
     assert h.counters()["floods"] == c["floods"]
 
 
+@pytest.mark.parametrize("soil,dx,dy,strips,nw,nd,ticks,warm", [("rockgravelpebblessand.soil", 256, 64, 2, 300, 100, 2, 0),
+                                                                 ("default.soil", 256, 64, 2, 250, 0, 3, 30), ("rocksand.soil", 512, 32, 4, 300, 150, 2, 0)])
+def test_relaxed_schedule_under_column_strips_equals_the_restatement(soil, dx, dy, strips, nw, nd, ticks, warm):
+    """what `bench.py --gpus N` runs by default -- the relaxed schedule in INTERIOR / SEAM chunks -- against its restatement in the
+    oracle (eligibility of every step and every flood reservation, fresh reservations per chunk, floods every epoch): full state
+    every tick; `warm` ticks of the reference first give the second case standing water (~1500 floods)."""
+    import ctypes as C
+    from hostsim_lib import lib
+    cfg = load_cfg(soil)
+    o = Oracle(cfg, dx, dy, seed=3); o.initialize()
+    for _ in range(warm):
+        o.tick(250, 0, True, False)
+    s0 = o.snapshot()
+    o = Oracle(cfg, dx, dy, seed=3); o.load(s0)                   # (both sides derive the sticky saturation bits from the snapshot)
+    h = HostSim(cfg, dx, dy, seed=3); h.load(s0, advance_rand=True)
+    L = lib(); L.hs_set_batch_strips.argtypes = [C.c_int] * 3
+    o.L.so_batched_set_strips.argtypes = [C.c_void_p] + [C.c_int] * 3
+    L.hs_set_batch_strips(strips, 16, 48); o.L.so_batched_set_strips(o.h, strips, 16, 48)
+    try:
+        for t in range(ticks):
+            h.relaxed_tick(nw, nd, True, nd > 0, nthreads=4, shuffle=t + 1)
+            o.relaxed_tick(nw, nd, True, nd > 0)
+            assert not compare(h.snapshot(), o.snapshot()), t
+    finally:
+        L.hs_set_batch_strips(1, 16, 48)
+    assert o.batched_stats()["guard_violations"] == 0
+    if warm:
+        assert h.counters()["floods"] > 1000
+
+
 def test_several_water_steps_per_epoch_stay_deterministic_and_sound():
     """The step function takes up to bs.rsteps water steps per epoch on the epoch's start state (SMX_RELAX_WATER_STEPS: measured
     +9 % and not adopted, profiles/r03_relaxed.md; the default is one step). The knob keeps the schedule's properties: the result

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Randomised differential run of the RELAXED schedule: device sources on host threads (tests/hostsim) against the independent
-restatement (oracle/soil_oracle.cpp r_water_generation) over random map shapes, soils, counts, tick counts, starting either from the
+restatement (oracle/soil_oracle.cpp r_water_generation) over random map shapes, soils, counts, tick counts, 1-3 column strips, starting either from the
 initial terrain or from a map that already carries lakes. usage: fuzz_relaxed.py SEED SECONDS"""
 import sys, time, random
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 from common import load_cfg
-from hostsim_lib import HostSim
-from oracle_lib import Oracle
+import ctypes
+from hostsim_lib import HostSim, lib
+from oracle_lib import Oracle, lib as olib
+L = lib(); L.hs_set_batch_strips.argtypes = [ctypes.c_int] * 3
+olib().so_batched_set_strips.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
 from soilmachine_amd.snapshot import compare
 soils = ["default.soil", "rockgravelpebblessand.soil", "painted.soil", "rocksand.soil", "sand.soil", "bigbutte.soil"]
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
@@ -15,7 +18,9 @@ KEYS = ["steps_water_top", "steps_water_all", "steps_wind", "nested_particles", 
 n = floods = 0
 while time.time() < t_end:
     soil = rng.choice(soils); cfg = load_cfg(soil)
-    dx = rng.choice([5, 17, 33, 48, 64, 80, 97, 130]); dy = rng.choice([4, 19, 32, 50, 64, 96])
+    dx = rng.choice([5, 17, 33, 48, 64, 80, 97, 130, 224, 260, 352]); dy = rng.choice([4, 19, 32, 50, 64, 96])
+    strips = rng.choice([1, 2, 3]) if dx >= 224 else 1
+    if strips > 1 and dx // strips < 2 * 48 + 16: strips = 1
     seed = rng.randrange(1000); nw = rng.choice([1, 7, 60, 250, 600]); nd = rng.choice([0, 0, 5, 40])
     ticks = rng.choice([1, 2, 4, 8]); wet = rng.random() < 0.4
     o = Oracle(cfg, dx, dy, seed=seed); o.initialize()
@@ -26,12 +31,14 @@ while time.time() < t_end:
         o = Oracle(cfg, dx, dy, seed=seed); o.load(s0)        # and the fixed active set of the 9-colour grid pass depends on it
     h = HostSim(cfg, dx, dy, seed=seed); h.load(o.snapshot(), advance_rand=True)
     c0 = o.counters()
-    desc = (soil, dx, dy, seed, nw, nd, ticks, wet)
+    desc = (soil, dx, dy, seed, nw, nd, ticks, wet, strips)
+    L.hs_set_batch_strips(strips, 16, 48); o.L.so_batched_set_strips(o.h, strips, 16, 48)
     for t in range(ticks):
         h.relaxed_tick(nw, nd, True, nd > 0, nthreads=rng.choice([1, 3, 5]), shuffle=rng.randrange(5))
         o.relaxed_tick(nw, nd, True, nd > 0)
         bad = compare(h.snapshot(), o.snapshot())
         if bad: print("MISMATCH", desc, t, bad[:3]); sys.exit(1)
+    L.hs_set_batch_strips(1, 16, 48)
     ch, co = h.counters(), o.counters()
     co = {k: co[k] - (c0[k] if k != 'rand_calls' else 0) for k in KEYS}
     if any(ch[k] != co[k] for k in KEYS): print("COUNTERS", desc, {k: (ch[k], co[k]) for k in KEYS if ch[k] != co[k]}); sys.exit(1)
