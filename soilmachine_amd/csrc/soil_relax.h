@@ -72,7 +72,15 @@ SMX_D void relax_flood_later(const BatchShared& bs, uint32_t slot, uint32_t pari
 // early wait for every fourth epoch. Once the ended ones are a sixteenth of the runners (or nobody runs), every epoch floods.
 // A function of the epoch's own counts: not of chunking, not of how the host drives the epochs.
 // (Under column strips the counts are one device's share, so every epoch floods there: the result must not depend on the partition.)
+#ifdef SMX_HOSTSIM
+static int g_hs_flood_rule = 0;                               // (host-side experiments only, tools/p2_statistics.py: 0 = the schedule's rule)
+#endif
 SMX_D bool relax_floods_due(const BatchShared& bs, uint32_t epoch, uint32_t nflood, uint32_t nrun) {
+#ifdef SMX_HOSTSIM
+  if (g_hs_flood_rule == 1) return true;                                                                               // every epoch
+  if (g_hs_flood_rule == 2) return bs.strips.n > 1 || (epoch & 1u) == 1u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun;
+  if (g_hs_flood_rule == 3) return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 64ull >= (unsigned long long)nrun;
+#endif
   return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun;
 }
 // after the epoch's edits are applied: which flagged cells can move anything at all? (Particle::cascade starts with the same
