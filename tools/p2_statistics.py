@@ -3,7 +3,7 @@
 the device headers run by host threads (tests/hostsim: bit-identical to the device) against the reference-order oracle from the
 same terrain and rand() stream, next to the reference-order oracle with two other rand() streams. One markdown row pair per soil.
   p2_statistics.py relaxed|batched [case ...]     (profiles/r02_p2_statistics.md: batched; profiles/r03_p2_statistics_relaxed.md: relaxed)"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 from common import load_cfg
@@ -13,6 +13,13 @@ CASES = {"rgps": ("rockgravelpebblessand.soil", 40, 250, 250), "rocksand": ("roc
          "sand": ("sand.soil", 40, 250, 250), "rgpbig": ("rockgravelpebbles_big.soil", 20, 1000, 0), "default_wet": ("default.soil", 150, 250, 0)}
 engine = sys.argv[1] if len(sys.argv) > 1 else "relaxed"
 names = sys.argv[2:] or list(CASES)
+if os.environ.get("HS_FLOOD_RULE"):                         # experiments with the flood-epoch rule (profiles/r03_flood_rule_cpu.md); 0 = the schedule's
+    import ctypes
+    from hostsim_lib import lib
+    lib().hs_set_flood_rule.argtypes = [ctypes.c_int]; lib().hs_set_flood_rule(int(os.environ["HS_FLOOD_RULE"]))
+    engine_label = f"relaxed, flood rule {os.environ['HS_FLOOD_RULE']}"
+else:
+    engine_label = None
 def standing(s):                                              # water sections on top (type 0)
     end = np.cumsum(s.count.astype(np.int64)); top = end[s.count > 0] - 1
     return int((s.type[top] == 0).sum())
@@ -40,5 +47,5 @@ for nm in names:
         return (rel(c["steps_water_all"], ce["steps_water_all"]), fac(c["nested_particles"], ce["nested_particles"]), rel(s.nsec, se.nsec),
                 fac(standing(s), standing(se)), f"{d.mean():.1e}", f"{np.sqrt((d * d).mean()):.2e}")
     r = row(h.snapshot(), h.counters()); cs = [row(c.snapshot(), c.counters()) for c in ctl]
-    print(f"| {soil[:-5]}, {ticks} ({nw} + {nd} / tick) | {engine} vs reference | " + " | ".join(r) + f" ({he.std():.3f}) |", flush=True)
+    print(f"| {soil[:-5]}, {ticks} ({nw} + {nd} / tick) | {engine_label or engine} vs reference | " + " | ".join(r) + f" ({he.std():.3f}) |", flush=True)
     print("| | reference, other streams | " + " | ".join(f"{a} / {b}" for a, b in zip(*cs)) + f" |   <!-- {time.time() - t0:.0f}s -->", flush=True)
