@@ -50,9 +50,12 @@ int g_poolsize = 10000000;
 // ---- count libc rand() draws (all std headers are already included above) ----
 static uint64_t g_rand_calls = 0;
 static inline int oracle_rand() { g_rand_calls++; return (rand)(); }
+static inline int oracle_rand_fn() { return oracle_rand(); }
 #define rand() oracle_rand()
 
+#define private public             // --load rebuilds the columns behind Layermap::dat (layermap.h:131) from a snapshot; nothing else uses it
 #include "source/layermap.h"
+#undef private
 #include "source/particle/water.h"
 #include "source/particle/wind.h"
 #include "source/io.h"
@@ -94,7 +97,8 @@ static double now_s() {
 }
 
 int main(int argc, char** argv) {
-  std::string soil = "soil/default.soil", dump_prefix, dump_at, soils_out;
+  std::string soil = "soil/default.soil", dump_prefix, dump_at, soils_out, load_path, heights_out;
+  long long rand_seed = -1;          // --rand-seed S: srand(S) once the terrain stands (the same map under another rand() stream: the P2 control)
   int size = 0, sizex = 0, sizey = 0, ticks = 1, nwater = -1, nwind = -1, dowater = 1, dowind = 1, quiet = 1;
   for (int i = 1; i + 1 < argc; i += 2) {
     std::string k = argv[i], v = argv[i + 1];
@@ -113,6 +117,9 @@ int main(int argc, char** argv) {
     else if (k == "--dump-at") dump_at = v;
     else if (k == "--soils-out") soils_out = v;
     else if (k == "--quiet") quiet = atoi(v.c_str());
+    else if (k == "--load") load_path = v;
+    else if (k == "--rand-seed") rand_seed = atoll(v.c_str());
+    else if (k == "--heights-out") heights_out = v;
     else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
   }
   std::vector<int> dumps;
@@ -158,6 +165,45 @@ int main(int argc, char** argv) {
     fprintf(f, "]}\n");
     fclose(f);
   }
+
+  // --load <snapshot>: continue from a state written by smx_save / snapshot_write (the same SMXSNAP1 layout): every column is rebuilt
+  // bottom -> top with the snapshot's type / size / floor / saturation, the frequency planes are restored and the rand() stream is
+  // advanced to the snapshot's draw count (the stream is srand(SEED)'s either way). Used to time the CPU path on the very state the
+  // GPU line's warm-up produced (bench.py cpu_baseline) -- test infrastructure.
+  uint64_t rand_calls_at_start = 0;
+  if (!load_path.empty()) {
+    FILE* f = fopen(load_path.c_str(), "rb");
+    SnapHeader h;
+    if (!f || fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SMXSNAP1", 8) != 0) { fprintf(stderr, "--load: cannot read %s\n", load_path.c_str()); return 3; }
+    if (h.dimx != SIZEX || h.dimy != SIZEY) { fprintf(stderr, "--load: snapshot is %dx%d, the run is %dx%d\n", h.dimx, h.dimy, SIZEX, SIZEY); return 3; }
+    const size_t n = (size_t)h.ncells, ns = (size_t)h.nsec;
+    std::vector<uint32_t> count(n), type(ns);
+    std::vector<double> sz(ns), fl(ns), sa(ns);
+    std::vector<float> wf(n), wt(n), wi(n);
+    bool ok = fread(count.data(), 4, n, f) == n && fread(type.data(), 4, ns, f) == ns && fread(sz.data(), 8, ns, f) == ns && fread(fl.data(), 8, ns, f) == ns &&
+              fread(sa.data(), 8, ns, f) == ns && fread(wf.data(), 4, n, f) == n && fread(wt.data(), 4, n, f) == n && fread(wi.data(), 4, n, f) == n;
+    fclose(f);
+    if (!ok) { fprintf(stderr, "--load: truncated snapshot\n"); return 3; }
+    size_t off = 0;
+    for (int x = 0; x < map.dim.x; x++)
+      for (int y = 0; y < map.dim.y; y++) {
+        const size_t c = (size_t)x * map.dim.y + y;
+        for (sec* t = map.dat[c]; t != NULL;) { sec* below = t->prev; map.pool.unget(t); t = below; }
+        sec* below = NULL;
+        for (uint32_t k = 0; k < count[c]; k++, off++) {
+          sec* E = map.pool.get(sz[off], (SurfType)type[off]);
+          if (E == NULL) { fprintf(stderr, "--load: pool exhausted\n"); return 3; }
+          E->floor = fl[off]; E->saturation = sa[off]; E->prev = below; E->next = NULL;
+          if (below) below->next = E;
+          below = E;
+        }
+        map.dat[c] = below;
+      }
+    memcpy(WaterParticle::frequency, wf.data(), n * 4); memcpy(WaterParticle::track, wt.data(), n * 4); memcpy(WindParticle::frequency, wi.data(), n * 4);
+    if (rand_seed < 0) { srand(SEED); g_rand_calls = 0; for (uint64_t i = 0; i < h.rand_calls; i++) (void)oracle_rand_fn(); }
+  }
+  if (rand_seed >= 0) { srand((unsigned)rand_seed); }
+  rand_calls_at_start = g_rand_calls;
 
   auto maybe_dump = [&](int t) {
     if (dump_prefix.empty()) return;
@@ -211,14 +257,35 @@ int main(int argc, char** argv) {
   Digest dg = snapshot_digest(s);
   uint64_t rc = g_rand_calls;
   int next_rand = (rand)();
+  // figures for the P2 envelope (tools/p2_envelope.py --reference): cells under standing water, its volume, nested particles
+  // (every particle constructor draws twice, water.h:13 / wind.h:15: what the top-level constructors did not draw, nested ones did)
+  uint64_t standing = 0; double water_volume = 0.0;
+  {
+    size_t off = 0;
+    for (uint64_t c = 0; c < s.h.ncells; c++) {
+      const uint32_t n = s.count[c];
+      if (n && s.type[off + n - 1] == 0) { standing++; water_volume += s.size[off + n - 1]; }
+      off += n;
+    }
+  }
+  const uint64_t top_draws = 2ull * (uint64_t)ticks * ((dowater ? (uint64_t)NWATER : 0ull) + (dowind ? (uint64_t)NWIND : 0ull));
+  const uint64_t nested = (rc - rand_calls_at_start - top_draws) / 2ull;
+  if (!heights_out.empty()) {        // float64 heights, Layermap order x*dimy + y
+    std::vector<double> hh(s.h.ncells);
+    size_t off = 0;
+    for (uint64_t c = 0; c < s.h.ncells; c++) { const uint32_t n = s.count[c]; hh[c] = n ? s.floor[off + n - 1] + s.size[off + n - 1] : 0.0; off += n; }
+    FILE* f = fopen(heights_out.c_str(), "wb");
+    if (f) { fwrite(hh.data(), 8, hh.size(), f); fclose(f); }
+  }
   if (quiet) std::cout.rdbuf(old);
   printf("JSON {\"soil\": \"%s\", \"seed\": %d, \"dimx\": %d, \"dimy\": %d, \"scale\": %d, \"ticks\": %d, \"nwater\": %d, \"nwind\": %d, "
          "\"dowater\": %d, \"dowind\": %d, \"sumh\": %.17g, \"nsec\": %llu, \"typehash\": \"%016llx\", \"poolfree\": %llu, "
          "\"rand_calls\": %llu, \"next_rand\": %d, \"steps_water_top\": %llu, \"steps_wind\": %llu, "
-         "\"t_init\": %.6f, \"t_water\": %.6f, \"t_grid\": %.6f, \"t_wind\": %.6f, \"t_freq\": %.6f}\n",
+         "\"t_init\": %.6f, \"t_water\": %.6f, \"t_grid\": %.6f, \"t_wind\": %.6f, \"t_freq\": %.6f, "
+         "\"standing\": %llu, \"water_volume\": %.17g, \"nested\": %llu, \"rand_seed\": %lld, \"loaded\": %d}\n",
          soil.c_str(), SEED, SIZEX, SIZEY, SCALE, ticks, NWATER, NWIND, dowater, dowind, dg.sumh,
          (unsigned long long)dg.nsec, (unsigned long long)dg.typehash, (unsigned long long)map.pool.free.size(),
          (unsigned long long)rc, next_rand, (unsigned long long)steps_water_top, (unsigned long long)steps_wind,
-         t_init, t_water, t_grid, t_wind, t_freq);
+         t_init, t_water, t_grid, t_wind, t_freq, (unsigned long long)standing, water_volume, (unsigned long long)nested, rand_seed, load_path.empty() ? 0 : 1);
   return 0;
 }

@@ -903,7 +903,7 @@ struct so_ctx {
   //            (x mod 3, y mod 3), Particle::cascade(.., 0);
   //   floods   particles that ended: behind 4x4-cell claim tiles without margin, lowest slot wins, a claim issued in one flood
   //            epoch is good for the next epoch only; flood epochs are every fourth epoch and every epoch in which at least
-  //            a sixteenth as many particles wait as ran (relax_floods_due); nested particles -> children of this generation.
+  //            1/64 as many particles wait as ran (relax_floods_due); nested particles -> children of this generation.
   //   strips   (so_batched_set_strips) INTERIOR / SEAM chunks of 32 epochs: a particle steps iff the columns its step touches are eligible
   //            in the running kind of chunk, a flood reservation is issued iff eligible, every chunk starts with fresh reservations of
   //            the waiting particles, every epoch is a flood epoch (the rule above counts one device's particles: not partition-invariant).
@@ -1018,7 +1018,7 @@ struct so_ctx {
         for (const auto& c : l) particle_cascade(f2{(float)c.first, (float)c.second}, 0);
       // ---- floods
       const uint32_t nflood = (uint32_t)waiting.size();
-      if (bs_n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun) {   // (strips: every epoch)
+      if (bs_n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 64ull >= (unsigned long long)nrun) {   // (strips: every epoch; 1/64 since round 4)
         std::vector<uint32_t> cand, win, rest;
         for (uint32_t i : waiting) if (claim_for[i] == epoch) cand.push_back(i);
         for (uint32_t i : cand) { const BRect& r = sl[i].rect; for (int tx = r.tx0; tx <= r.tx1; tx++) for (int ty = r.ty0; ty <= r.ty1; ty++) { uint32_t& m = tilemin[(size_t)tx * nty + ty]; if (i < m) m = i; } }

@@ -69,9 +69,13 @@ SMX_D void relax_flood_later(const BatchShared& bs, uint32_t slot, uint32_t pari
   if (want) { if (k < bs.list_cap) bs.flist[parity][k] = slot; else SMX_A_ADD(&bs.ctrl[BC_LIST_LOST], 1u); }
 }
 // Floods are long, branchy paths (~150 us each on a lane); while nearly everybody is still running, the few particles that ended
-// early wait for every fourth epoch. Once the ended ones are a sixteenth of the runners (or nobody runs), every epoch floods.
+// early wait for every fourth epoch. Once the ended ones are 1/64 of the runners (or nobody runs), every epoch floods.
 // A function of the epoch's own counts: not of chunking, not of how the host drives the epochs.
 // (Under column strips the counts are one device's share, so every epoch floods there: the result must not depend on the partition.)
+// Round 4: the threshold is 1/64 (round 3 shipped 1/16). A claim issued in one flood epoch is only good for the next epoch, so floods
+// progress when two flood epochs follow each other, i.e. once the threshold holds; with 1/16 the established wet regime ran +11 % water
+// steps against the reference (control <= +5 %), with 1/64 +2 % at equal height RMSE (profiles/r03_flood_rule_cpu.md, r04_p2_*).
+constexpr unsigned long long RELAX_FLOOD_SHARE = 64ull;
 #ifdef SMX_HOSTSIM
 static int g_hs_flood_rule = 0;                               // (host-side experiments only, tools/p2_statistics.py: 0 = the schedule's rule)
 #endif
@@ -79,9 +83,9 @@ SMX_D bool relax_floods_due(const BatchShared& bs, uint32_t epoch, uint32_t nflo
 #ifdef SMX_HOSTSIM
   if (g_hs_flood_rule == 1) return true;                                                                               // every epoch
   if (g_hs_flood_rule == 2) return bs.strips.n > 1 || (epoch & 1u) == 1u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun;
-  if (g_hs_flood_rule == 3) return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 64ull >= (unsigned long long)nrun;
+  if (g_hs_flood_rule == 16) return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun;   // round 3's rule
 #endif
-  return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun;
+  return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * RELAX_FLOOD_SHARE >= (unsigned long long)nrun;
 }
 // after the epoch's edits are applied: which flagged cells can move anything at all? (Particle::cascade starts with the same
 // conservative test, Sim::cascade_precheck: the others are done) -- the rest go to their colour's cascade list

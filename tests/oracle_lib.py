@@ -184,8 +184,9 @@ def have_ref() -> bool:
 def run_ref(soil: str, seed: int = 0, size: int = 0, ticks: int = 1, nwater: int = -1, nwind: int = -1,
             water: bool = True, wind: bool = True, pool: int | None = None, dump_prefix: str | None = None,
             dump_at=(), soils_out: str | None = None, lean: bool = False, timeout: float | None = None,
-            sizex: int = 0, sizey: int = 0) -> dict:
-    """Run oracle/_ref/soil_ref (the reference's own headers, compiled headless) and return its JSON line."""
+            sizex: int = 0, sizey: int = 0, load: str | None = None, rand_seed: int | None = None, heights_out: str | None = None) -> dict:
+    """Run oracle/_ref/soil_ref (the reference's own headers, compiled headless) and return its JSON line.
+    load: continue from a snapshot file (smx_save / --dump-prefix layout); rand_seed: srand() again once the terrain stands."""
     cmd = [REF_LEAN_BIN if lean else REF_BIN, "--soil", soil, "--seed", str(seed), "--ticks", str(ticks),
            "--water", str(int(water)), "--wind", str(int(wind))]
     if size:
@@ -204,6 +205,12 @@ def run_ref(soil: str, seed: int = 0, size: int = 0, ticks: int = 1, nwater: int
         cmd += ["--dump-prefix", dump_prefix, "--dump-at", ",".join(str(t) for t in dump_at)]
     if soils_out:
         cmd += ["--soils-out", soils_out]
+    if load:
+        cmd += ["--load", load]
+    if rand_seed is not None:
+        cmd += ["--rand-seed", str(rand_seed)]
+    if heights_out:
+        cmd += ["--heights-out", heights_out]
     out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=timeout).stdout
     for line in out.splitlines():
         if line.startswith("JSON "):
