@@ -152,7 +152,17 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
     if barrier:
         barrier(m)
     t0 = time.perf_counter()
-    sm.tick(steps)
+    per_tick = []                                               # one entry per timed tick: what the driver's window (ticks W+1 .. W+K) is made of
+    tl, cl, tml = t0, c0, {k: 0.0 for k in ("ms_water", "ms_grid", "ms_wind", "ms_freq")}
+    for k in range(steps):
+        sm.tick(1)
+        m.sync()                                                # (a tick ends with host synchronisations of its own: this adds none that matter)
+        tn, cn, tmn = time.perf_counter(), m.counters(), m.timing()
+        per_tick.append({"tick": warmup + k + 1, "ms": 1e3 * (tn - tl),
+                         "ms_water": tmn["ms_water"] - tml["ms_water"], "ms_grid": tmn["ms_grid"] - tml["ms_grid"], "ms_wind": tmn["ms_wind"] - tml["ms_wind"],
+                         "steps_water": cn["steps_water_all"] - cl["steps_water_all"], "steps_wind": cn["steps_wind"] - cl["steps_wind"],
+                         "floods": cn["floods"] - cl["floods"], "nested": cn["nested_particles"] - cl["nested_particles"]})
+        tl, cl, tml = tn, cn, tmn
     if barrier:
         barrier(m)
     else:
@@ -165,7 +175,7 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
         "dt": dt, "steps_w": steps_w, "steps_d": steps_d, "tm": tm, "digest": m.digest(),
         "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"],
         "nested": c1["nested_particles"] - c0["nested_particles"], "floods": c1["floods"] - c0["floods"],
-        "pool_overflow": c1["pool_overflow"],
+        "pool_overflow": c1["pool_overflow"], "per_tick": per_tick,
         "engine_stats": dict({k: c1[k] - c0[k] for k in ("spec_rounds", "spec_aborts", "spec_fallbacks", "spec_executed")},
                              **{k: b1[k] - b0[k] for k in b1}),
     }
@@ -502,6 +512,7 @@ def main():
             "steps_definition": "value: move()==true + interact(), top-level AND nested particles; value_top_level: top-level only "
                                 "(what cpu_baseline can count)",
             "ms_per_tick": 1e3 * tmax / args.steps, "phase_ms_per_tick": head["phase_ms_per_tick"],
+            "per_tick": r.get("per_tick"),
             "steps_per_tick": head["steps_per_tick"], "engine_stats": head["engine_stats"], "digest": head["digest"],
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_exact": parity, "lines": lines, "lbm_wind": lbm,
             # nothing was dropped inside the timed region (nested particles that did not fit the children buffer, sediment

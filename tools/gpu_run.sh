@@ -34,6 +34,11 @@ for s in "$@"; do
     headrelax) run headrelax 30 300 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     headrelax8) run headrelax8 30 300 env SMX_RELAX_WIND_STEPS=8 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     headrelaxw0) run headrelaxw0 30 300 env SMX_RELAX_WIND_MIN=4000000000 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
+    drv)       run drv 60 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-lines --no-cpu-baseline; cp $out/drv.log $out/drv.json 2>/dev/null ;;
+    gaps)      run gaps 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/gaps -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 2 --warmup 6
+               python tools/kernel_stats.py $out/gaps | tee $out/gaps.kernels
+               python tools/trace_gaps.py $out/gaps --last-ms ${LASTMS:-1400} | tee $out/gaps.summary
+               rm -rf $out/gaps ;;
     ktrace)    run ktrace 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 3 --warmup 2
                python tools/kernel_stats.py $out/ktrace | tee $out/ktrace.summary ;;
     ktracew)   run ktracew 30 300 env SMX_RELAX_WIND_MIN=${WMIN:-4096} SMX_RELAX_WIND_STEPS=${WSTEPS:-8} rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktracew -o t -- python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 3 --warmup 2
