@@ -70,7 +70,7 @@ constexpr int R_MAXSTEPS = 8;                 // relaxed schedule: steps one win
 struct BatchShared {
   unsigned long long* claim[2];               // sized for one word per CELL; indexed [tx * nty + ty] at the current granularity
   int tshift, ntx, nty;                       // claim granularity: tiles of 2^tshift x 2^tshift cells (0 = single cells)
-  int txb;                                    // first tile column the planes hold (DevState::x_lo >> tshift: a strip context holds its range only)
+  int txb, txe;                               // tile columns [txb, txe) the planes hold (DevState::x_lo >> tshift ...: a strip context holds its range only)
   BWater* water; BWind* wind;                 // slots of the current generation
   uint32_t* live;                             // indices of the slots that are not DONE (rebuilt by batch_compact)
   BChild* children; uint32_t child_cap;
@@ -172,11 +172,14 @@ SMX_D void bmark_dirty_cells(const DevState& s, const BatchShared& bs, int cx0, 
   for (int gx = cx0 >> GRID_SHIFT; gx <= (cx1 >> GRID_SHIFT); gx++)
     for (int gy = cy0 >> GRID_SHIFT; gy <= (cy1 >> GRID_SHIFT); gy++) bs.dirty[(size_t)gx * gty + gy] = 1;
 }
+// (a reservation that reaches past the columns a strip context holds -- a resident particle's old rectangle after the strips were
+//  re-cut, a wide dilate -- is neither written nor ever held: the planes end at [txb, txe))
 SMX_D void bclaim(const BatchShared& bs, int plane, const BRect& r, unsigned long long tag) {
-  for (int tx = r.tx0; tx <= r.tx1; tx++)
+  for (int tx = r.tx0 < bs.txb ? bs.txb : r.tx0; tx <= r.tx1 && tx < bs.txe; tx++)
     for (int ty = r.ty0; ty <= r.ty1; ty++) (void)SMX_A_MAX64(&bs.claim[plane][(size_t)(tx - bs.txb) * bs.nty + ty], tag);
 }
 SMX_D bool bholds(const BatchShared& bs, int plane, const BRect& r, unsigned long long tag) {
+  if (r.tx1 >= r.tx0 && (r.tx0 < bs.txb || r.tx1 >= bs.txe)) return false;
   bool ok = true;
   for (int tx = r.tx0; tx <= r.tx1; tx++)
     for (int ty = r.ty0; ty <= r.ty1; ty++) ok &= (bs.claim[plane][(size_t)(tx - bs.txb) * bs.nty + ty] == tag);
@@ -546,7 +549,7 @@ SMX_HD BStrips batch_make_strips(int dimx, int n, int a, int b) {
 SMX_HD void batch_apply_schedule(BatchShared& bs, const DevState& s, const BSched& k) {
   bs.tshift = k.tshift; bs.dilate = k.dilate; bs.maxsteps = k.maxsteps;
   bs.ntx = (s.dimx + (1 << k.tshift) - 1) >> k.tshift; bs.nty = (s.dimy + (1 << k.tshift) - 1) >> k.tshift;
-  bs.txb = s.x_lo >> k.tshift;
+  bs.txb = s.x_lo >> k.tshift; bs.txe = ((s.x_hi - 1) >> k.tshift) + 1;
 }
 
 // ---------------- grid pass: one colour, one tile ----------------

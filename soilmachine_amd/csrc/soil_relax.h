@@ -13,7 +13,8 @@
 //   apply   (relax_apply)    per cell: the queued requests in ENTRY order (slot, then step, then the reference's order inside a step), each
 //           with exactly Layermap::remove / add (layermap.h:230-339): column invariants are exact.
 //   filter  (relax_filter)   the flagged cells that can move anything at all (the conservative test Particle::cascade starts with,
-//           on the map after the epoch's edits) enter the cascade list of their colour (x mod 3, y mod 3);
+//           on the map after the epoch's edits) enter the cascade list of their colour (x mod 3, y mod 3) -- except the isolated ones
+//           (no other flagged cell within two cells), which cascade at once: same result, eight launches' worth of latency less;
 //   cascade (relax_cascade)  the listed cells, ONCE each, with the reference's Particle::cascade(.., 0) -- in nine colour passes
 //           (the cascades of one pass touch disjoint 3x3 blocks, so they commute).
 //   floods  water.h:123-145 reach 4 cells and spawn nested particles: they stay behind claim tiles (batch_water_epoch, run over the
@@ -88,7 +89,13 @@ SMX_D bool relax_floods_due(const BatchShared& bs, uint32_t epoch, uint32_t nflo
   return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * RELAX_FLOOD_SHARE >= (unsigned long long)nrun;
 }
 // after the epoch's edits are applied: which flagged cells can move anything at all? (Particle::cascade starts with the same
-// conservative test, Sim::cascade_precheck: the others are done) -- the rest go to their colour's cascade list
+// conservative test, Sim::cascade_precheck: the others are done) -- the rest go to their colour's cascade list.
+// ISOLATED cells cascade right here (round 4): a flagged cell with no other flagged cell within two cells of it (Chebyshev) shares
+// no column of its 3x3 block with any other flagged cell's block -- neither with a block this pass is still testing, nor with one a
+// colour pass will work on. Cascades on disjoint blocks commute and each tests only its own block, so running it now, in the filter's
+// own launch, gives exactly the state the nine colour passes would leave (the restatement, oracle/soil_oracle.cpp r_water_generation,
+// still runs every cell through its colour: tests/test_relaxed.py, test_gpu_relaxed.py compare full states). What is left for the
+// colour passes is the residue: cells in pits and channels where particles crowd (measured: profiles/r04_relaxed.md).
 template <class P>
 SMX_D void relax_filter(Sim<P>& sim, const BatchShared& bs, uint32_t c, bool valid, uint32_t epoch) {
   const DevState& s = sim.s;
@@ -99,6 +106,15 @@ SMX_D void relax_filter(Sim<P>& sim, const BatchShared& bs, uint32_t c, bool val
     sim.template load_block<2>(x, y, b);
     need = sim.cascade_precheck(b);
     if (!need) sim.n_casc++;                                  // (a listed cell counts in cascade_blk)
+    else {
+      bool alone = true;                                      // (flags outside the columns this context holds cannot be set by it)
+      const int xa = x - 2 < s.x_lo ? s.x_lo : x - 2, xb = x + 2 >= s.x_hi ? s.x_hi - 1 : x + 2;
+      const int ya = y - 2 < 0 ? 0 : y - 2, yb = y + 2 >= s.dimy ? s.dimy - 1 : y + 2;
+      for (int xx = xa; xx <= xb; xx++)
+        for (int yy = ya; yy <= yb; yy++)
+          if ((xx != x || yy != y) && bs.cflag[(size_t)xx * (size_t)s.dimy + (size_t)yy] == bs.rtag) alone = false;
+      if (alone) { sim.cascade_blk(x, y, b); need = false; }
+    }
     col = (uint32_t)((x % 3) * 3 + (y % 3));
   }
   const uint32_t par = epoch & 1u;

@@ -61,10 +61,16 @@ struct RcclTransport : StripTransport {
   XBundle* d_hdr = nullptr;                                   // [2] device staging of the headers (send, receive)
   unsigned long long* d_coll = nullptr;                       // small device scratch of the collectives
   void* d_gather = nullptr; size_t gather_cap = 0; void* d_mine = nullptr; size_t mine_cap = 0;
-  ~RcclTransport() override { if (comm) g_rccl.CommDestroy(comm); hipFree(d_hdr); hipFree(d_coll); hipFree(d_gather); hipFree(d_mine); }
+  XBundle* h_hdr = nullptr; uint32_t hdr_slot = 0;            // pinned ring of outgoing headers: the async copy reads its slot when the stream gets there,
+  static constexpr uint32_t HDR_RING = 64;                    // long after send_bundle's caller has dropped its own (stack) header; every chunk synchronises
+                                                              // the stream at least once (recv_bundle, the live-count all-reduce), so at most a few slots are in flight
+  ~RcclTransport() override { if (comm) g_rccl.CommDestroy(comm); hipFree(d_hdr); hipFree(d_coll); hipFree(d_gather); hipFree(d_mine); if (h_hdr) hipHostFree(h_hdr); }
   int send_bundle(smx_ctx* ctx, int peer, const XBundle& b) override {
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemcpyAsync(&d_hdr[0], &b, sizeof(b), hipMemcpyHostToDevice, st));
+    if (!h_hdr) HIPCHK(hipHostMalloc(&h_hdr, HDR_RING * sizeof(XBundle)));
+    XBundle* slot = &h_hdr[hdr_slot++ % HDR_RING];
+    *slot = b;
+    HIPCHK(hipMemcpyAsync(&d_hdr[0], slot, sizeof(b), hipMemcpyHostToDevice, st));
     // same shape on both sides: the header as an operation of its own (the receiver needs it before it can post the rest),
     // then ONE group with the payloads -- point-to-point operations between two ranks pair up in the order they were issued
     NCCLCHK(g_rccl.Send(&d_hdr[0], sizeof(XBundle), ncclUint8, peer, comm, st));

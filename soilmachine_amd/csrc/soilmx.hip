@@ -337,9 +337,9 @@ __global__ void __launch_bounds__(64) k_relax_filter(DevState s, BatchShared bs,
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   BatchPolicy pol(s, bs);
   Sim<BatchPolicy> sim(s, sh, pol);
-  relax_filter(sim, bs, i < n ? bs.flagl[par][i] : 0u, i < n, epoch);
-  sim.flush_counters();
-  relax_commit_cascade_counters(s, pol.a_casc, 0ull);
+  relax_filter(sim, bs, i < n ? bs.flagl[par][i] : 0u, i < n, epoch);   // (isolated cells cascade in here)
+  sim.flush_counters(); pol.finish(s);
+  relax_commit_cascade_counters(s, pol.a_casc, pol.a_tr);
 }
 __global__ void __launch_bounds__(64) k_relax_cascade(DevState s, BatchShared bs, uint32_t epoch, uint32_t colour) {
   const uint32_t par = epoch & 1u;
@@ -432,8 +432,8 @@ __global__ void __launch_bounds__(256) k_relax_tail(DevState s, BatchShared bs, 
         BatchPolicy pol(s, bs);
         Sim<BatchPolicy> sim(s, sh, pol);
         relax_filter(sim, bs, i < n ? bs.flagl[par][i] : 0u, i < n, epoch);
-        sim.flush_counters();
-        nc += pol.a_casc;
+        sim.flush_counters(); pol.finish(s);
+        nc += pol.a_casc; nt += pol.a_tr;
       }
     }
     __syncthreads();
@@ -599,6 +599,7 @@ __global__ void __launch_bounds__(64) k_strip_unpack_columns(DevState s, BatchSh
   const uint32_t* h = reinterpret_cast<const uint32_t*>(r);
   const uint32_t cc = h[0], count = h[1];
   if (cc >= (unsigned long long)s.dimx * s.dimy || (unsigned long long)offs[i] + 24ull + 32ull * count > nbytes) return;
+  if (cc < (unsigned long long)s.x_lo * s.dimy || cc >= (unsigned long long)s.x_hi * s.dimy) return;   // (a strip context holds [x_lo, x_hi) only: cells / flags are biased pointers)
   const size_t x = cc / (size_t)s.dimy, y = cc % (size_t)s.dimy, fi = y * (size_t)s.dimx + x;
   s.wtrack[fi] = __uint_as_float(h[2]); s.windfreq[fi] = __uint_as_float(h[3]);
   BatchPolicy pol(s, bs);
@@ -1564,7 +1565,7 @@ static void launch_classify(smx_ctx* ctx);
 static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
   BatchShared& bs = ctx->bs;
   if (!bs.ctrl) {
-    bs.tshift = -1; bs.ntx = ctx->cfg.dimx; bs.nty = ctx->cfg.dimy; bs.txb = 0;
+    bs.tshift = -1; bs.ntx = ctx->cfg.dimx; bs.nty = ctx->cfg.dimy; bs.txb = 0; bs.txe = ctx->cfg.dimx;
     const size_t nt = ctx->lcells + 2 * (size_t)ctx->cfg.dimy;   // one claim word per held cell (+ a row of slack for tiles cut by the range's edges): enough for every granularity
     HIPCHK(hipMalloc(&bs.claim[0], nt * 8)); HIPCHK(hipMalloc(&bs.claim[1], nt * 8));
     HIPCHK(hipMalloc(&bs.ctrl, BC_COUNT * 4)); HIPCHK(hipMemsetAsync(bs.ctrl, 0, BC_COUNT * 4, ctx->stream));
@@ -1922,6 +1923,7 @@ static int d_gen_end_impl(smx_ctx* ctx, void* children_out, uint32_t cap, uint32
   uint32_t nc = ctx->h_bctrl[BC_NCHILD];
   if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
   if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
+  if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
   if (nc > bs.child_cap) nc = bs.child_cap;
   if (vec) { vec->resize(nc); children_out = vec->data(); cap = nc; }
   if (nc > cap) { ctx->err = "smx_d_gen_end: children buffer too small (call again with room for *n records)"; *n = nc; return -2; }

@@ -407,7 +407,7 @@ extern "C" void hs_set_relax_water(int steps) { g_relax_water_steps = steps < 1 
 extern "C" void hs_set_relax_wind(uint32_t n, int steps) { g_relax_wind_min = n; g_relax_wind_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
 static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) {
   const DevState& s = c->d;
-  b.bs.tshift = -1; b.bs.ntx = s.dimx; b.bs.nty = s.dimy; b.bs.txb = 0;
+  b.bs.tshift = -1; b.bs.ntx = s.dimx; b.bs.nty = s.dimy; b.bs.txb = 0; b.bs.txe = s.dimx;
   const size_t nt = (size_t)s.dimx * s.dimy;                // one claim word per cell: enough for every granularity
   b.claim0.assign(nt, 0); b.claim1.assign(nt, 0);
   if (wind) b.wind.resize(nslots); else b.water.resize(nslots);
@@ -514,8 +514,9 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
             parallel_for(nf, nthreads, [&](uint32_t i) {
               BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
               relax_filter(sim, bs, bs.flagl[par][i], true, epoch);
-              sim.flush_counters();
+              sim.flush_counters(); pol.finish(s);
               if (pol.a_casc) SMX_A_ADD64(&s.ctr[C_CASCADE_CALLS], (unsigned long long)pol.a_casc);
+              if (pol.a_tr) SMX_A_ADD64(&s.ctr[C_CASCADE_TRANSFERS], (unsigned long long)pol.a_tr);
             }, shuffle ? shuffle + 15 + epoch : 0);
           }
           for (uint32_t col = 0; col < 9u; col++) {                                            // k_relax_cascade(_small)
