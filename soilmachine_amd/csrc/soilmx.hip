@@ -35,6 +35,7 @@
 #include "soil_relax.h"
 #include "soil_lbm.h"
 #include <algorithm>
+#include <rocprim/rocprim.hpp>   // device radix sort of the nested particles' keys (children -> next generation, batch_generations)
 
 using namespace smx;
 
@@ -903,6 +904,7 @@ struct smx_ctx {
   bool batch_wind_buf = false;
   uint32_t* d_draws = nullptr; uint32_t* h_draws = nullptr; uint32_t draws_cap = 0;
   BChild* d_kids = nullptr; uint32_t kids_cap = 0;
+  unsigned long long* d_skeys[2] = {nullptr, nullptr}; uint32_t* d_sidx[2] = {nullptr, nullptr}; void* d_stemp = nullptr; size_t stemp_bytes = 0; uint32_t sort_cap = 0;   // children sort (device)
   uint32_t* h_bctrl = nullptr;
   int batch_dilate = 0;
   uint32_t relax_wind_min = 0xFFFFFFFFu;   // relaxed schedule: wind runs relaxed while more particles than this are running (default: never --
@@ -1063,7 +1065,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1624,6 +1626,38 @@ __global__ void __launch_bounds__(256) k_relax_rebuild_floods(BatchShared bs, ui
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   relax_flood_later(bs, i, parity, i < nslots && bs.water[i].state == B_ENDED);
 }
+// Children of a generation -> the next generation's slots, in key order (the order decides slot numbers = priorities and rand() draws),
+// without leaving the device: keys are unique ((parent << 8) | sequence), so any sort gives the one order. Round 3 copied the records to
+// the host, std::sort-ed them there and copied them back: 5-6 ms of an idle device per generation once a tick spawns 10^6 nested
+// particles (profiles/r04_relaxed.md).
+__global__ void __launch_bounds__(256) k_child_keys(const BChild* __restrict__ ch, uint32_t n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) { keys[i] = ch[i].key; idx[i] = i; }
+}
+__global__ void __launch_bounds__(256) k_child_gather(const BChild* __restrict__ ch, const uint32_t* __restrict__ idx, uint32_t n, BChild* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) out[i] = ch[idx[i]];
+}
+static int sort_children(smx_ctx* ctx, uint32_t nc) {       // bs.children[0, nc) -> ctx->d_kids[0, nc), ascending key; asynchronous on the context's stream
+  hipStream_t st = ctx->stream;
+  if (nc == 0) return 0;
+  if (ctx->kids_cap < nc) { hipFree(ctx->d_kids); ctx->d_kids = nullptr; ctx->kids_cap = 0; const uint32_t cap = nc + nc / 2; HIPCHK(hipMalloc(&ctx->d_kids, (size_t)cap * sizeof(BChild))); ctx->kids_cap = cap; }
+  if (ctx->sort_cap < nc) {
+    for (int k = 0; k < 2; k++) { hipFree(ctx->d_skeys[k]); hipFree(ctx->d_sidx[k]); ctx->d_skeys[k] = nullptr; ctx->d_sidx[k] = nullptr; }
+    hipFree(ctx->d_stemp); ctx->d_stemp = nullptr; ctx->stemp_bytes = 0; ctx->sort_cap = 0;
+    const uint32_t cap = nc + nc / 2;
+    for (int k = 0; k < 2; k++) { HIPCHK(hipMalloc(&ctx->d_skeys[k], (size_t)cap * 8)); HIPCHK(hipMalloc(&ctx->d_sidx[k], (size_t)cap * 4)); }
+    size_t tb = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, ctx->d_skeys[0], ctx->d_skeys[1], ctx->d_sidx[0], ctx->d_sidx[1], (size_t)cap, 0u, 64u, st));
+    HIPCHK(hipMalloc(&ctx->d_stemp, tb)); ctx->stemp_bytes = tb; ctx->sort_cap = cap;
+  }
+  const unsigned nb = (nc + 255u) / 256u;
+  hipLaunchKernelGGL(k_child_keys, dim3(nb), dim3(256), 0, st, ctx->bs.children, nc, ctx->d_skeys[0], ctx->d_sidx[0]);
+  size_t tb = ctx->stemp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(ctx->d_stemp, tb, ctx->d_skeys[0], ctx->d_skeys[1], ctx->d_sidx[0], ctx->d_sidx[1], (size_t)nc, 0u, 64u, st));
+  hipLaunchKernelGGL(k_child_gather, dim3(nb), dim3(256), 0, st, ctx->bs.children, ctx->d_sidx[1], nc, ctx->d_kids);
+  return 0;
+}
 // One CHUNK of a particle phase on the context's current generation: the schedule for `nlive_sched` running particles (all strips
 // together), fresh reservations where the schedule asks for them, then the chunk's epochs over the `nlive` slots of bs.live.
 // Shared by the single-context driver (batch_generations) and the step-wise one of the column strips (smx_d_chunk).
@@ -1722,10 +1756,11 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
   if (epochs_run) *epochs_run = chunk_epochs;
   return 0;
 }
-static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BChild> kids) {
+// generations of one phase: n top-level particles, or (nkids > 0) the children the grid pass left, already sorted into ctx->d_kids
+static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, uint32_t nkids) {
   hipStream_t st = ctx->stream;
-  bool first = kids.empty();
-  uint32_t nslots = first ? n : (uint32_t)kids.size();
+  bool first = nkids == 0;
+  uint32_t nslots = first ? n : nkids;
   if (nslots == 0) return 0;
   RandState r;                                              // the host draws for the device: glibc rand() is a serial recurrence
   HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, st));
@@ -1743,12 +1778,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     const bool relax_gen = ctx->cfg.engine == SMX_ENGINE_RELAXED;
     ctx->bs.relaxed = relax_gen ? 1 : 0;
     if (relax_gen) HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // flood, flag and cascade lists start empty
-    const BChild* dk = nullptr;
-    if (!first) {
-      if (ctx->kids_cap < nslots) { hipFree(ctx->d_kids); ctx->d_kids = nullptr; ctx->kids_cap = 0; HIPCHK(hipMalloc(&ctx->d_kids, (size_t)nslots * sizeof(BChild))); ctx->kids_cap = nslots; }
-      HIPCHK(hipMemcpyAsync(ctx->d_kids, kids.data(), (size_t)nslots * sizeof(BChild), hipMemcpyHostToDevice, st));
-      dk = ctx->d_kids;
-    }
+    const BChild* dk = first ? nullptr : ctx->d_kids;        // (sorted there by sort_children)
     const unsigned nb = (nslots + 63u) / 64u;
     if (wind) hipLaunchKernelGGL(k_batch_spawn<true>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk, (const uint32_t*)nullptr);
     else hipLaunchKernelGGL(k_batch_spawn<false>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk, (const uint32_t*)nullptr);
@@ -1779,13 +1809,11 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, std::vector<BC
     if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
     if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
     if (nc > bs.child_cap) nc = bs.child_cap;
-    kids.resize(nc);
-    if (nc) HIPCHK(hipMemcpyAsync(kids.data(), bs.children, (size_t)nc * sizeof(BChild), hipMemcpyDeviceToHost, st));
+    if (wind) nc = 0;
+    if (nc && sort_children(ctx, nc)) return -1;             // -> ctx->d_kids, on the device
     HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));   // NCHILD, CHILD_LOST
-    HIPCHK(hipStreamSynchronize(st));
-    std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
     first = false;
-    nslots = wind ? 0u : nc;
+    nslots = nc;
   }
   HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1821,12 +1849,9 @@ static int batch_grid(smx_ctx* ctx) {
   if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
   if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
   if (nc > bs.child_cap) nc = bs.child_cap;
-  std::vector<BChild> kids(nc);
-  if (nc) HIPCHK(hipMemcpyAsync(kids.data(), bs.children, (size_t)nc * sizeof(BChild), hipMemcpyDeviceToHost, st));
+  if (nc && sort_children(ctx, nc)) return -1;
   HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
-  HIPCHK(hipStreamSynchronize(st));
-  std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
-  if (!kids.empty()) return batch_generations(ctx, false, 0, std::move(kids));
+  if (nc) return batch_generations(ctx, false, 0, nc);
   return 0;
 }
 
@@ -2051,7 +2076,7 @@ int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   FULLMAP("smx_tick_water (a strip ticks with smx_strips_tick)")
   roctx_range rr("soilmx:water");
   PhaseTimer t(ctx, 0);
-  if (is_batched(ctx)) return batch_generations(ctx, false, nwater > 0 ? (uint32_t)nwater : 0u, {});
+  if (is_batched(ctx)) return batch_generations(ctx, false, nwater > 0 ? (uint32_t)nwater : 0u, 0u);
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwater, false);
   PhaseTimer tk(ctx, 4);
   hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwater);
@@ -2074,7 +2099,7 @@ int smx_tick_wind(smx_ctx* ctx, int32_t nwind) {
   FULLMAP("smx_tick_wind (a strip ticks with smx_strips_tick)")
   roctx_range rr("soilmx:wind");
   PhaseTimer t(ctx, 2);
-  if (is_batched(ctx)) return batch_generations(ctx, true, nwind > 0 ? (uint32_t)nwind : 0u, {});
+  if (is_batched(ctx)) return batch_generations(ctx, true, nwind > 0 ? (uint32_t)nwind : 0u, 0u);
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwind, true);
   PhaseTimer tk(ctx, 5);
   hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwind);

@@ -519,6 +519,37 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
               if (pol.a_tr) SMX_A_ADD64(&s.ctr[C_CASCADE_TRANSFERS], (unsigned long long)pol.a_tr);
             }, shuffle ? shuffle + 15 + epoch : 0);
           }
+          static FILE* rstats = getenv("HS_RESIDUE_STATS") ? fopen(getenv("HS_RESIDUE_STATS"), "w") : nullptr;   // analysis only: what is left for the colour passes?
+          if (rstats) {
+            const uint32_t par = epoch & 1u;
+            uint32_t nf = b.ctrl[BC_NFLAG + par]; if (nf > bs.flag_cap) nf = bs.flag_cap;
+            std::vector<uint32_t> fl(bs.flagl[par], bs.flagl[par] + nf);
+            std::map<uint32_t, uint32_t> id; for (uint32_t i = 0; i < nf; i++) id[fl[i]] = i;
+            std::vector<uint32_t> parent(nf); for (uint32_t i = 0; i < nf; i++) parent[i] = i;
+            std::function<uint32_t(uint32_t)> find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+            for (uint32_t i = 0; i < nf; i++) {
+              const int x = (int)(fl[i] / (uint32_t)s.dimy), y = (int)(fl[i] % (uint32_t)s.dimy);
+              for (int dx = -2; dx <= 2; dx++) for (int dy = -2; dy <= 2; dy++) {
+                const int xx = x + dx, yy = y + dy; if ((!dx && !dy) || xx < 0 || yy < 0 || xx >= s.dimx || yy >= s.dimy) continue;
+                auto it = id.find((uint32_t)xx * (uint32_t)s.dimy + (uint32_t)yy); if (it != id.end()) { const uint32_t a = find(i), c = find(it->second); if (a != c) parent[a] = c; }
+              }
+            }
+            std::vector<uint32_t> csize(nf, 0), cneedy(nf, 0); std::vector<uint32_t> ccol(nf, 0);
+            for (uint32_t i = 0; i < nf; i++) csize[find(i)]++;
+            uint32_t residue = 0, ncol_used = 0;
+            for (uint32_t col = 0; col < 9u; col++) {
+              uint32_t nc = b.ctrl[BC_NCASC + 9u * par + col]; if (nc > bs.clist_cap) nc = bs.clist_cap;
+              residue += nc; if (nc) ncol_used++;
+              for (uint32_t i = 0; i < nc; i++) { const uint32_t r = find(id[bs.clist[par][(size_t)col * bs.clist_cap + i]]); cneedy[r]++; ccol[r] |= 1u << col; }
+            }
+            uint32_t hist[6] = {0, 0, 0, 0, 0, 0}, maxdepth = 0;   // residue cells by the size of their cluster: 2, 3, 4, 5-8, 9-16, >16
+            for (uint32_t i = 0; i < nf; i++) if (cneedy[i]) {
+              const uint32_t z = csize[i]; const int bkt = z <= 2 ? 0 : z == 3 ? 1 : z == 4 ? 2 : z <= 8 ? 3 : z <= 16 ? 4 : 5; hist[bkt] += cneedy[i];
+              const uint32_t d = (uint32_t)__builtin_popcount(ccol[i]); if (d > maxdepth) maxdepth = d;
+            }
+            fprintf(rstats, "%s %u %u live %u flagged %u residue %u colours %u maxdepth %u  bysize2/3/4/8/16/more %u %u %u %u %u %u\n", wind ? "wind" : "water", nslots, epoch, nlive, nf, residue, ncol_used, maxdepth,
+                    hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+          }
           for (uint32_t col = 0; col < 9u; col++) {                                            // k_relax_cascade(_small)
             const uint32_t par = epoch & 1u;
             uint32_t nc = b.ctrl[BC_NCASC + 9u * par + col]; if (nc > bs.clist_cap) nc = bs.clist_cap;

@@ -30,14 +30,15 @@ for s in "$@"; do
     quick)     run quick 40 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu ;;
     parity)    run parity 60 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_depth.py tests/test_host_compat.py -x -q -m gpu ;;
     gpusuite)  run gpusuite 120 1500 python -m pytest tests -x -q -m gpu --durations=15 ;;
+    batchtest) run batchtest 60 600 python -m pytest tests/test_gpu_batched.py -x -q -m gpu --durations=5 ;;
     relaxtest) run relaxtest 60 600 python -m pytest tests/test_gpu_relaxed.py -x -q -m gpu --durations=8 ;;
     headrelax) run headrelax 30 300 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     headrelax8) run headrelax8 30 300 env SMX_RELAX_WIND_STEPS=8 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     headrelaxw0) run headrelaxw0 30 300 env SMX_RELAX_WIND_MIN=4000000000 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     drv)       run drv 60 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-lines --no-cpu-baseline; cp $out/drv.log $out/drv.json 2>/dev/null ;;
-    gaps)      run gaps 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/gaps -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 2 --warmup 6
+    gaps)      run gaps 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/gaps -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 2 --warmup ${GWARM:-6}
                python tools/kernel_stats.py $out/gaps | tee $out/gaps.kernels
-               python tools/trace_gaps.py $out/gaps --last-ms ${LASTMS:-1400} | tee $out/gaps.summary
+               python tools/trace_gaps.py $out/gaps --last-ticks ${LASTTICKS:-1} | tee $out/gaps.summary
                rm -rf $out/gaps ;;
     ktrace)    run ktrace 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 3 --warmup 2
                python tools/kernel_stats.py $out/ktrace | tee $out/ktrace.summary ;;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does the time BETWEEN kernels go? From a rocprofv3 --kernel-trace CSV (…kernel_trace.csv: one row per dispatch with start / end
 timestamps): busy time, idle time, and the idle time attributed to (previous kernel -> next kernel) pairs.
-  trace_gaps.py <dir-or-csv> [--skip-ms N] [--last-ms M]      (skip everything before N ms after the first dispatch: the warm-up)"""
+  trace_gaps.py <dir-or-csv> [--skip-ms N] [--last-ms M] [--last-ticks K]      (skip everything before N ms after the first dispatch: the warm-up)"""
 import csv, glob, os, sys
 from collections import defaultdict
 
@@ -21,6 +21,11 @@ def main():
     rows.sort()
     t0 = rows[0][0] + int(skip_ms * 1e6)
     rows = [r for r in rows if r[0] >= t0]
+    if "--last-ticks" in sys.argv:                            # whole ticks: a tick ends with its k_map_frequency launch
+        k = int(sys.argv[sys.argv.index("--last-ticks") + 1])
+        ends = [r[1] for r in rows if r[2].startswith("k_map_frequency")]
+        if len(ends) > k:
+            rows = [r for r in rows if ends[-k - 1] < r[0] and r[1] <= ends[-1]]
     if "--last-ms" in sys.argv:
         t1 = rows[-1][1] - int(float(sys.argv[sys.argv.index("--last-ms") + 1]) * 1e6)
         rows = [r for r in rows if r[0] >= t1]
