@@ -72,7 +72,10 @@ typedef struct smx_counters {
   uint64_t pool_overflow;          /* pool.get() on an empty pool (layermap.h:92-95)                 */
   uint64_t spec_rounds;            /* speculative engine: execution rounds                           */
   uint64_t spec_aborts;            /* speculative engine: particle executions thrown away            */
-  uint64_t reserved[2];
+  uint64_t reserved[2];            /* [0] phases the speculative engine handed to the serial walker, [1] particle executions         */
+  uint64_t spec_subphases_cut;     /* speculative engine: sub-phases that ended early (nested-slot budget used up) and were re-armed  */
+  uint64_t spec_serial_particles;  /* ... single particles run by the serial walker between two sub-phases (more nested particles    */
+                                   /*     than a sub-phase has slots)                                                                */
 } smx_counters;
 
 /* Elapsed device time of the phases of the last smx_tick* calls, measured with HIP events on the
@@ -132,10 +135,10 @@ int smx_read_surface(smx_ctx* ctx, uint32_t* out);      /* Layermap::surface(ive
  * File = the snapshot layout of soilmachine_amd/snapshot.py (64-byte header "SMXSNAP1", per-cell section counts, sections
  * bottom -> top, the three frequency planes) followed by a trailer "SMXRAND1" with the rand() generator's 31-word ring, its
  * index and the number of draws -- a loaded context continues the libc stream exactly where the saved one stopped.
- * The exact engines continue bit-identically. The throughput engines (BATCHED / RELAXED) fix the active set of their grid pass at
- * its start from a per-column "has held a saturation" bit that is context state, not part of the file (import and load re-derive
- * it from the saturations present): a throughput run resumed from a file is a valid result of the schedule, but it can differ from
- * the uninterrupted run in columns whose saturation had returned to zero. ---- */
+ * Since round 4 a second trailer "SMXFLAG1" carries the per-column flag plane (one byte per cell; its sticky "has held a saturation"
+ * bit is context state the column records cannot express, and the throughput engines fix the active set of their grid pass from
+ * it): every engine now continues bit-identically from a file (tests/test_gpu_depth.py). A bare snapshot without the trailers still
+ * loads (return 1: re-seed the generator; the flag plane is re-derived from the saturations present). ---- */
 int smx_save(smx_ctx* ctx, const char* path);
 int smx_load(smx_ctx* ctx, const char* path);           /* dims must match the context; SCALE and soils are the caller's */
 
@@ -167,6 +170,9 @@ int smx_fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void*
  * (layermap.h:477-510: first section starting at or below SLICE/SCALE; a section reaching above it is drawn flat at y = SLICE,
  * blended with Air's colour where its water table reaches the cut), mode 1 = Layermap::slice(s = cut) (layermap.h:557-613). */
 int smx_fill_vertices_cut(smx_ctx* ctx, const float* colors4, int32_t ncolors, int32_t mode, double cut, void* out_vertices44);
+/* ONE column's vertex under the same rules (mode < 0: no cut) -- Layermap::update(ivec2, Vertexpool&) (layermap.h:475-549) for a
+ * host-driven single edit; out = 44 bytes. */
+int smx_fill_vertex_cut(smx_ctx* ctx, const float* colors4, int32_t ncolors, int32_t mode, double cut, int32_t x, int32_t y, void* out_vertex44);
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out);      /* Layermap::height(vec2) (layermap.h:427) */
 
 /* ---- observability ---- */

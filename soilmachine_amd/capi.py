@@ -28,7 +28,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
         "cascade_transfers", "wcascade_calls", "grid_active_cells", "rand_calls", "pool_free", "pool_overflow",
-        "spec_rounds", "spec_aborts")] + [("reserved", C.c_uint64 * 2)]
+        "spec_rounds", "spec_aborts")] + [("reserved", C.c_uint64 * 2), ("spec_subphases_cut", C.c_uint64), ("spec_serial_particles", C.c_uint64)]
 
     def as_dict(self) -> dict:
         d = {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
@@ -68,7 +68,7 @@ SYMBOLS = [
     "smx_initialize", "smx_import_columns", "smx_import_frequency", "smx_num_sections", "smx_export_columns",
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
-    "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices", "smx_fill_vertices_cut",
+    "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices", "smx_fill_vertices_cut", "smx_fill_vertex_cut",
     "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_timing_reset", "smx_set_engine", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind", "smx_strips_rccl_unique_id", "smx_strips_attach_rccl", "smx_strips_attach", "smx_strips_detach", "smx_strips_tick", "smx_strips_stats",
     "smx_d_set_own", "smx_d_gen_begin", "smx_d_gen_spawn", "smx_d_next_phase", "smx_d_chunk", "smx_d_gen_end", "smx_d_pack_columns",
     "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep",
@@ -123,6 +123,7 @@ def load() -> C.CDLL:
     L.smx_normals.argtypes = [vp, vp]
     L.smx_fill_vertices.argtypes = [vp, vp, C.c_int32, vp]
     L.smx_fill_vertices_cut.argtypes = [vp, vp, C.c_int32, C.c_int32, dbl, vp]
+    L.smx_fill_vertex_cut.argtypes = [vp, vp, C.c_int32, C.c_int32, dbl, C.c_int32, C.c_int32, vp]
     L.smx_heights_bilinear.argtypes = [vp, vp, i32, vp]
     L.smx_save.argtypes = [vp, C.c_char_p]
     L.smx_load.argtypes = [vp, C.c_char_p]

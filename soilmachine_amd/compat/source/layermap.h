@@ -190,15 +190,16 @@ class Layermap {
     vertexpool.index();
     vertexpool.update();
   }
-  // one column (host-driven edits): the top section from the host mirrors. The SLICE cut of layermap.h:477-510 needs the
-  // buried sections, which live on the device: the whole-map update(Vertexpool&) below applies it (smx_fill_vertices_cut)
+  // one column (host-driven edits), with the SLICE cut of layermap.h:477-510 (it needs the buried sections, which live on the device:
+  // smx_fill_vertex_cut runs the whole-map kernel on the one block that holds the column and brings the 44-byte record back)
   void update(ivec2 p, Vertexpool<Vertex>& vertexpool) {                                            // layermap.h:475-549
     if (section == NULL) return;
-    refresh();
+    flush();
+    static_assert(sizeof(Vertex) == 44, "Vertex is the 44-byte record smx_fill_vertex_cut writes");
+    std::vector<float> col(4 * soils.size());
+    for (size_t k = 0; k < soils.size(); k++) { col[4 * k] = soils[k].color.x; col[4 * k + 1] = soils[k].color.y; col[4 * k + 2] = soils[k].color.z; col[4 * k + 3] = soils[k].color.w; }
     const size_t c = (size_t)p.x * dim.y + p.y;
-    const uint32_t ty = smirror[c];
-    if (hmirror[c] == 0.0 && ty == 0) vertexpool.fill(section, (int)c, vec3(p.x, 0, p.y), vec3(0, 1, 0), soils[0].color, 0);
-    else vertexpool.fill(section, (int)c, vec3(p.x, SCALE * hmirror[c], p.y), normal(p), soils[ty].color, (int)ty);
+    check(smx_fill_vertex_cut(ctx, col.data(), (int32_t)soils.size(), 0, (double)SLICE, p.x, p.y, vertexpool.get(section, (int)c)), "smx_fill_vertex_cut");
   }
   // The whole map in one device pass (smx_fill_vertices_cut writes the 44-byte records straight into the pool's memory). A
   // section is one bucket of contiguous vertices -- in the host tree's own pool (source/include/vertexpool.h:97-100: start of

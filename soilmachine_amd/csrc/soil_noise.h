@@ -2,6 +2,27 @@
 // (layermap.h:181-196 -> surface.h:82-99 -> FastNoiseLite.h:321-345,473-552,686-727,865-885,1053-1150).
 // Integer hash + float arithmetic in source order; compiled with -ffp-contract=off so every cell gets
 // the bit pattern the reference's CPU code produces.
+//
+// simplex2_3d / fbm below restate the algorithm of FastNoiseLite (the noise library the reference vendors as
+// source/include/FastNoiseLite.h, v1.0.1): bit-exact float arithmetic leaves one legal order of operations, so the
+// statements follow the library's. FastNoiseLite is distributed under the MIT License:
+//
+//   MIT License
+//   Copyright(c) 2020 Jordan Peck (jordan.me2@gmail.com)
+//   Copyright(c) 2020 Contributors
+//
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files(the "Software"), to deal in the Software without restriction, including without limitation the
+//   rights to use, copy, modify, merge, publish, distribute, sublicense, and / or sell copies of the Software, and to
+//   permit persons to whom the Software is furnished to do so, subject to the following conditions :
+//
+//   The above copyright notice and this permission notice shall be included in all copies or substantial portions of
+//   the Software.
+//
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//   WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR
+//   COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
 #pragma once
 #include <stdint.h>
 

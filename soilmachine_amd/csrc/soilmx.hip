@@ -769,12 +769,12 @@ __global__ void __launch_bounds__(256) k_normals(DevState s, float* __restrict__
 // stride per thread would scatter every store over two lines).
 // mode -1: no cut (the top section). mode 0: Layermap::update's SLICE cut (layermap.h:477-510). mode 1: Layermap::slice(s)
 // (layermap.h:557-613). thr = the cut height in map units, ycut = the y written for a cut column.
-struct VCut { int mode; double thr; float ycut; };
+struct VCut { int mode; double thr; float ycut; unsigned block0 = 0; };   // block0: first 256-cell block of the launch (one column: smx_fill_vertex_cut)
 __global__ void __launch_bounds__(256) k_fill_vertices(DevState s, const float* __restrict__ colors4, uint32_t ncolors,
                                                        float* __restrict__ out, VCut cut) {
   __shared__ float stage[256 * 11];
   const size_t n = (size_t)s.dimx * s.dimy;
-  const size_t c0 = (size_t)blockIdx.x * 256, c = c0 + threadIdx.x;
+  const size_t c0 = ((size_t)blockIdx.x + cut.block0) * 256, c = c0 + threadIdx.x;
   if (c < n) {
     const int x = (int)(c / s.dimy), y = (int)(c % s.dimy);
     Sec r = s.cells[c];
@@ -894,7 +894,7 @@ struct smx_ctx {
   std::vector<EvPair> pending;
   std::vector<hipEvent_t> evpool;
   smx_timing timing{};
-  uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0;
+  uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0, spec_subphases_cut = 0, spec_serial_particles = 0;
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
   uint32_t* h_ctrl = nullptr;         // pinned host copy of the control block
@@ -1310,6 +1310,10 @@ int smx_save(smx_ctx* ctx, const char* path) {
   std::vector<float> wf(n), wt(n), wi(n);
   if (smx_export_columns(ctx, count.data(), type.data(), size.data(), floor.data(), sat.data())) return -1;
   if (smx_read_frequency(ctx, wf.data(), wt.data(), wi.data())) return -1;
+  // the per-column flag plane (bit1 = "this column has held a saturation", sticky): context state the column records do not
+  // carry; the throughput engines fix the active set of their grid pass from it, so a resume without it can differ
+  std::vector<uint8_t> fl(n);
+  HIPCHK(hipMemcpyAsync(fl.data(), ctx->d.flags, n, hipMemcpyDeviceToHost, ctx->stream));
   RandTrailer tr; memcpy(tr.magic, "SMXRAND1", 8);
   RandState r;
   HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
@@ -1323,7 +1327,8 @@ int smx_save(smx_ctx* ctx, const char* path) {
   bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
   ok = ok && fwrite(count.data(), 4, n, f) == n && fwrite(type.data(), 4, ns, f) == ns && fwrite(size.data(), 8, ns, f) == ns &&
        fwrite(floor.data(), 8, ns, f) == ns && fwrite(sat.data(), 8, ns, f) == ns && fwrite(wf.data(), 4, n, f) == n &&
-       fwrite(wt.data(), 4, n, f) == n && fwrite(wi.data(), 4, n, f) == n && fwrite(&tr, sizeof(tr), 1, f) == 1;
+       fwrite(wt.data(), 4, n, f) == n && fwrite(wi.data(), 4, n, f) == n && fwrite(&tr, sizeof(tr), 1, f) == 1 &&
+       fwrite("SMXFLAG1", 1, 8, f) == 8 && fwrite(fl.data(), 1, n, f) == n;
   ok = (fclose(f) == 0) && ok;
   if (!ok) { ctx->err = std::string("smx_save: short write to ") + path; return -7; }
   return 0;
@@ -1350,6 +1355,8 @@ int smx_load(smx_ctx* ctx, const char* path) {
             fread(floor.data(), 8, ns, f) == ns && fread(sat.data(), 8, ns, f) == ns && fread(wf.data(), 4, n, f) == n &&
             fread(wt.data(), 4, n, f) == n && fread(wi.data(), 4, n, f) == n;
   RandTrailer tr; const bool have_rand = ok && fread(&tr, sizeof(tr), 1, f) == 1 && memcmp(tr.magic, "SMXRAND1", 8) == 0;
+  std::vector<uint8_t> fl; char fmagic[8];
+  if (have_rand && fread(fmagic, 1, 8, f) == 8 && memcmp(fmagic, "SMXFLAG1", 8) == 0) { fl.resize(n); if (fread(fl.data(), 1, n, f) != n) fl.clear(); }
   fclose(f);
   if (!ok) { ctx->err = "smx_load: truncated snapshot"; return -7; }
   {
@@ -1361,6 +1368,14 @@ int smx_load(smx_ctx* ctx, const char* path) {
   }
   if (smx_import_columns(ctx, count.data(), type.data(), size.data(), floor.data(), sat.data())) return -1;
   if (smx_import_frequency(ctx, wf.data(), wt.data(), wi.data())) return -1;
+  if (!fl.empty()) {                                         // the sticky bit on top of what the import derived from the columns
+    std::vector<uint8_t> cur(n);
+    HIPCHK(hipMemcpyAsync(cur.data(), ctx->d.flags, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t c = 0; c < n; c++) cur[c] |= (uint8_t)(fl[c] & F_SAT);
+    HIPCHK(hipMemcpyAsync(ctx->d.flags, cur.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   if (have_rand) {
     RandState r; memcpy(r.ring, tr.ring, sizeof(r.ring)); r.idx = tr.idx; r.calls = tr.calls;
     HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, ctx->stream));
@@ -1398,7 +1413,7 @@ int smx_read_heights(smx_ctx* ctx, double* out) { return read_plane(ctx, out, ct
 int smx_read_surface(smx_ctx* ctx, uint32_t* out) { return read_plane(ctx, out, ctx->ncells * 4, 1); }
 int smx_normals(smx_ctx* ctx, float* out3) { return read_plane(ctx, out3, ctx->ncells * 12, 2); }
 
-static int fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44, VCut cut) {
+static int fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, void* out_vertices44, VCut cut, long long one_cell = -1) {
   FULLMAP("smx_fill_vertices")
   if (!colors4 || ncolors <= 0 || !out_vertices44) { ctx->err = "smx_fill_vertices: colors4/out must be given"; return -2; }
   const size_t bytes = ctx->ncells * 44;
@@ -1408,6 +1423,13 @@ static int fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, vo
   }
   if (ncolors > 256) ncolors = 256;
   HIPCHK(hipMemcpyAsync(ctx->d_vcol, colors4, (size_t)ncolors * 16, hipMemcpyHostToDevice, ctx->stream));
+  if (one_cell >= 0) {                                        // one column (Layermap::update(ivec2, ...)): the block that holds it, 44 bytes back
+    cut.block0 = (unsigned)((size_t)one_cell / 256);
+    hipLaunchKernelGGL(k_fill_vertices, dim3(1), dim3(256), 0, ctx->stream, ctx->d, ctx->d_vcol, (uint32_t)ncolors, ctx->d_vtx, cut);
+    HIPCHK(hipMemcpyAsync(out_vertices44, reinterpret_cast<const char*>(ctx->d_vtx) + (size_t)one_cell * 44, 44, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
   hipLaunchKernelGGL(k_fill_vertices, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d, ctx->d_vcol,
                      (uint32_t)ncolors, ctx->d_vtx, cut);
   HIPCHK(hipMemcpyAsync(out_vertices44, ctx->d_vtx, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1424,6 +1446,14 @@ int smx_fill_vertices_cut(smx_ctx* ctx, const float* colors4, int32_t ncolors, i
   else { c.thr = cut / (double)ctx->d.scale; c.ycut = (float)cut; }                                                    // s/SCALE, vec3(p.x, s, p.y)
   return fill_vertices(ctx, colors4, ncolors, out_vertices44, c);
 }
+int smx_fill_vertex_cut(smx_ctx* ctx, const float* colors4, int32_t ncolors, int32_t mode, double cut, int32_t x, int32_t y, void* out_vertex44) {
+  if (x < 0 || y < 0 || x >= ctx->cfg.dimx || y >= ctx->cfg.dimy) { ctx->err = "smx_fill_vertex_cut: position outside the map"; return -2; }
+  VCut c;
+  c.mode = mode < 0 ? -1 : (mode ? 1 : 0); c.thr = 0.0; c.ycut = 0.f;
+  if (mode == 0) { const int sl = (int)cut; c.thr = (double)((float)sl / (float)ctx->d.scale); c.ycut = (float)sl; }
+  else if (mode > 0) { c.thr = cut / (double)ctx->d.scale; c.ycut = (float)cut; }
+  return fill_vertices(ctx, colors4, ncolors, out_vertex44, c, (long long)x * ctx->cfg.dimy + y);
+}
 
 int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out) {
   FULLMAP("smx_heights_bilinear")
@@ -1439,7 +1469,7 @@ int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out
 }
 
 // ---------------- speculative engine: host driver ----------------
-static int spec_alloc(smx_ctx* ctx, uint32_t n) {          // n = particles of the phase; it owns n + SPEC_MAXNEST slots
+static int spec_alloc(smx_ctx* ctx, uint32_t n) {          // n = particles of a sub-phase; it owns n + SPEC_MAXNEST slots
   FULLMAP("the speculative engine")
   if (ctx->spec_cap >= n) return 0;
   SpecShared& sh = ctx->sh;
@@ -1473,11 +1503,13 @@ static int spec_alloc(smx_ctx* ctx, uint32_t n) {          // n = particles of t
   return 0;
 }
 
-// One particle phase (SoilMachine.cpp:287-298 or :303-307) with the speculative engine; falls back to the serial
-// walker for whatever the speculation could not commit. Results are bit-identical either way.
-static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
-  if (n <= 0) return 0;
-  if (spec_alloc(ctx, (uint32_t)n)) return -1;
+// One SUB-PHASE of a particle phase with the speculative engine: the next `n` top-level particles of the phase, from the generator
+// state and the map as they stand. It ends when all n are committed (outcome 0), when the nested particles it has committed use up
+// the slots a sub-phase owns (outcome 1: everything committed so far stays, the caller goes on with a fresh sub-phase from the
+// continued rand() stream -- water.h:246-264 draws nested particles from the one stream, which is why the slots are finite), or
+// when the speculation cannot go on (outcome 2: no pool headroom, stalled prefix -- the caller hands the rest to the serial walker).
+// Results are bit-identical whichever way a phase is cut (tests/test_gpu_parity.py, tests/test_hostsim.py).
+static int spec_subphase(smx_ctx* ctx, int32_t n, bool wind, uint32_t* committed, int* outcome) {
   // engine mode per phase: water = blocked-filter + suspend/resume, wind = suspend/resume only (long wind particles
   // are nearly always "blocked somewhere": better to let them run up to the contested cell) -- host-sim measurements
   static const uint32_t mode_water = [] { const char* e = getenv("SMX_SPEC_MODE"); return e ? (uint32_t)atoi(e) : 3u; }();
@@ -1499,7 +1531,7 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
     else if (wind_scout) hipLaunchKernelGGL(k_spec_scout<true>, dim3((ns + L - 1) / L), dim3(64), 0, st, ctx->d, sh, L);
   }
   uint32_t np = (uint32_t)n > SPEC_WINDOW ? SPEC_WINDOW : (uint32_t)n, last_base = 0, stall = 0;
-  bool fallback = false;
+  *outcome = 0;
   static const bool trace_rounds = [] { const char* e = getenv("SMX_TRACE_ROUNDS"); return e && atoi(e) != 0; }();
   uint32_t prev_exec = 0, prev_sum = 0;
   if (trace_rounds) HIPCHK(hipStreamSynchronize(st));
@@ -1530,23 +1562,21 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
               c[SC_EXECUTED] - prev_exec, c[SC_SUM_MAXSTEPS] - prev_sum, c[SC_ABORTS], c[SC_KILLS], c[SC_SUSPENDS]);
       prev_exec = c[SC_EXECUTED]; prev_sum = c[SC_SUM_MAXSTEPS]; t_round = now;
     }
-    if (c[SC_N] == 0) { fallback = true; break; }                       // no pool headroom: nothing was executed
+    if (c[SC_N] == 0) { *outcome = 2; break; }                          // no pool headroom: nothing was executed
     if (c[SC_TOP] == (uint32_t)n) break;                                // n top-level particles committed
     np = c[SC_NPENDING];
     if (c[SC_BASE] == last_base) stall++; else { stall = 0; last_base = c[SC_BASE]; }
-    if (np == 0 || stall >= SPEC_STALL_LIMIT || c[SC_NESTED_COMMITTED] + 64 > SPEC_MAXNEST || round > 100000) { fallback = true; break; }
+    if (c[SC_NESTED_COMMITTED] + 64 > SPEC_MAXNEST) { *outcome = 1; break; }   // the sub-phase's nested slots are used up: commit, re-arm
+    if (np == 0 || stall >= SPEC_STALL_LIMIT || round > 100000) { *outcome = 2; break; }
   }
   const uint32_t* c = ctx->h_ctrl;
   ctx->spec_rounds += c[SC_ROUNDS]; ctx->spec_aborts += c[SC_ABORTS]; ctx->spec_kills += c[SC_KILLS]; ctx->spec_executed += c[SC_EXECUTED];
-  if (fallback) {
-    ctx->spec_fallbacks++;
-    const uint32_t base = (c[SC_N] == 0) ? 0u : c[SC_TOP];             // top-level particles the speculation committed
+  *committed = (c[SC_N] == 0) ? 0u : c[SC_TOP];                        // top-level particles the speculation committed
+  if (*outcome != 0) {
     if (c[SC_N] != 0) {
       hipLaunchKernelGGL(k_spec_abandon, dim3(1), dim3(64), 0, st, ctx->d, sh);
       hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(256), 0, st, ctx->d, sh, 0u);
     }
-    if (wind) hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, st, ctx->d, n - (int)base);
-    else hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, st, ctx->d, n - (int)base);
   } else {
     hipLaunchKernelGGL(k_spec_end, dim3(1), dim3(256), 0, st, ctx->d, sh, 1u);
   }
@@ -1558,6 +1588,34 @@ static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
     if (crossed) { ctx->err = "speculative phase ran past pool_capacity (pool.get() would have failed inside it): raise pool_capacity"; return -6; }
   }
   if (c[SC_RECLAIM_LOST] != 0) { ctx->err = "speculative phase: reclaim list overflow (pool nodes leaked)"; return -6; }
+  return 0;
+}
+// One particle phase (SoilMachine.cpp:287-298 or :303-307) with the speculative engine, in sub-phases of at most SPEC_SUB top-level
+// particles (round 4; round 3 gave the WHOLE rest of a phase to the one-lane serial walker as soon as 1 024 nested particles had
+// committed: 0.4 M steps/s on the headline workload). Only what the speculation cannot do at all goes to the serial walker.
+static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
+  if (n <= 0) return 0;
+  static const uint32_t SPEC_SUB = [] { const char* e = getenv("SMX_SPEC_SUB"); const int v = e ? atoi(e) : 4096; return (uint32_t)(v < 64 ? 64 : v); }();
+  if (spec_alloc(ctx, std::min<uint32_t>((uint32_t)n, SPEC_SUB))) return -1;
+  hipStream_t st = ctx->stream;
+  uint32_t remaining = (uint32_t)n;
+  auto serial = [&](uint32_t k) {                            // the reference's order on one lane, from the state as it stands
+    PhaseTimer tk(ctx, wind ? 5 : 4);
+    if (wind) hipLaunchKernelGGL(k_wind_serial, dim3(1), dim3(64), 0, st, ctx->d, (int)k);
+    else hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, st, ctx->d, (int)k);
+  };
+  while (remaining > 0) {
+    const uint32_t m = std::min(remaining, SPEC_SUB);
+    uint32_t committed = 0; int outcome = 0;
+    const int rc = spec_subphase(ctx, (int32_t)m, wind, &committed, &outcome);
+    if (rc) return rc;
+    remaining -= committed;
+    if (outcome == 0) continue;
+    ctx->spec_subphases_cut++;
+    if (outcome == 2) { ctx->spec_fallbacks++; serial(remaining); remaining = 0; }
+    else if (committed == 0) { ctx->spec_serial_particles++; serial(1u); remaining -= 1u; }   // one particle with more nested particles than a sub-phase has slots
+  }
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -2225,6 +2283,7 @@ int smx_get_counters(smx_ctx* ctx, smx_counters* out) {
   out->pool_free = ctx->cfg.pool_capacity - c[C_LIVE_SECTIONS]; out->pool_overflow = c[C_POOL_OVERFLOW];
   out->spec_rounds = ctx->spec_rounds; out->spec_aborts = ctx->spec_aborts;
   out->reserved[0] = ctx->spec_fallbacks; out->reserved[1] = ctx->spec_executed;
+  out->spec_subphases_cut = ctx->spec_subphases_cut; out->spec_serial_particles = ctx->spec_serial_particles;
   return 0;
 }
 int smx_get_timing(smx_ctx* ctx, smx_timing* out) {

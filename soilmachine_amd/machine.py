@@ -128,6 +128,14 @@ class Layermap:
             self._chk(self.L.smx_fill_vertices_cut(self.h, capi.ptr(colors), colors.shape[0], 0 if mode == "update" else 1, float(cut), capi.ptr(out)))
         return out
 
+    def vertex(self, x: int, y: int, colors: np.ndarray, cut=None, mode: str = "update") -> np.ndarray:
+        """ONE column's vertex under the same rules: Layermap::update(ivec2, Vertexpool&) (layermap.h:475-549) -> (11,) float32."""
+        colors = np.ascontiguousarray(colors, np.float32).reshape(-1, 4)
+        out = np.zeros(11, np.float32)
+        m = -1 if cut is None else (0 if mode == "update" else 1)
+        self._chk(self.L.smx_fill_vertex_cut(self.h, capi.ptr(colors), colors.shape[0], m, float(cut or 0.0), int(x), int(y), capi.ptr(out)))
+        return out
+
     def heights_bilinear(self, pos: np.ndarray) -> np.ndarray:
         pos = np.ascontiguousarray(pos, np.float32)
         out = np.zeros(pos.shape[0])

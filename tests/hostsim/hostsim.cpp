@@ -299,9 +299,11 @@ template <class F> static void parallel_for(uint32_t n, int nthreads, F f, unsig
 }
 static int g_boundary_threads = 1;
 extern "C" void hs_set_boundary_threads(int n) { g_boundary_threads = n < 1 ? 1 : n; }
+static uint32_t g_spec_sub = 4096;                          // top-level particles per sub-phase (soilmx.hip spec_phase: SPEC_SUB)
+extern "C" void hs_set_spec_sub(int n) { g_spec_sub = n < 1 ? 1u : (uint32_t)n; }
+// one sub-phase (mirrors soilmx.hip spec_subphase): returns 0 = all n committed, 1 = cut (nested slots used up), 2 = give the rest to the serial walker
 template <bool WIND>
-static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) {
-  if (n == 0) return 0;
+static int spec_subphase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned shuffle, uint32_t* stats, uint32_t* committed) {
   const DevState& s = c->d;
   SpecBuffers b; spec_setup(c, b, n);
   const SpecShared& sh = b.sh;
@@ -345,7 +347,8 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
     }
     if (sh.ctrl[SC_TOP] == n) break;
     if (sh.ctrl[SC_BASE] == last_base) stall++; else { stall = 0; last_base = sh.ctrl[SC_BASE]; }
-    if (sh.ctrl[SC_NPENDING] == 0 || stall >= SPEC_STALL_LIMIT || sh.ctrl[SC_NESTED_COMMITTED] > SPEC_MAXNEST - 64) {
+    if (sh.ctrl[SC_NESTED_COMMITTED] > SPEC_MAXNEST - 64) { fell_back = 1; break; }   // nested slots used up: commit, the caller re-arms
+    if (sh.ctrl[SC_NPENDING] == 0 || stall >= SPEC_STALL_LIMIT) {
       if (getenv("HS_TRACE")) {
         const SpecPart& q = sh.part[sh.ctrl[SC_BASE]];
         if (q.fail_cell != NOCLAIM) {
@@ -356,19 +359,39 @@ static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned s
         fprintf(stderr, "[hostsim] fallback: npending %u stall %u nested %u base %u top %u | base particle: status %u overflow %u attempts %u nlog %u nalloc %u nfree %u nested %u\n",
                 sh.ctrl[SC_NPENDING], stall, sh.ctrl[SC_NESTED_COMMITTED], sh.ctrl[SC_BASE], sh.ctrl[SC_TOP], q.status, q.overflow, q.attempts, q.nlog, q.nalloc, q.nfree, q.nested);
       }
-      fell_back = 1; break;
+      fell_back = 2; break;
     }
   }
-  if (stats) { stats[0] = sh.ctrl[SC_ROUNDS]; stats[1] = sh.ctrl[SC_ABORTS]; stats[2] = sh.ctrl[SC_KILLS]; stats[3] = (uint32_t)fell_back; stats[4] = sh.ctrl[SC_EXECUTED]; stats[5] = sh.ctrl[SC_SUM_MAXSTEPS]; }
+  if (stats) { stats[0] += sh.ctrl[SC_ROUNDS]; stats[1] += sh.ctrl[SC_ABORTS]; stats[2] += sh.ctrl[SC_KILLS]; stats[4] += sh.ctrl[SC_EXECUTED]; stats[5] += sh.ctrl[SC_SUM_MAXSTEPS]; }
+  if (sh.ctrl[SC_N] == 0) { *committed = 0; return 2; }     // no pool headroom: nothing was executed
   if (fell_back) {
     spec_abandon(s, sh);
     const uint32_t base = sh.ctrl[SC_TOP];                   // top-level particles committed so far
     spec_end(s, sh, base, sh.ctrl[SC_NESTED_COMMITTED]);
-    if (WIND) hs_wind(c, (int)(n - base)); else hs_water(c, (int)(n - base));
-    return 1;
+    *committed = base;
+    return fell_back;
   }
   spec_end(s, sh, n, sh.ctrl[SC_NESTED_COMMITTED]);
+  *committed = n;
   return 0;
+}
+// a particle phase in sub-phases of at most g_spec_sub top-level particles (mirrors soilmx.hip spec_phase); returns 1 if any part of the
+// phase went to the serial walker. stats[3] = (sub-phases cut << 16) | phases handed to the serial walker | single serial particles << 8
+template <bool WIND>
+static int spec_phase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) {
+  if (stats) for (int i = 0; i < 6; i++) stats[i] = 0;
+  uint32_t remaining = n; int any_serial = 0;
+  while (remaining > 0) {
+    const uint32_t m = remaining < g_spec_sub ? remaining : g_spec_sub;
+    uint32_t committed = 0;
+    const int outcome = spec_subphase<WIND>(c, m, nthreads, scout, shuffle, stats, &committed);
+    remaining -= committed;
+    if (outcome == 0) continue;
+    if (stats) stats[3] += 1u << 16;
+    if (outcome == 2) { if (WIND) hs_wind(c, (int)remaining); else hs_water(c, (int)remaining); remaining = 0; any_serial = 1; if (stats) stats[3] += 1u; }
+    else if (committed == 0) { if (WIND) hs_wind(c, 1); else hs_water(c, 1); remaining -= 1u; any_serial = 1; if (stats) stats[3] += 1u << 8; }
+  }
+  return any_serial;
 }
 extern "C" {
 int hs_spec_water(hs_ctx* c, int n, int nthreads, int scout, unsigned shuffle, uint32_t* stats) { return spec_phase<false>(c, (uint32_t)n, nthreads, scout, shuffle, stats); }

@@ -223,6 +223,25 @@ def test_checkpoint_on_disk_resumes_bit_exactly(engine, tmp_path):
     assert not compare(s5, golden_snapshot("default64", 5)) or engine == capi.ENGINE_BATCHED
 
 
+@pytest.mark.parametrize("engine", [capi.ENGINE_RELAXED, capi.ENGINE_BATCHED])
+def test_throughput_engine_resumes_from_a_checkpoint_with_lakes(engine, tmp_path):
+    """The sticky "has held a saturation" flag of a column is context state the column records do not carry; the throughput engines fix
+    the active set of their grid pass from it. Since round 4 smx_save writes the flag plane (trailer SMXFLAG1) and smx_load restores
+    it: a run resumed in the wet regime -- saturations come and go under the lakes -- equals the uninterrupted one, bit for bit."""
+    cfg = load_cfg("default.soil")
+    kw = dict(seed=0, nwater=250, nwind=0, dowind=False, engine=engine)
+    a = SoilMachine(cfg, 96, **kw)
+    a.tick(60, sync=True)                                        # lakes from tick ~40 at this size
+    assert a.map.counters()["floods"] > 500
+    path = str(tmp_path / "wet.smx")
+    a.map.save(path)
+    a.tick(25, sync=True)
+    b = SoilMachine(cfg, 96, **dict(kw, seed=5))
+    assert b.map.restore(path)
+    b.tick(25, sync=True)
+    assert not compare(a.map.snapshot(), b.map.snapshot())
+
+
 @pytest.mark.parametrize("mode,cut", [("update", 60), ("update", 25), ("slice", 47.5)])
 def test_vertex_stream_with_slice_cut(mode, cut):
     """smx_fill_vertices_cut = Layermap::update's SLICE rule (layermap.h:477-510) / Layermap::slice(s) (:557-613): the first
@@ -274,3 +293,15 @@ def test_vertex_stream_with_slice_cut(mode, cut):
             want[c] = [x, np.float32(SC * top), y, *nrm[c], *col, ty]
     assert ncut > 100 and nempty >= 1
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # one column at a time (smx_fill_vertex_cut = Layermap::update(ivec2, Vertexpool&), what the drop-in header's update(p, pool) calls):
+    # the same record, cut columns, the empty one and the map's last cell included
+    rng = np.random.default_rng(5)
+    cells = list(rng.integers(0, n * n, 40)) + [9 * n + 9, n * n - 1, 0, 5 * n + 5, 20 * n + 33]
+    for c in cells:
+        x, y = divmod(int(c), n)
+        one = m.vertex(x, y, colors, cut=cut, mode=mode)
+        assert np.array_equal(one.view(np.uint32), want[c].view(np.uint32)), (x, y)
+    plain = m.vertices(colors)
+    for c in cells[:8]:
+        x, y = divmod(int(c), n)
+        assert np.array_equal(m.vertex(x, y, colors).view(np.uint32), plain[c].view(np.uint32))

@@ -274,3 +274,28 @@ def test_speculative_engine_statistics_and_exactness_1024():
     for k in ("steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
               "cascade_transfers", "rand_calls"):
         assert oc[k] == c[k], k
+
+
+def test_speculative_sub_phases_replace_the_serial_fallback():
+    """Round 4: when the nested particles of a phase outnumber the slots one speculative (sub-)phase owns, the
+    sub-phase commits, ends and is re-armed from the continued rand() stream -- the rest of the phase no longer goes to the one-lane
+    serial walker. 256^2 with lakes, 4000 + 300 particles per tick (thousands of nested particles per phase): full state, counters
+    and rand() draws equal the reference-order oracle's; no serial fallback; sub-phases were in fact cut."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 256
+    o = Oracle(cfg, n, n, seed=0)
+    o.initialize()
+    for _ in range(6):
+        o.tick(cfg.NWATER, cfg.NWIND, True, True)
+    sm = SoilMachine(cfg, n, seed=0, nwater=4000, nwind=300, engine=capi.ENGINE_SPECULATIVE)
+    sm.map.load(o.snapshot(), rand_seed=0)
+    base = o.counters()
+    for t in range(2):
+        sm.tick(1, sync=True)
+        o.tick(4000, 300, True, True)
+        assert not compare(sm.map.snapshot(), o.snapshot()), f"tick {t}"
+    oc, c = o.counters(), sm.map.counters()
+    for k in ("steps_water_all", "steps_wind", "nested_particles", "floods"):
+        assert oc[k] - base[k] == c[k], k
+    assert oc["nested_particles"] - base["nested_particles"] > 2048
+    assert c["spec_fallbacks"] == 0 and c["spec_serial_particles"] == 0 and c["spec_subphases_cut"] >= 2

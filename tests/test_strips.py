@@ -16,7 +16,7 @@ from common import load_cfg
 from hostsim_lib import HostSim, HostSimStripBackend, lib
 from oracle_lib import Oracle
 from soilmachine_amd.snapshot import Snapshot, compare
-from soilmachine_amd.strips import StripGeometry, StripRank, ThreadComm, TorchComm, merge_owned, run_threads
+from strips_ref import StripGeometry, StripRank, ThreadComm, TorchComm, merge_owned, run_threads
 
 CK = ("steps_water_all", "steps_water_top", "steps_wind", "floods", "nested_particles", "cascade_calls", "cascade_transfers")
 

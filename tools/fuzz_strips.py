@@ -11,7 +11,7 @@ from common import load_cfg
 from hostsim_lib import HostSim, HostSimStripBackend, lib
 from oracle_lib import Oracle
 from soilmachine_amd.snapshot import compare
-from soilmachine_amd.strips import StripGeometry, StripRank, ThreadComm, merge_owned, run_threads
+from strips_ref import StripGeometry, StripRank, ThreadComm, merge_owned, run_threads
 CK = ("steps_water_all", "steps_water_top", "steps_wind", "floods", "nested_particles", "cascade_calls", "cascade_transfers")
 L = lib(); L.hs_set_batch_strips.argtypes = [ctypes.c_int] * 3
 soils = ["default.soil", "rockgravelpebblessand.soil", "painted.soil", "rocksand.soil", "sand.soil"]
