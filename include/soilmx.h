@@ -184,6 +184,10 @@ int smx_get_counters(smx_ctx* ctx, smx_counters* out);
 int smx_get_timing(smx_ctx* ctx, smx_timing* out);
 int smx_timing_reset(smx_ctx* ctx);
 int smx_set_engine(smx_ctx* ctx, int32_t engine);
+/* speculative engine (round 4): a particle phase runs in sub-phases of at most `particles_per_subphase` top-level particles, each owning
+ * `nested_slots` rand() slots for the nested particles its floods spawn (water.h:246-264); a sub-phase whose slots are used up commits
+ * and is re-armed from the continued stream. 0 = defaults (4096 / 8192). Results never depend on the values. */
+int smx_set_spec_limits(smx_ctx* ctx, uint32_t particles_per_subphase, uint32_t nested_slots);
 /* batched engine only: widen every reservation by `tiles` 4x4-cell tiles (0 = default; >= the map's tile count makes
  * the engine run the particles strictly one after the other, i.e. in the reference's order) */
 int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles);

@@ -99,8 +99,8 @@ constexpr int SPEC_NCTR = 9;
 constexpr uint32_t SPEC_SOLO_AFTER = 3;       // rounds without a commit after which the lowest particle runs alone
 constexpr uint32_t SPEC_STALL_LIMIT = 24;     // ... and after which the host gives the phase to the serial walker
 constexpr uint32_t SPEC_SCOUT_MARGIN = 64;    // slots past the n-th that are scouted too (they run when nested particles void lower slots)
-constexpr uint32_t SPEC_MAXNEST = 1024;        // nested particles one speculative phase can absorb (else: serial fallback);
-                                              // a phase of n particles owns n + SPEC_MAXNEST slots
+constexpr uint32_t SPEC_MAXNEST = 1024;        // default of SpecShared::maxnest: nested particles one speculative sub-phase can absorb before it
+                                              // is cut and re-armed; a sub-phase of n particles owns n + maxnest slots (<= 65535: SpecWork::nested)
 
 struct alignas(64) SpecLog {                  // undo record of one touched cell (or one modified pool node)
   uint32_t cell, prev;                        // cell index, stamp value it replaced
@@ -131,6 +131,7 @@ enum SpecCtrl { SC_NPENDING = 0, SC_BASE, SC_N, SC_NESTED_COMMITTED, SC_NODE_CUR
                 SC_NSLOTS, SC_TOP, SC_STALL, SC_SOLO, SC_HIGH, SC_POOL_CROSSED, SC_COUNT = 24 };
 
 struct SpecShared {
+  uint32_t maxnest = SPEC_MAXNEST;   // nested-particle slots of a sub-phase (host: smx SMX_SPEC_MAXNEST / hs_set_spec_maxnest)
   uint32_t* stamp;
   uint32_t* claim;
   SpecPart* part;
@@ -783,11 +784,11 @@ SMX_D void spec_begin_team(const DevState& s, const SpecShared& sh, uint32_t n, 
     // spec_end_team re-checks the live count afterwards (SC_POOL_CROSSED -> the host reports an error).
     const bool room = live + 65536ull + 512ull * n < s.pool_capacity && (unsigned long long)*s.free_count > 65536ull + 512ull * n;
     sh.ctrl[SC_N] = room ? n : 0; sh.ctrl[SC_NPENDING] = room ? ((n > SPEC_WINDOW) ? SPEC_WINDOW : n) : 0;
-    sh.ctrl[SC_NSLOTS] = n + SPEC_MAXNEST;
+    sh.ctrl[SC_NSLOTS] = n + sh.maxnest;
     sh.ctrl[SC_HIGH] = (n > SPEC_WINDOW) ? SPEC_WINDOW : n;
     sh.ctrl[SC_NFREE_START] = *s.free_count;
   }
-  for (uint32_t p = tid; p < n + SPEC_MAXNEST; p += nt) {  // one record per SLOT (n particles + the nested ones' slots)
+  for (uint32_t p = tid; p < n + sh.maxnest; p += nt) {  // one record per SLOT (n particles + the nested ones' slots)
     SpecPart& q = sh.part[p];
     q.status = ST_PENDING; q.kill = 0; q.aborted = 0; q.fail_cell = NOCLAIM; q.noff = 0; q.nested = 0; q.nlog = 0;
     q.nchunks = 0; q.ndeps = 0; q.dep_overflow = 0; q.nalloc = 0; q.nfree = 0; q.overflow = 0; q.attempts = 0; q.nnode = 0;

@@ -894,6 +894,7 @@ struct smx_ctx {
   std::vector<EvPair> pending;
   std::vector<hipEvent_t> evpool;
   smx_timing timing{};
+  uint32_t spec_sub = 0, spec_maxnest = 0; bool spec_realloc = false;   // smx_set_spec_limits (0 = defaults)
   uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0, spec_subphases_cut = 0, spec_serial_particles = 0;
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
@@ -1086,6 +1087,13 @@ int smx_set_soils(smx_ctx* ctx, const smx_soil* soils, int32_t n) {
 }
 int smx_set_scale(smx_ctx* ctx, int32_t scale) { ctx->d.scale = scale; ctx->cfg.scale = scale; return 0; }
 int smx_set_engine(smx_ctx* ctx, int32_t engine) { ctx->cfg.engine = engine; return 0; }
+// speculative engine: top-level particles per sub-phase / nested-particle slots of a sub-phase (0 = default: 4096 / 8192). Tests use
+// small values to drive the sub-phase hand-over; results never depend on them.
+int smx_set_spec_limits(smx_ctx* ctx, uint32_t particles_per_subphase, uint32_t nested_slots) {
+  if (nested_slots && (nested_slots < 128u || nested_slots > 60000u)) { ctx->err = "smx_set_spec_limits: nested_slots must lie in [128, 60000]"; return -2; }
+  ctx->spec_sub = particles_per_subphase ? std::max(64u, particles_per_subphase) : 0u; ctx->spec_maxnest = nested_slots; ctx->spec_realloc = true;
+  return 0;
+}
 // Column strips need every reservation to fit between the inset and the seam half-width (soil_batch.h BStrips), or a particle
 // near a boundary is eligible in neither kind of chunk and the phase never ends. Widest reservations of batch_schedule:
 // water 3 tiles of 4 cells, wind 3 tiles of 4 / 2 tiles of 8, each plus the margin on both sides.
@@ -1471,7 +1479,8 @@ int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out
 // ---------------- speculative engine: host driver ----------------
 static int spec_alloc(smx_ctx* ctx, uint32_t n) {          // n = particles of a sub-phase; it owns n + SPEC_MAXNEST slots
   FULLMAP("the speculative engine")
-  if (ctx->spec_cap >= n) return 0;
+  if (ctx->spec_cap >= n && !ctx->spec_realloc) return 0;
+  ctx->spec_realloc = false;
   SpecShared& sh = ctx->sh;
   if (ctx->spec_cap) {
     hipFree(sh.part); hipFree(sh.chunk_tab); hipFree(sh.arena); hipFree(sh.alloc_log); hipFree(sh.free_log);
@@ -1486,7 +1495,12 @@ static int spec_alloc(smx_ctx* ctx, uint32_t n) {          // n = particles of a
     HIPCHK(hipHostMalloc(&ctx->h_ctrl, SC_COUNT * 4));
   }
   const uint32_t cap = n < 1024 ? 1024 : n;                 // particles
-  const uint32_t slots = cap + SPEC_MAXNEST;                // per-slot records (soil_spec.h "rand() SLOTS")
+  // nested-particle slots of a sub-phase: 8192 on the device (21 KB of per-slot records each: 170 MB). With the 1 024 of round 3 a
+  // sub-phase of 4 096 particles at the headline's density was cut -- everything in flight rolled back on one lane and run again --
+  // after ~650 committed particles (profiles/r04_exact_subphases.md)
+  static const uint32_t maxnest = [] { const char* e = getenv("SMX_SPEC_MAXNEST"); const int v = e ? atoi(e) : 8192; return (uint32_t)(v < 128 ? 128 : (v > 60000 ? 60000 : v)); }();
+  sh.maxnest = ctx->spec_maxnest ? ctx->spec_maxnest : maxnest;
+  const uint32_t slots = cap + sh.maxnest;                  // per-slot records (soil_spec.h "rand() SLOTS")
   HIPCHK(hipMalloc(&sh.part, (size_t)slots * sizeof(SpecPart)));
   HIPCHK(hipMalloc(&sh.chunk_tab, (size_t)slots * MAX_CHUNKS * 4));
   sh.arena_chunks = cap * 32u < 16384u ? 16384u : cap * 32u;
@@ -1566,7 +1580,7 @@ static int spec_subphase(smx_ctx* ctx, int32_t n, bool wind, uint32_t* committed
     if (c[SC_TOP] == (uint32_t)n) break;                                // n top-level particles committed
     np = c[SC_NPENDING];
     if (c[SC_BASE] == last_base) stall++; else { stall = 0; last_base = c[SC_BASE]; }
-    if (c[SC_NESTED_COMMITTED] + 64 > SPEC_MAXNEST) { *outcome = 1; break; }   // the sub-phase's nested slots are used up: commit, re-arm
+    if (c[SC_NESTED_COMMITTED] + 64 > sh.maxnest) { *outcome = 1; break; }   // the sub-phase's nested slots are used up: commit, re-arm
     if (np == 0 || stall >= SPEC_STALL_LIMIT || round > 100000) { *outcome = 2; break; }
   }
   const uint32_t* c = ctx->h_ctrl;
@@ -1595,7 +1609,8 @@ static int spec_subphase(smx_ctx* ctx, int32_t n, bool wind, uint32_t* committed
 // committed: 0.4 M steps/s on the headline workload). Only what the speculation cannot do at all goes to the serial walker.
 static int spec_phase(smx_ctx* ctx, int32_t n, bool wind) {
   if (n <= 0) return 0;
-  static const uint32_t SPEC_SUB = [] { const char* e = getenv("SMX_SPEC_SUB"); const int v = e ? atoi(e) : 4096; return (uint32_t)(v < 64 ? 64 : v); }();
+  static const uint32_t SPEC_SUB_ENV = [] { const char* e = getenv("SMX_SPEC_SUB"); const int v = e ? atoi(e) : 4096; return (uint32_t)(v < 64 ? 64 : v); }();
+  const uint32_t SPEC_SUB = ctx->spec_sub ? ctx->spec_sub : SPEC_SUB_ENV;
   if (spec_alloc(ctx, std::min<uint32_t>((uint32_t)n, SPEC_SUB))) return -1;
   hipStream_t st = ctx->stream;
   uint32_t remaining = (uint32_t)n;

@@ -232,8 +232,11 @@ struct SpecBuffers {
   std::vector<uint32_t> draws;
   SpecShared sh;
 };
+static uint32_t g_spec_maxnest = SPEC_MAXNEST;
+extern "C" void hs_set_spec_maxnest(int n) { g_spec_maxnest = n < 128 ? 128u : (uint32_t)n; }
 static void spec_setup(hs_ctx* c, SpecBuffers& b, uint32_t nparticles) {
-  const uint32_t n = nparticles + SPEC_MAXNEST;             // one record per slot
+  b.sh.maxnest = g_spec_maxnest;
+  const uint32_t n = nparticles + b.sh.maxnest;             // one record per slot
   b.stamp.assign(c->n, 0); b.claim.assign(c->n, NOCLAIM);
   b.part.resize(n); b.chunk_tab.assign((size_t)n * MAX_CHUNKS, 0);
   const uint32_t arena_chunks = std::max<uint32_t>(4096, nparticles * 64);
@@ -347,7 +350,7 @@ static int spec_subphase(hs_ctx* c, uint32_t n, int nthreads, int scout, unsigne
     }
     if (sh.ctrl[SC_TOP] == n) break;
     if (sh.ctrl[SC_BASE] == last_base) stall++; else { stall = 0; last_base = sh.ctrl[SC_BASE]; }
-    if (sh.ctrl[SC_NESTED_COMMITTED] > SPEC_MAXNEST - 64) { fell_back = 1; break; }   // nested slots used up: commit, the caller re-arms
+    if (sh.ctrl[SC_NESTED_COMMITTED] > sh.maxnest - 64) { fell_back = 1; break; }   // nested slots used up: commit, the caller re-arms
     if (sh.ctrl[SC_NPENDING] == 0 || stall >= SPEC_STALL_LIMIT) {
       if (getenv("HS_TRACE")) {
         const SpecPart& q = sh.part[sh.ctrl[SC_BASE]];

@@ -288,6 +288,7 @@ def test_speculative_sub_phases_replace_the_serial_fallback():
     for _ in range(6):
         o.tick(cfg.NWATER, cfg.NWIND, True, True)
     sm = SoilMachine(cfg, n, seed=0, nwater=4000, nwind=300, engine=capi.ENGINE_SPECULATIVE)
+    sm.map._chk(sm.map.L.smx_set_spec_limits(sm.map.h, 0, 1024))       # round 3's slot budget: forces the hand-over (default: 8192)
     sm.map.load(o.snapshot(), rand_seed=0)
     base = o.counters()
     for t in range(2):

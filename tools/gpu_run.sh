@@ -68,6 +68,7 @@ for s in "$@"; do
                  run pmcwet$i 40 300 env SMX_WET_N=5 rocprofv3 --pmc $set --output-format csv -d $out/pmcwet$i -o p -- python tools/gpu_wet_exact.py --one ${ENGINE:-serial}
                  python tools/pmc_by_kernel.py $out/pmcwet$i | tee $out/pmcwet$i.summary
                done ;;
+    exacttrace) run exacttrace 60 600 env SMX_TRACE_ROUNDS=1 python bench.py --only exact_area_scaled; grep 'round' $out/exacttrace.err | head -400 > $out/exacttrace.rounds; grep -c round $out/exacttrace.err; rm -f $out/exacttrace.err ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
     envelope)  run envelope 60 900 python tools/p2_envelope.py --size ${ESIZE:-1024} --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts ${ECOUNTS:-area} ;;
     envelope4096) run envelope4096 60 600 python tools/p2_envelope.py --size 4096 --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts file ;;
