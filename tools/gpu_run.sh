@@ -69,6 +69,9 @@ for s in "$@"; do
                  python tools/pmc_by_kernel.py $out/pmcwet$i | tee $out/pmcwet$i.summary
                done ;;
     exacttrace) run exacttrace 60 600 env SMX_TRACE_ROUNDS=1 python bench.py --only exact_area_scaled; grep 'round' $out/exacttrace.err | head -400 > $out/exacttrace.rounds; grep -c round $out/exacttrace.err; rm -f $out/exacttrace.err ;;
+    exactk)    run exactk 60 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/exactk -o t -- python bench.py --only exact_area_scaled
+               python tools/kernel_stats.py $out/exactk | tee $out/exactk.kernels; python tools/trace_gaps.py $out/exactk | tee $out/exactk.summary; rm -rf $out/exactk ;;
+    exactmode2) run exactmode2 60 600 env SMX_SPEC_MODE=2 python bench.py --only exact_area_scaled ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
     envelope)  run envelope 60 900 python tools/p2_envelope.py --size ${ESIZE:-1024} --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts ${ECOUNTS:-area} ;;
     envelope4096) run envelope4096 60 600 python tools/p2_envelope.py --size 4096 --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts file ;;
