@@ -18,7 +18,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
   * every line carries the state digest after its timed region (section count, type hash, sum of heights, rand() draws).
   * "roofline": algorithmic bytes of the dominant kernel / its HIP-event duration (events on the library's own stream,
     bracketing nothing but launches of that kernel) vs the 8 TB/s HBM peak; "phases" gives the same for the O(cells)
-    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r03_pmc.json), labelled as such.
+    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r04_pmc.json), labelled as such.
   * "cpu_baseline": the reference's own CPU loop (oracle/_ref/soil_ref_lean = the unmodified reference headers,
     render-only Layermap::update elided) timed on this box's host: 1 core on a bounded sample of the headline
     workload, and an all-cores line (independent processes, different SEEDs -- the reference has no threads).
@@ -56,10 +56,15 @@ def host_cpu_model() -> str:
     return ""
 
 
-def run_ref_lean(soil: str, size: int, nwater: int, nwind: int, seed: int, ticks: int, pool: int, core: int | None, exe_name: str = "soil_ref_lean"):
+def run_ref_lean(soil: str, size: int, nwater: int, nwind: int, seed: int, ticks: int, pool: int, core: int | None, exe_name: str = "soil_ref_lean",
+                 load: str | None = None, rand_seed: int | None = None):
     exe = os.path.join(ROOT, "oracle", "_ref", exe_name)
     cmd = [exe, "--soil", os.path.join(ROOT, "soilmachine_amd", "soils", soil), "--seed", str(seed), "--size", str(size),
            "--ticks", str(ticks), "--nwater", str(nwater), "--nwind", str(nwind), "--pool", str(pool)]
+    if load:
+        cmd += ["--load", load]                                  # continue from a state written by smx_save (oracle/ref_driver.cpp --load)
+    if rand_seed is not None:
+        cmd += ["--rand-seed", str(rand_seed)]
     if core is not None:
         cmd = ["taskset", "-c", str(core)] + cmd
     return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
@@ -72,72 +77,80 @@ def parse_ref(out: str):
     return None
 
 
-def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool: int, all_cores: bool) -> dict | None:
-    """Time the reference's own CPU path on this host (bounded sample). Test/bench infrastructure only.
+def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool: int, all_cores: bool, load: str | None = None, tick0: int = 0,
+                 gpu_same_tick: dict | None = None) -> dict | None:
+    """Time the reference's own CPU path on this host. Test/bench infrastructure only.
+    load = a checkpoint of the GPU line's state after its warm-up (smx_save): the CPU then runs the SAME tick(s) the GPU line times first,
+    at the SAME particle counts. Without it: a bounded sample from the initial terrain.
     The unmodified reference can only count TOP-LEVEL steps (nested particles run inside WaterParticle::cascade):
     cpu value = top-level steps/s, to be compared with the GPU line's `value_top_level` (same definition)."""
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean")):
         return None
     t0 = time.time()
-    p = run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, 0)
+    p = run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, 0, load=load)
     j = parse_ref(p.communicate()[0])
     if j is None:
-        p = run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, None)
+        p = run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, None, load=load)
         j = parse_ref(p.communicate()[0])
     if j is None:
         return None
     wall = time.time() - t0
     t_tick = j["t_water"] + j["t_grid"] + j["t_wind"] + j["t_freq"]
     steps = j["steps_water_top"] + j["steps_wind"]
+    window = (f"tick(s) {tick0 + 1}..{tick0 + ticks} continued from the state the GPU line's {tick0} warm-up ticks produced (smx_save -> ref_driver --load): the same state, "
+              f"the same counts and the first tick(s) of the GPU line's timed window") if load else f"{ticks} tick(s) from the initial terrain"
     out = {
         "value": steps / t_tick if t_tick > 0 else None, "unit": "particle-steps/s", "cores": 1, "kind": "reference",
-        "sample": f"{ticks} tick(s) of {size}x{size}, {soil}, nwater={nwater}, nwind={nwind}, SEED 0 with oracle/_ref/soil_ref_lean "
+        "sample": f"{window}; {size}x{size}, {soil}, nwater={nwater}, nwind={nwind} with oracle/_ref/soil_ref_lean "
                   f"(the reference's own headers, render-only Layermap::update elided), 1 thread pinned; steps = TOP-LEVEL "
                   f"move()==true (nested particles are not countable in the unmodified reference): compare with the GPU "
                   f"line's value_top_level; whole tick in the denominator",
         "ms_per_tick": 1e3 * t_tick / ticks, "ms_water": 1e3 * j["t_water"] / ticks, "ms_grid": 1e3 * j["t_grid"] / ticks,
         "ms_wind": 1e3 * j["t_wind"] / ticks, "ms_freq": 1e3 * j["t_freq"] / ticks,
         "particle_phase_steps_per_s": steps / max(j["t_water"] + j["t_wind"], 1e-9),
-        "steps_per_tick": steps / ticks, "host_cpu": host_cpu_model(), "host_cores_total": os.cpu_count(), "wall_s": wall,
+        "steps_per_tick": steps / ticks, "nested_per_tick": j.get("nested", 0) / ticks, "host_cpu": host_cpu_model(), "host_cores_total": os.cpu_count(), "wall_s": wall,
         "init_s": j["t_init"],
     }
-    out["regime_note"] = ("NOT the GPU line's tick window: the CPU sample is tick 1 of a dry map at reduced particle counts (its O(cells) grid "
-                          "pass over a dry map dominates ms_per_tick), the GPU line times later ticks at the full counts. particle-steps/s of "
-                          "the particle phases (particle_phase_steps_per_s) does not depend on the count and is the like-for-like figure; "
-                          "ms_per_tick is not comparable. tools/wet_regime.py times CPU and GPU over the same window where that fits a run.")
+    if gpu_same_tick:
+        out["gpu_same_tick"] = gpu_same_tick                      # the GPU line's own record of that tick (ms, steps)
+    if not load:
+        out["regime_note"] = ("NOT the GPU line's tick window: a bounded sample from the initial terrain (dry map: the O(cells) grid pass dominates ms_per_tick); "
+                              "particle_phase_steps_per_s is the like-for-like figure")
+    procs = []
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref")):   # SURVEY 8d "as-is": Layermap::update's render work kept (layermap.h:475-549)
-        p = run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, 0, "soil_ref")
-        ja = parse_ref(p.communicate()[0])
-        if ja is not None:
-            ta = ja["t_water"] + ja["t_grid"] + ja["t_wind"] + ja["t_freq"]
-            out["as_is"] = {"value": (ja["steps_water_top"] + ja["steps_wind"]) / ta if ta > 0 else None, "unit": "particle-steps/s", "cores": 1, "kind": "reference",
-                            "sample": "the same sample with oracle/_ref/soil_ref: the reference's headers UNCHANGED, Layermap::update(ivec2, Vertexpool&) doing its "
-                                      "render-side work after every edit as in the real application",
-                            "ms_per_tick": 1e3 * ta / ticks, "ms_water": 1e3 * ja["t_water"] / ticks, "ms_grid": 1e3 * ja["t_grid"] / ticks, "ms_wind": 1e3 * ja["t_wind"] / ticks}
+        procs.append(("as_is", run_ref_lean(soil, size, nwater, nwind, 0, ticks, pool, 0, "soil_ref", load=load)))
+    nproc = 0
+    t1 = time.time()
     if all_cores:
-        # the reference is single-threaded: "all cores" = independent processes with different SEEDs (SURVEY.md 8d),
-        # as many as fit the box's memory (each holds its own 4096^2 layermap + POOLSIZE)
+        # the reference is single-threaded: "all cores" = independent processes (SURVEY.md 8d), as many as fit the box's memory (each holds
+        # its own layermap + POOLSIZE): other SEEDs from the initial terrain, or -- from a checkpoint -- the same state under other rand() streams
         ncpu = os.cpu_count() or 1
         try:
             mem_gb = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2**30
         except (ValueError, OSError):
             mem_gb = 64.0
-        per_proc_gb = (pool * 56 + size * size * 24) / 2**30 + 0.5
-        nproc = int(max(1, min(ncpu, 32, (0.5 * mem_gb) // per_proc_gb)))
-        t1 = time.time()
-        procs = [run_ref_lean(soil, size, nwater, nwind, s, ticks, pool, s % ncpu) for s in range(nproc)]
-        js = [parse_ref(q.communicate()[0]) for q in procs]
-        js = [x for x in js if x is not None]
-        if js:
-            agg = sum((x["steps_water_top"] + x["steps_wind"]) /
-                      max(x["t_water"] + x["t_grid"] + x["t_wind"] + x["t_freq"], 1e-9) for x in js)
-            out["all_cores"] = {"value": agg, "unit": "particle-steps/s (sum over independent processes)", "cores": len(js),
-                                "note": f"{len(js)} independent soil_ref_lean processes (SEED 0..{len(js) - 1}), one pinned core each, "
-                                        f"same bounded sample; the reference has no threads", "wall_s": time.time() - t1}
+        per_proc_gb = (pool * 56 + size * size * 60) / 2**30 + 0.5
+        nproc = int(max(1, min(ncpu - 1, 32, (0.5 * mem_gb) // per_proc_gb)))
+        for q in range(nproc):
+            procs.append(("all", run_ref_lean(soil, size, nwater, nwind, 0 if load else q, ticks, pool, (q + 1) % ncpu, load=load, rand_seed=(5000 + q) if (load and q) else None)))
+    js = [(k, parse_ref(q.communicate()[0])) for k, q in procs]
+    for k, ja in js:
+        if k == "as_is" and ja is not None:
+            ta = ja["t_water"] + ja["t_grid"] + ja["t_wind"] + ja["t_freq"]
+            out["as_is"] = {"value": (ja["steps_water_top"] + ja["steps_wind"]) / ta if ta > 0 else None, "unit": "particle-steps/s", "cores": 1, "kind": "reference",
+                            "sample": "the same sample with oracle/_ref/soil_ref: the reference's headers UNCHANGED, Layermap::update(ivec2, Vertexpool&) doing its "
+                                      "render-side work after every edit as in the real application" + (" (timed while the all-cores processes run)" if nproc else ""),
+                            "ms_per_tick": 1e3 * ta / ticks, "ms_water": 1e3 * ja["t_water"] / ticks, "ms_grid": 1e3 * ja["t_grid"] / ticks, "ms_wind": 1e3 * ja["t_wind"] / ticks}
+    ja = [x for k, x in js if k == "all" and x is not None]
+    if ja:
+        agg = sum((x["steps_water_top"] + x["steps_wind"]) / max(x["t_water"] + x["t_grid"] + x["t_wind"] + x["t_freq"], 1e-9) for x in ja)
+        out["all_cores"] = {"value": agg, "unit": "particle-steps/s (sum over independent processes)", "cores": len(ja),
+                            "note": f"{len(ja)} independent soil_ref_lean processes, one pinned core each, the same sample"
+                                    f"{' under other rand() streams' if load else ' (SEED 0..' + str(len(ja) - 1) + ')'}; the reference has no threads", "wall_s": time.time() - t1}
     return out
 
 
-def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None, rand_seed=None, keep_heights=False):
+def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None, rand_seed=None, keep_heights=False, save_after_warmup=None):
     """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers).
     rand_seed: re-seed the libc stream after the terrain is built (same map, another rand() stream: the parity control)."""
     from soilmachine_amd.machine import SoilMachine
@@ -146,6 +159,11 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
     if rand_seed is not None:
         m._chk(m.L.smx_srand(m.h, int(rand_seed)))
     sm.tick(warmup, sync=True)
+    if save_after_warmup:                                       # the state the timed window starts from: what cpu_baseline continues (outside the timed region)
+        try:
+            m.save(save_after_warmup)
+        except Exception:
+            save_after_warmup = None
     c0 = m.counters()
     b0 = m.batch_stats()
     m.timing_reset()
@@ -351,6 +369,7 @@ def main():
 
     strips = world > 1 and throughput
     dimx = n
+    ckpt = None
     if strips:
         # ONE map in `world` column strips. Default (weak scaling): the map grows with N -- every GPU owns a size x size strip of
         # a (N*size) x size map and its share of N x the particles, i.e. per-GPU work is what the N=1 line measures. --strong
@@ -360,7 +379,11 @@ def main():
             pool = max(10_000_000, 3 * dimx * n)
         r = measure_strips(cfg, dimx, n, nwater, nwind, pool, local_rank, args.steps, args.warmup, dist, barrier, torch, engine)
     else:
-        r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier)
+        want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean"))
+        ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"soilmx_bench_{os.getpid()}.smx") if want_cpu else None
+        r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier, save_after_warmup=ckpt)
+        if ckpt and not os.path.exists(ckpt):
+            ckpt = None
     steps = r["steps_w"] + r["steps_d"]
     dev = torch.device("cuda", local_rank) if (torch.cuda.is_available() and (dist is None or dist.get_backend() == "nccl")) else torch.device("cpu")
     tmax, total_steps = distrib.aggregate(dist, r["dt"], steps, dev)
@@ -391,11 +414,11 @@ def main():
         traffic, traffic_src = None, ("not collected in this process: rocprofv3 --pmc runs as its own job (tools/gpu_run.sh pmc); no committed pass "
                                       "matches this workload string")
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
             k = pmc.get("kernels", {}).get(kn.split(" ")[0])
             if k and pmc.get("workload") == f"{n}/{nwater}/{nwind}/{eng_name}":
                 traffic = k["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r03_pmc.json (separate rocprofv3 --pmc passes of this command on the same box type, not measured in this run)"
+                traffic_src = "profiles/r04_pmc.json (separate rocprofv3 --pmc passes of this command on the same box type, not measured in this run)"
         except (OSError, ValueError, KeyError):
             pass
         ncells = n * n
@@ -431,7 +454,7 @@ def main():
                     f"tick = water + grid pass + wind + frequency")
         head = line_of(r, "headline", workload, eng_name, args.steps)
         lines = [strips4] if strips4 else []
-        parity = None
+        parity = pref = None
         if not args.no_lines and world == 1:
             k3, w3 = max(2, min(args.steps, 3)), max(1, min(args.warmup, 2))
             dcfg = loadsoil(os.path.join(ROOT, "soilmachine_amd", "soils", "default.soil"))
@@ -440,7 +463,7 @@ def main():
             extra = []   # name, cfg, soil, size, nwater, nwind, engine, pool, steps, warmup, workload, in the default run?
             if throughput:
                 # the bit-exact engine on the HEADLINE's workload (same map, same counts): what parity-green throughput is today
-                # (82 s per tick at 4096^2 / 64 000 + 16 000: measured once, profiles/r03_exact_area_scaled_4096.json; --full or --only re-measures it)
+                # (37 s per tick at 4096^2 / 64 000 + 16 000: measured once, profiles/r04_exact_area_scaled_4096.json; --full or --only re-measures it)
                 extra.append(("exact_area_scaled", cfg, soil, n, nwater, nwind, "spec", pool, 1, 1, workload, False))
                 other = "batched" if eng_name == "relaxed" else "relaxed"
                 extra.append((f"{other}_area_scaled", cfg, soil, n, nwater, nwind, other, pool, k3, w3, workload, True))
@@ -478,6 +501,15 @@ def main():
                     parity["larger_maps"] = "profiles/r03_p2_envelope_1024.json (tools/p2_envelope.py on the MI355X)"
                 except Exception as e:
                     parity = {"error": str(e)}
+                # ... and against THE REFERENCE (oracle/_ref/soil_ref_lean on this box's host cores), eight control streams, z-scores: 1024^2 at the
+                # headline's particle density, ticks 1-10 (~25 s; the record at the headline's own size and counts: profiles/r04_p2_reference_4096.json)
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import p2_reference
+                    pref = p2_reference.run(soil, 1024, 10, 8, eng_name, device=local_rank, verbose=False)
+                    pref["headline_size_record"] = "profiles/r04_p2_reference_4096.json (tools/p2_reference.py --size 4096 --ticks 10 --nctl 16 on the MI355X box)"
+                except Exception as e:
+                    pref = {"error": str(e)}
         if args.only is not None:
             print(json.dumps(lines[0] if lines else {"error": f"no line named {args.only}"}), flush=True)
             if dist is not None:
@@ -491,9 +523,14 @@ def main():
                 lbm = {"error": str(e)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:             # (rank 0 at N=1 only: the other ranks would wait at the barrier for it)
-            # bounded sample: an eighth of the headline's particle counts for one tick (CPU steps/s does not depend on the count)
-            cw, cd = (max(nwater // 8, 1000), max(nwind // 8, 250 if nwind else 0)) if nwater > 8000 else (nwater, nwind)
-            cpu = cpu_baseline(soil, n, cw, cd, args.cpu_ticks, pool, all_cores=True)
+            # the SAME tick the timed window starts with, from the SAME state (the checkpoint measure() wrote after the warm-up), at the SAME
+            # counts: ~25 s of one core at 4096^2 / 64 000 + 16 000. Fallback (no checkpoint): a bounded sample from the initial terrain.
+            if ckpt:
+                pt0 = (r.get("per_tick") or [None])[0]
+                cpu = cpu_baseline(soil, n, nwater, nwind, args.cpu_ticks, pool, all_cores=True, load=ckpt, tick0=args.warmup, gpu_same_tick=pt0)
+            else:
+                cw, cd = (max(nwater // 8, 1000), max(nwind // 8, 250 if nwind else 0)) if nwater > 8000 else (nwater, nwind)
+                cpu = cpu_baseline(soil, n, cw, cd, args.cpu_ticks, pool, all_cores=True)
         p2 = "P2: deterministic, statistical vs the reference (parity_vs_exact; never claimed bit-exact)"
         out = {
             "metric": "particle-steps/s", "value": total_steps / tmax, "unit": "particle-steps/s", "n_gpus": world,
@@ -505,21 +542,26 @@ def main():
                                         "weak: one (N*size) x size map, every GPU owns a size x size strip and 1/N of N x the particles "
                                         "(per-GPU work = the N=1 line)") if strips else "independent replicas (exact engines do not shard)"),
                        "parity": p2 if throughput else head["parity"],
-                       "bit_exact_on_this_workload": {"engine": "speculative (bit-identical to the reference)", "value": 878861.5, "unit": "particle-steps/s", "ms_per_tick": 82287.6,
-                                                      "source": "profiles/r03_exact_area_scaled_4096.json (bench.py --only exact_area_scaled on the MI355X; 3 min per run, "
-                                                                "so not part of the default bench)"} if (throughput and n == 4096 and nwater == 64000 and soil == SOIL) else None},
+                       "bit_exact_on_this_workload": {"engine": "speculative (bit-identical to the reference)", "value": 1965543.4, "unit": "particle-steps/s", "ms_per_tick": 36793.6,
+                                                      "source": "profiles/r04_exact_area_scaled_4096.json (bench.py --only exact_area_scaled on the MI355X: sub-phases, no serial "
+                                                                "fallback; 75 s per run, so not part of the default bench; round 3: 82 288 ms)"} if (throughput and n == 4096 and nwater == 64000 and soil == SOIL) else None},
             "value_top_level": head["value_top_level"] if world == 1 else None,
             "steps_definition": "value: move()==true + interact(), top-level AND nested particles; value_top_level: top-level only "
                                 "(what cpu_baseline can count)",
             "ms_per_tick": 1e3 * tmax / args.steps, "phase_ms_per_tick": head["phase_ms_per_tick"],
             "per_tick": r.get("per_tick"),
             "steps_per_tick": head["steps_per_tick"], "engine_stats": head["engine_stats"], "digest": head["digest"],
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_exact": parity, "lines": lines, "lbm_wind": lbm,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_exact": parity, "parity_vs_reference": pref, "lines": lines, "lbm_wind": lbm,
             # nothing was dropped inside the timed region (nested particles that did not fit the children buffer, sediment
             # that found no pool node): a line with work skipped would not be a measurement
             "work_dropped": {"children_lost": int(head["engine_stats"].get("children_lost", 0)), "pool_overflow": int(head.get("pool_overflow") or 0)},
         }
         print(json.dumps(out), flush=True)
+    try:
+        if not strips and ckpt:
+            os.remove(ckpt)
+    except (OSError, NameError):
+        pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -425,7 +425,7 @@ struct BatchBuffers {
 static int g_relaxed = 0;                                   // 1: particle phases run the relaxed schedule (SMX_ENGINE_RELAXED)
 static uint32_t g_relax_wind_min = 0xFFFFFFFFu;                   // wind: relaxed while more particles than this run ...
 static int g_relax_wind_steps = 4;                          // ... taking up to this many steps per epoch (smx_set_relax_wind)
-static uint32_t g_relax_tag = 0;
+static std::atomic<uint32_t> g_relax_tag{0};   // (atomic: several HostSim instances may tick on different threads of one process, tools/p2_ensemble.py)
 extern "C" void hs_set_relaxed(int on) { g_relaxed = on; }
 static int g_relax_water_steps = 1;                         // relaxed water: steps per epoch (smx_set_relax_water)
 extern "C" void hs_set_flood_rule(int r) { g_hs_flood_rule = r; }   // experiments: see soil_relax.h relax_floods_due
@@ -523,7 +523,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
           for (uint32_t i = 0; i < nslots; i++) relax_flood_later(bs, i, epoch & 1u, b.water[i].state == B_ENDED);
         }
         for (int k = 0; k < chunk_epochs; k++, epoch++) {
-          b.bs.rtag = ++g_relax_tag; if (b.bs.rtag == 0u) b.bs.rtag = ++g_relax_tag;
+          b.bs.rtag = g_relax_tag.fetch_add(1u) + 1u; if (b.bs.rtag == 0u) b.bs.rtag = g_relax_tag.fetch_add(1u) + 1u;
           parallel_for(nlive, nthreads, [&](uint32_t i) {                                       // k_relax_step
             BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
             if (wind) relax_wind_step(sim, bs, bs.live[i], epoch); else relax_water_step(sim, bs, bs.live[i], epoch);
