@@ -692,8 +692,7 @@ struct so_ctx {
   uint32_t b_cell_above = 0xFFFFFFFFu;            // water reserves single cells while more particles than this run (tests lower it)
   void b_schedule(bool wind, uint32_t nlive, int base, int& tshift, int& dilate, int& maxsteps) const {
     if (wind) {
-      tshift = 2; dilate = 1; maxsteps = 8;
-      if (nlive <= 4096u) { tshift = 3; dilate = 1; maxsteps = 32; }
+      tshift = 2; dilate = 1; maxsteps = 32;                  // (round 4: one schedule at every particle count, soil_batch.h batch_schedule)
     } else {
       tshift = 2; dilate = 0; maxsteps = 4;
       if (nlive > b_cell_above) { tshift = 0; maxsteps = 1; }

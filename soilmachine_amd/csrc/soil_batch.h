@@ -530,8 +530,12 @@ struct BSched { int tshift, dilate, maxsteps; };
 SMX_HD BSched batch_schedule(bool wind, uint32_t nlive, int base_dilate, uint32_t fine_above = 0xFFFFFFFFu) {
   BSched k;
   if (wind) {
-    k.tshift = 2; k.dilate = 1; k.maxsteps = 8;
-    if (nlive <= 4096u) { k.tshift = 3; k.dilate = 1; k.maxsteps = 32; }
+    // round 4 (profiles/r04_wind_schedule.md, swept on the device): 4x4-cell tiles with one tile of margin and up to 32 actions per epoch at
+    // EVERY particle count. Round 2's schedule (8 actions, and 8x8-cell tiles / 32 actions below 4 096 running particles) cost 206-220 ms of
+    // wind phase on the headline workload, this one 139 ms: larger tiles and margins only add contention; how many actions fit an epoch
+    // is bounded by the geometry (a wind particle leaves a 12-cell reservation after ~6 steps), not by the limit.
+    k.tshift = 2; k.dilate = 1; k.maxsteps = 32;
+    (void)nlive;
   } else {
     k.tshift = 2; k.dilate = 0; k.maxsteps = 4;
     if (nlive > fine_above) { k.tshift = 0; k.maxsteps = 1; }

@@ -1744,8 +1744,9 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     static const char* ew = getenv("SMX_BATCH_SCHED"); static const char* ed = getenv("SMX_BATCH_SCHED_WIND");
     const char* e = wind ? ed : ew; int a, d, k;
     if (e && sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; }
-    static const char* et = getenv("SMX_BATCH_SCHED_TAIL");   // "thr:tshift,dilate,maxsteps[;thr2:...]" (ascending thr): first thr >= nlive wins
-    if (!wind && et) {
+    static const char* etw = getenv("SMX_BATCH_SCHED_TAIL"); static const char* etd = getenv("SMX_BATCH_SCHED_TAIL_WIND");   // "thr:tshift,dilate,maxsteps[;thr2:...]" (ascending thr): first thr >= nlive wins
+    const char* et = wind ? etd : etw;
+    if (et) {
       const char* q = et; unsigned thr;
       while (q && sscanf(q, "%u:%d,%d,%d", &thr, &a, &d, &k) == 4) {
         if (nlive_sched <= thr) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; break; }

@@ -48,6 +48,8 @@ for s in "$@"; do
     tracex)    run tracex 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 3 ;;
     headwaves) for w in ${WAVES_LIST:-512 1024}; do run headwaves_$w 30 300 env SMX_BATCH_WAVES=$w python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
     headwsteps) for w in ${WSTEPS_LIST:-1 2}; do run headwsteps_$w 30 300 env SMX_RELAX_WATER_STEPS=$w python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
+    windtail)  i=0; IFS='|'; for w in ${WT_LIST}; do i=$((i+1)); IFS=' '; run windtail_$i 30 300 env SMX_BATCH_SCHED_TAIL_WIND="$w" python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 4 --warmup 3; IFS='|'; done; IFS=' ' ;;
+    chunksweep) for kv in ${CS_LIST}; do run cs_$kv 30 300 env ${kv} python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 4 --warmup 3; done ;;
     headbatch) run headbatch 30 300 python bench.py --engine batched --no-lines --no-cpu-baseline --steps 3 --warmup 2 ;;
     tracerelax) run tracerelax 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 5 ;;
     stripstest) run stripstest 60 900 python -m pytest tests/test_gpu_strips.py -x -q -m gpu --durations=8 ;;

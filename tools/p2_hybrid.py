@@ -25,6 +25,11 @@ def run(mode, sd):
             L.hs_grid(h.h)
             if nd: L.hs_wind(h.h, nd)
             L.hs_freq(h.h)
+        elif mode == "tpb_water":           # the BATCHED (exclusive) water schedule, exact grid + wind: concurrency without relaxed isolation
+            L.hs_batched_water(h.h, nw, 1, 0)
+            L.hs_grid(h.h)
+            if nd: L.hs_wind(h.h, nd)
+            L.hs_freq(h.h)
         elif mode.startswith("tp_water_split"):   # the same in k sequential batches of nw/k particles: less intra-tick concurrency
             k = int(mode[len("tp_water_split"):])
             L.hs_set_relaxed(1)
