@@ -56,9 +56,10 @@ def main():
             for _ in range(ticks): x.tick(nw, nd, True, nd > 0)
         def run_e(h):
             f = h.relaxed_tick if a.engine == "relaxed" else h.batched_tick
-            for _ in range(ticks): f(nw, nd, True, nd > 0, nthreads=1)
-        with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
-            futs = [ex.submit(run_e, h) for h in engs] + [ex.submit(run_o, x) for x in refs]
+            for _ in range(ticks): f(nw, nd, True, nd > 0, nthreads=3)
+        with ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4) - 3)) as ex:
+            futs = [ex.submit(run_o, x) for x in refs]
+            for h in engs: run_e(h)                          # ONE host-sim at a time: its engine switches are process-global (hs_set_relaxed)
             for f in futs: f.result()
         R = [figs(x.snapshot(), x.counters()) for x in refs]
         E = [figs(h.snapshot(), h.counters()) for h in engs]
