@@ -393,7 +393,8 @@ __global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs,
 // The tail of a relaxed water generation (a few hundred particles left, for hundreds of epochs; and every nested generation after
 // its first steps): ONE workgroup runs whole epochs back to back -- step, apply, filter, nine cascade colours, floods -- with
 // workgroup barriers where the dense schedule has kernel boundaries. Same phases, same order, same results; no launch per phase.
-constexpr uint32_t RELAX_TAIL = 1024;                         // running particles up to which the tail kernel takes over
+constexpr uint32_t RELAX_TAIL = 256;                          // running particles up to which the tail kernel takes over (one per thread of its
+                                                              // workgroup; round 3: 1 024 = four per thread -- 2.6 % slower on the headline, r04 sweep)
 __global__ void __launch_bounds__(256) k_relax_tail(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch0, uint32_t nepochs, uint32_t tag0) {
   SMX_LOAD_SOILS(sh)
   __shared__ uint32_t busy;
@@ -1779,7 +1780,8 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     // result does not depend on where a generation is cut into chunks; with strips the chunk is the unit of the exchange).
     static const int RCHUNK_KIDS = [] { const char* e = getenv("SMX_RELAX_CHUNK_KIDS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
     static const bool use_tail = [] { const char* e = getenv("SMX_RELAX_TAIL"); return e ? atoi(e) != 0 : true; }();
-    const bool tail = !wind && use_tail && nlive <= RELAX_TAIL;
+    static const uint32_t tail_at = [] { const char* e = getenv("SMX_RELAX_TAIL_AT"); return e ? (uint32_t)atoi(e) : RELAX_TAIL; }();
+    const bool tail = !wind && use_tail && nlive <= tail_at;
     chunk_epochs = strips ? B_CHUNK : (tail ? 64 : (first ? CHUNK : RCHUNK_KIDS));
     ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : std::max(2, ctx->relax_water_steps); ctx->bs.rsteps = wind ? ctx->relax_wind_steps : ctx->relax_water_steps;
     if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(ctx->cflag_alloc, 0, ctx->lcells * 4, st)); }   // (tags never repeat)
@@ -1796,12 +1798,19 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
       const uint32_t lpw = batch_lanes_per_wave(nlive);
       const unsigned nbl = (nlive + lpw - 1u) / lpw, nb64 = (nlive + 63u) / 64u;
       const unsigned ncb = (unsigned)(((size_t)nlive * (size_t)(wind ? ctx->bs.rstride : ctx->bs.rsteps) + 63u) / 64u);   // worst case of the flagged / one cascade list
-      const unsigned nfb = std::max(1024u, (unsigned)((nslots + 63u) / 64u));   // floods: at least 1024 wavefronts to spread over
+      static const unsigned fb_min = [] { const char* e = getenv("SMX_RELAX_FLOOD_BLOCKS"); return e ? (unsigned)atoi(e) : 1024u; }();
+      const unsigned nfb = std::max(fb_min, (unsigned)((nslots + 63u) / 64u));   // floods: at least 1024 wavefronts to spread over
       for (int k = 0; k < chunk_epochs; k++, epoch++) {
         ctx->bs.rtag = ++ctx->relax_tag;
         {
-          PhaseTimer tk(ctx, wind ? 5 : 4, 1u);             // every launch of the step kernel between its own pair of events
-          if (wind) hipLaunchKernelGGL(k_relax_step<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+          // the step kernel between its own pair of events -- every `sample`-th launch (an event pair costs a few microseconds of an epoch
+          // that lasts a few hundred; the average launch duration bench.py reports is over the bracketed launches only)
+          static const int sample = [] { const char* e = getenv("SMX_STEP_EVENT_SAMPLE"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : v; }();
+          const bool timed = sample > 0 && (k % sample) == 0;
+          if (timed) { PhaseTimer tk(ctx, wind ? 5 : 4, 1u);
+            if (wind) hipLaunchKernelGGL(k_relax_step<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+            else hipLaunchKernelGGL(k_relax_step<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
+          } else if (wind) hipLaunchKernelGGL(k_relax_step<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
           else hipLaunchKernelGGL(k_relax_step<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
         }
         hipLaunchKernelGGL(k_relax_apply, dim3(nb64), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
