@@ -497,6 +497,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
     while (nlive > 0) {
       BSched sc = batch_schedule(wind, nlive, g_batch_dilate, g_batch_cell_above);
       if (const char* e = getenv("HS_SCHED")) { int a, d, k; if (sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; } }   // exploration only
+      if (const char* e = wind ? nullptr : getenv("HS_SCHED_WATER")) { int a, d, k; if (sscanf(e, "%d,%d,%d", &a, &d, &k) == 3) { sc.tshift = a; sc.dilate = d; sc.maxsteps = k; } }   // ... water (floods) only
       const bool strips = b.bs.strips.n > 1;
       const bool relaxed_now = relax_gen && (!wind || nlive > g_relax_wind_min);
       bool regrain = sc.tshift != b.bs.tshift;               // first chunk, or the claim granularity changes

@@ -75,6 +75,7 @@ for s in "$@"; do
                python tools/kernel_stats.py $out/exactk | tee $out/exactk.kernels; python tools/trace_gaps.py $out/exactk | tee $out/exactk.summary; rm -rf $out/exactk ;;
     exactmode2) run exactmode2 60 600 env SMX_SPEC_MODE=2 python bench.py --only exact_area_scaled ;;
     p2ref)     run p2ref 60 ${PTO:-900} python tools/p2_reference.py --size ${PSIZE:-4096} --ticks ${PTICKS:-10} --nctl ${PNCTL:-8} --engine ${PENGINE:-relaxed} --out $out/p2ref_${PSIZE:-4096}.json; tail -12 $out/p2ref.err ;;
+    p2var)     i=0; for kv in ${PV_LIST}; do i=$((i+1)); run p2var_$i 60 ${PTO:-600} env ${kv} python tools/p2_reference.py --size ${PSIZE:-2048} --ticks ${PTICKS:-10} --nctl ${PNCTL:-16} --engine relaxed --out $out/p2var_$i.json; tail -9 $out/p2var_$i.err; done ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
     envelope)  run envelope 60 900 python tools/p2_envelope.py --size ${ESIZE:-1024} --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts ${ECOUNTS:-area} ;;
     envelope4096) run envelope4096 60 600 python tools/p2_envelope.py --size 4096 --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts file ;;
