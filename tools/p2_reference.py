@@ -56,7 +56,7 @@ def zscores(eng, ref, ctl):
     return out
 
 
-def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="relaxed", device=0, verbose=True, nwater=None, nwind=None):
+def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="relaxed", device=0, verbose=True, nwater=None, nwind=None, water_batches=1):
     """Returns the report dict, or {"skipped": reason}."""
     from soilmachine_amd import capi
     from soilmachine_amd.machine import SoilMachine
@@ -90,7 +90,19 @@ def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="
         ENG = {"relaxed": capi.ENGINE_RELAXED, "batched": capi.ENGINE_BATCHED, "spec": capi.ENGINE_SPECULATIVE}
         sm = SoilMachine(cfg, size, seed=0, nwater=nwater, nwind=nwind, dowind=nwind > 0, pool=pool, device=device, engine=ENG[engine])
         tg = time.time()
-        sm.tick(ticks, sync=True)
+        if water_batches <= 1:
+            sm.tick(ticks, sync=True)
+        else:                                                     # experiment: the tick's water particles in k sequential generations (less intra-tick concurrency)
+            for _ in range(ticks):
+                left = nwater
+                for q in range(water_batches):
+                    n_q = left // (water_batches - q); left -= n_q
+                    sm.water(n_q)
+                sm.grid_pass()
+                if nwind > 0:
+                    sm.wind(nwind)
+                sm.map_frequency(); sm.reset_frequency()
+            sm.map.sync()
         t_gpu = time.time() - tg
         m = sm.map
         c = m.counters()
@@ -142,8 +154,10 @@ def main():
     ap.add_argument("--engine", default="relaxed")
     ap.add_argument("--soil", default="rockgravelpebblessand.soil")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--water-batches", type=int, default=int(os.environ.get("P2_WATER_BATCHES", "1")))
     a = ap.parse_args()
-    rep = run(a.soil, a.size, a.ticks, a.nctl, a.engine)
+    rep = run(a.soil, a.size, a.ticks, a.nctl, a.engine, water_batches=a.water_batches)
+    rep["water_batches"] = a.water_batches
     if "figures" in rep:
         for k in FIGS:
             f = rep["figures"][k]
