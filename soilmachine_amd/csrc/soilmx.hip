@@ -896,6 +896,7 @@ struct smx_ctx {
   std::vector<hipEvent_t> evpool;
   smx_timing timing{};
   uint32_t spec_sub = 0, spec_maxnest = 0; bool spec_realloc = false;   // smx_set_spec_limits (0 = defaults)
+  int water_generations = 1;                                 // smx_set_water_generations
   uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0, spec_subphases_cut = 0, spec_serial_particles = 0;
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
@@ -1109,6 +1110,11 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) {
     ctx->err = "smx_set_batch_dilate: reservations with this margin do not fit the seam zones of the column strips"; return -2;
   }
   ctx->batch_dilate = tiles;
+  return 0;
+}
+int smx_set_water_generations(smx_ctx* ctx, int32_t k) {
+  if (k < 1 || k > 64) { ctx->err = "smx_set_water_generations: 1..64"; return -2; }
+  ctx->water_generations = k;
   return 0;
 }
 int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epoch) {
@@ -2159,7 +2165,19 @@ int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
   FULLMAP("smx_tick_water (a strip ticks with smx_strips_tick)")
   roctx_range rr("soilmx:water");
   PhaseTimer t(ctx, 0);
-  if (is_batched(ctx)) return batch_generations(ctx, false, nwater > 0 ? (uint32_t)nwater : 0u, 0u);
+  if (is_batched(ctx)) {
+    // throughput engines: the phase's particles as `water_generations` consecutive top-level generations of n/k (smx_set_water_generations;
+    // default 1). Particles of one generation advance together and do not see the water the same generation adds; k > 1 trades
+    // throughput for the reference's feedback between particles of a tick (profiles/r04_p2_analysis.md). Exactly k phase calls of n/k.
+    uint32_t left = nwater > 0 ? (uint32_t)nwater : 0u;
+    const uint32_t k = ctx->water_generations < 1 ? 1u : (uint32_t)ctx->water_generations;
+    for (uint32_t q = 0; q < k && left > 0; q++) {
+      const uint32_t nq = left / (k - q);
+      left -= nq;
+      if (nq) { const int rc = batch_generations(ctx, false, nq, 0u); if (rc) return rc; }
+    }
+    return 0;
+  }
   if (ctx->cfg.engine == SMX_ENGINE_SPECULATIVE) return spec_phase(ctx, nwater, false);
   PhaseTimer tk(ctx, 4);
   hipLaunchKernelGGL(k_water_serial, dim3(1), dim3(64), 0, ctx->stream, ctx->d, nwater);

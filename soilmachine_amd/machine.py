@@ -180,6 +180,10 @@ class Layermap:
         """relaxed schedule: wind steps relaxed (up to `steps_per_epoch` steps per epoch) while more than `min_running` particles run"""
         self._chk(self.L.smx_set_relax_wind(self.h, int(min_running), int(steps_per_epoch)))
 
+    def set_water_generations(self, k: int):
+        """throughput engines: the water phase's particles as k consecutive generations of n/k (smx_set_water_generations)"""
+        self._chk(self.L.smx_set_water_generations(self.h, int(k)))
+
     def set_batch_strips(self, nstrips: int, inset: int = 16, seam_halfwidth: int = 48):
         self._chk(self.L.smx_set_batch_strips(self.h, int(nstrips), int(inset), int(seam_halfwidth)))
 

@@ -132,3 +132,23 @@ def test_relaxed_strip_schedule_device_equals_host_threads():
     finally:
         L.hs_set_batch_strips(1, 16, 48)
     assert m.counters()["floods"] == h.counters()["floods"] > 300
+
+
+def test_water_generations_equal_k_phase_calls():
+    """smx_set_water_generations(k): smx_tick_water(n) == k consecutive calls of n/k (the fidelity knob of profiles/r04_p2_analysis.md is
+    nothing but the phase API applied k times) -- full state and counters, relaxed engine, lakes included."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n, nw, nd, k = 192, 900, 200, 4
+    a = machine(cfg, n, n, nw, nd, True, capi.ENGINE_RELAXED)
+    b = machine(cfg, n, n, nw, nd, True, capi.ENGINE_RELAXED)
+    a.map.set_water_generations(k)
+    for t in range(6):
+        a.tick(1, sync=True)
+        left = nw
+        for q in range(k):
+            nq = left // (k - q); left -= nq
+            b.water(nq)
+        b.grid_pass(); b.wind(nd); b.map_frequency(); b.reset_frequency(); b.map.sync()
+        assert not compare(a.map.snapshot(), b.map.snapshot()), t
+    ca, cb = a.map.counters(), b.map.counters()
+    assert {x: ca[x] for x in RKEYS} == {x: cb[x] for x in RKEYS}

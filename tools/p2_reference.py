@@ -90,19 +90,9 @@ def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="
         ENG = {"relaxed": capi.ENGINE_RELAXED, "batched": capi.ENGINE_BATCHED, "spec": capi.ENGINE_SPECULATIVE}
         sm = SoilMachine(cfg, size, seed=0, nwater=nwater, nwind=nwind, dowind=nwind > 0, pool=pool, device=device, engine=ENG[engine])
         tg = time.time()
-        if water_batches <= 1:
-            sm.tick(ticks, sync=True)
-        else:                                                     # experiment: the tick's water particles in k sequential generations (less intra-tick concurrency)
-            for _ in range(ticks):
-                left = nwater
-                for q in range(water_batches):
-                    n_q = left // (water_batches - q); left -= n_q
-                    sm.water(n_q)
-                sm.grid_pass()
-                if nwind > 0:
-                    sm.wind(nwind)
-                sm.map_frequency(); sm.reset_frequency()
-            sm.map.sync()
+        if water_batches > 1:                                     # the tick's water particles as k consecutive generations (smx_set_water_generations)
+            sm.map.set_water_generations(water_batches)
+        sm.tick(ticks, sync=True)
         t_gpu = time.time() - tg
         m = sm.map
         c = m.counters()
