@@ -20,8 +20,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
     bracketing nothing but launches of that kernel) vs the 8 TB/s HBM peak; "phases" gives the same for the O(cells)
     streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r04_pmc.json), labelled as such.
   * "cpu_baseline": the reference's own CPU loop (oracle/_ref/soil_ref_lean = the unmodified reference headers,
-    render-only Layermap::update elided) timed on this box's host: 1 core on a bounded sample of the headline
-    workload, and an all-cores line (independent processes, different SEEDs -- the reference has no threads).
+    render-only Layermap::update elided) timed on this box's host on THE SAME tick the timed window starts with: the state after the
+    warm-up is checkpointed (smx_save, outside the timed region) and the reference continues it (ref_driver --load) at the same counts,
+    1 core pinned; an all-cores line (independent processes from that state -- the reference has no threads) and the "as-is" line.
+  * "parity_vs_reference": z-scores of the timed engine against the reference itself (tools/p2_reference.py: 1024^2, 8 control streams).
   * N > 1: one process per GPU. The throughput engines run ONE map in N column strips, driven inside the library (smx_strips_*: halo
     columns + migrating particles point to point with ncclSend/ncclRecv on device buffers, live count by ncclAllReduce). Default "scaling": "weak" -- the map is
     (N*size) x size, every GPU owns a size x size strip and its share of N x the particles, so per-GPU work is the N=1 line's;
