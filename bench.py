@@ -153,7 +153,7 @@ def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool
 
 
 def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None, rand_seed=None, keep_heights=False, save_after_warmup=None,
-            water_generations=1):
+            water_generations=1, grid_interleave=0):
     """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers).
     rand_seed: re-seed the libc stream after the terrain is built (same map, another rand() stream: the parity control)."""
     from soilmachine_amd.machine import SoilMachine
@@ -163,6 +163,8 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
         m._chk(m.L.smx_srand(m.h, int(rand_seed)))
     if water_generations > 1:
         m.set_water_generations(water_generations)
+    if grid_interleave > 0:
+        m.set_grid_interleave(grid_interleave)
     sm.tick(warmup, sync=True)
     if save_after_warmup:                                       # the state the timed window starts from: what cpu_baseline continues (outside the timed region)
         try:
@@ -336,6 +338,8 @@ def main():
     ap.add_argument("--no-lines", action="store_true", help="only the headline measurement")
     ap.add_argument("--cpu-ticks", type=int, default=1)
     ap.add_argument("--strong", action="store_true", help="N > 1: keep the map at --size^2 and split it (default: the map grows with N)")
+    ap.add_argument("--grid-interleave", type=int, default=0, help="throughput engines: the grid pass's nested particles run after every k colours of tiles "
+                                                                  "(smx_set_grid_interleave; fidelity knob like --water-generations; the headline is quoted at 0)")
     ap.add_argument("--water-generations", type=int, default=1, help="throughput engines: the tick's water particles as k consecutive generations (smx_set_water_generations; "
                                                                      "a fidelity knob, profiles/r04_p2_analysis.md; the headline is quoted at 1)")
     args = ap.parse_args()
@@ -389,7 +393,7 @@ def main():
         want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean"))
         ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"soilmx_bench_{os.getpid()}.smx") if want_cpu else None
         r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier, save_after_warmup=ckpt,
-                    water_generations=args.water_generations if throughput else 1)
+                    water_generations=args.water_generations if throughput else 1, grid_interleave=args.grid_interleave if throughput else 0)
         if ckpt and not os.path.exists(ckpt):
             ckpt = None
     steps = r["steps_w"] + r["steps_d"]
@@ -544,7 +548,7 @@ def main():
             "metric": "particle-steps/s", "value": total_steps / tmax, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True,
             "scaling": "strong" if (strips and args.strong) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "engine": eng_name, "water_generations": args.water_generations if throughput else None,
+            "config": {"workload": workload, "engine": eng_name, "water_generations": args.water_generations if throughput else None, "grid_interleave": args.grid_interleave if throughput else None,
                        "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
                        "scaling_note": (None if world == 1 else ("--strong: the N=1 map split into N strips" if (strips and args.strong) else
                                         "weak: one (N*size) x size map, every GPU owns a size x size strip and 1/N of N x the particles "

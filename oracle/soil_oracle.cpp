@@ -908,6 +908,7 @@ struct so_ctx {
   //            the waiting particles, every epoch is a flood epoch (the rule above counts one device's particles: not partition-invariant).
   // =====================================================================================================
   bool b_relaxed = false;
+  int b_grid_interleave = 0;                                  // so_set_grid_interleave (smx_set_grid_interleave)
   struct RReq { int x, y; double vol, amount; uint32_t type; int kind; int cx, cy; };   // kind 1: erode, 2: deposit
   uint32_t r_surf(int x, int y) const { const uint32_t t = top[cidx(x, y)]; return t == NIL ? 0u : type[t]; }
   bool r_precheck(int x, int y) const {
@@ -1067,7 +1068,7 @@ struct so_ctx {
     uint64_t visited = 0;
     b_children.clear();
     for (int ph = 0; ph < (bs_n > 1 ? 2 : 1); ph++)
-    for (int col = 0; col < 9; col++)
+    for (int col = 0; col < 9; col++) {
       for (int tx = col / 3; tx < ntx; tx += 3) {
         if (bs_n > 1) {                                       // INTERIOR sweep: tiles whose neighbourhood lies inside one strip; SEAM sweep: the rest
           const int cx0 = std::max(tx - 1, 0) << B_GRID, cx1 = std::min(((tx + 2) << B_GRID) - 1, dimx - 1);
@@ -1089,6 +1090,17 @@ struct so_ctx {
           b_guard = nullptr; b_defer = false;
         }
       }
+      // smx_set_grid_interleave(k): the nested particles of every k colours run -- all their generations -- before the next colour's tiles,
+      // i.e. while the cells of the later colours are still wet, as the reference's nested particles find the raster-later cells (water.h:246-264
+      // run inside water.h:335-343). Not under column strips. The rest (and everything when k = 0) after the last colour, below.
+      if (b_grid_interleave > 0 && bs_n <= 1 && col < 8 && (col + 1) % b_grid_interleave == 0) {
+        std::vector<BChild> part = b_children;
+        b_children.clear();
+        std::stable_sort(part.begin(), part.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
+        if (!part.empty() && !getenv("DBG_GRID_NOCHILD")) b_generations(false, 0, part);
+        B_TILE = B_GRID;
+      }
+    }
     ctr.wcascade_calls += n - visited;                        // the reference "calls" cascade on every cell (water.h:340)
     ctr.grid_active_cells += visited;
     std::vector<BChild> kids = b_children;
@@ -1257,6 +1269,7 @@ void so_batched_tick(so_ctx* c, int nwater, int nwind, int dowater, int dowind) 
   if (dowind) so_batched_wind(c, nwind);
   if (dowater) { c->map_frequency(); c->reset_frequency(); }
 }
+void so_set_grid_interleave(so_ctx* c, int k) { c->b_grid_interleave = k < 0 ? 0 : k; }
 void so_set_relaxed(so_ctx* c, int on) { c->b_relaxed = on != 0; }   // water generations of so_batched_* follow the relaxed schedule
 void so_batched_set_dilate(so_ctx* c, int tiles) { c->b_base_dilate = tiles < 0 ? 0 : tiles; }
 void so_batched_set_cell_above(so_ctx* c, uint32_t n) { c->b_cell_above = n; }

@@ -897,6 +897,7 @@ struct smx_ctx {
   smx_timing timing{};
   uint32_t spec_sub = 0, spec_maxnest = 0; bool spec_realloc = false;   // smx_set_spec_limits (0 = defaults)
   int water_generations = 1;                                 // smx_set_water_generations
+  int grid_interleave = 0;                                   // smx_set_grid_interleave
   uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0, spec_subphases_cut = 0, spec_serial_particles = 0;
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
@@ -1115,6 +1116,11 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) {
 int smx_set_water_generations(smx_ctx* ctx, int32_t k) {
   if (k < 1 || k > 64) { ctx->err = "smx_set_water_generations: 1..64"; return -2; }
   ctx->water_generations = k;
+  return 0;
+}
+int smx_set_grid_interleave(smx_ctx* ctx, int32_t k) {
+  if (k < 0 || k > 9) { ctx->err = "smx_set_grid_interleave: 0..9"; return -2; }
+  ctx->grid_interleave = k;
   return 0;
 }
 int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epoch) {
@@ -1929,6 +1935,21 @@ static int batch_grid(smx_ctx* ctx) {
     if (mx * my == 0) continue;
     { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_batch_grid, dim3((mx * my + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, col, mx, my); }
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
+    // smx_set_grid_interleave(k): the nested particles of every k colours run -- all their generations -- before the next colour's tiles, i.e.
+    // while the cells of the later colours are still wet, as the reference's nested particles find the raster-later cells (they run inside
+    // the raster sweep, water.h:246-264 in :335-343). Not under column strips; k = 0 (default): all of them after the pass.
+    if (ctx->grid_interleave > 0 && bs.strips.n <= 1 && col < 8u && (col + 1u) % (uint32_t)ctx->grid_interleave == 0u) {
+      HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      uint32_t nq = ctx->h_bctrl[BC_NCHILD];
+      if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
+      if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
+      if (nq > bs.child_cap) nq = bs.child_cap;
+      if (nq && sort_children(ctx, nq)) return -1;
+      HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
+      if (nq) { const int rc = batch_generations(ctx, false, 0, nq); if (rc) return rc; }
+      ctx->bs.tshift = GRID_SHIFT;                           // (the generations ran their own schedule)
+    }
   }
   hipLaunchKernelGGL(k_batch_grid_finish, dim3(1), dim3(1), 0, st, ctx->d, v0);
   HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));

@@ -647,6 +647,8 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
 extern "C" {
 void hs_batched_water(hs_ctx* c, int n, int nthreads, unsigned shuffle) { BatchBuffers b; batch_generations(c, b, false, (uint32_t)n, {}, nthreads, shuffle); }
 void hs_batched_wind(hs_ctx* c, int n, int nthreads, unsigned shuffle) { BatchBuffers b; batch_generations(c, b, true, (uint32_t)n, {}, nthreads, shuffle); }
+static int g_grid_interleave = 0;
+void hs_set_grid_interleave(int k) { g_grid_interleave = k < 0 ? 0 : k; }
 void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
   const DevState& s = c->d;
   const size_t n = c->n;
@@ -682,6 +684,14 @@ void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
     }, shuffle ? shuffle + 3 + col : 0);
     for (unsigned long long v : vis) visited += v;
     batch_merge_freed(c, b);
+    if (g_grid_interleave > 0 && b.bs.strips.n <= 1 && col < 8u && (col + 1u) % (uint32_t)g_grid_interleave == 0u) {   // smx_set_grid_interleave (soilmx.hip batch_grid)
+      uint32_t nq = b.ctrl[BC_NCHILD]; if (nq > b.bs.child_cap) nq = b.bs.child_cap;
+      std::vector<BChild> kq(b.children.begin(), b.children.begin() + nq);
+      std::sort(kq.begin(), kq.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
+      b.ctrl[BC_NCHILD] = 0;
+      if (!kq.empty()) { BatchBuffers b2; batch_generations(c, b2, false, 0, kq, nthreads, shuffle); }
+      b.bs.tshift = GRID_SHIFT;
+    }
   }
   c->ctr[C_WCASCADE_CALLS] += n - visited;                   // every other cell still "calls" WaterParticle::cascade once
   c->ctr[C_GRID_ACTIVE] += visited;

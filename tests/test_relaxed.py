@@ -199,3 +199,39 @@ def test_relaxed_schedule_under_column_strips_is_deterministic_and_sound():
     column_invariants(runs[0][0])
     c = runs[0][1]
     assert c["pool_overflow"] == 0 and c["live_sections"] == runs[0][0].nsec and c["steps_water_all"] > 20000 and c["floods"] > 300
+
+
+@pytest.mark.parametrize("k,gens", [(3, 1), (1, 2)])
+def test_fidelity_knobs_equal_the_independent_restatement(k, gens):
+    """smx_set_grid_interleave(k) -- the grid pass's nested particles run after every k colours of tiles instead of after the pass -- and
+    smx_set_water_generations (the water phase as consecutive generations: just repeated phase calls) on the host: device headers on host
+    threads == the restatement with the same option (oracle/soil_oracle.cpp batched_grid), full state and counters, through lakes."""
+    cfg = load_cfg("default.soil")
+    n, nw = 96, 180
+    o0 = Oracle(cfg, n, n, seed=0); o0.initialize()
+    for _ in range(45):
+        o0.tick(250, 0, True, False)                              # lakes (the reference-order oracle alone: fast)
+    s0 = o0.snapshot()
+    h = HostSim(cfg, n, n, seed=0); h.load(s0, advance_rand=True)
+    o = Oracle(cfg, n, n, seed=0); o.load(s0)
+    base = o.counters()
+    h.L.hs_set_grid_interleave(k); o.L.so_set_grid_interleave(o.h, k)
+    try:
+        for t in range(6):
+            h.L.hs_set_relaxed(1); o.L.so_set_relaxed(o.h, 1)
+            try:
+                left = nw
+                for q in range(gens):
+                    nq = left // (gens - q); left -= nq
+                    h.L.hs_batched_water(h.h, nq, 4, t + 1); o.L.so_batched_water(o.h, nq)
+                h.L.hs_batched_grid(h.h, 4, t + 1); o.L.so_batched_grid(o.h)
+            finally:
+                h.L.hs_set_relaxed(0); o.L.so_set_relaxed(o.h, 0)
+            h.L.hs_freq(h.h); o.L.so_map_frequency(o.h); o.L.so_reset_frequency(o.h)
+            bad = compare(h.snapshot(), o.snapshot())
+            assert not bad, f"tick {t}: {bad}"
+    finally:
+        h.L.hs_set_grid_interleave(0); o.L.so_set_grid_interleave(o.h, 0)
+    ch, co = h.counters(), o.counters()
+    assert {x: ch[x] for x in RKEYS if x != "rand_calls"} == {x: co[x] - base[x] for x in RKEYS if x != "rand_calls"}
+    assert co["nested_particles"] - base["nested_particles"] > 300 and o.batched_stats()["guard_violations"] == 0
