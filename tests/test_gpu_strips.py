@@ -4,7 +4,7 @@ refuses two ranks on one device). Either way the result must equal ONE context r
 schedule, and that schedule must equal its CPU restatement. Two drivers: the library's own (csrc/soil_strips_host.h,
 smx_strips_*: C++ protocol, device-resident messages; here over the host-callback transport -- the RCCL transport is the same
 protocol with ncclSend/ncclRecv in place of the callbacks and is exercised with the one rank a single device allows) and round 2's
-Python driver (soilmachine_amd/strips.py StripRank, the protocol's executable description, also run by the host-sim)."""
+Python driver (tests/strips_ref.py StripRank, the protocol's executable description, also run by the host-sim)."""
 import ctypes
 import os
 import sys
