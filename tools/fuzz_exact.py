@@ -23,7 +23,9 @@ while time.time() < t_end:
     for _ in range(warm): o.tick(nw, 0, True, False)
     h = HostSim(cfg, dx, dy, seed=seed); h.load(o.snapshot())
     HostSim.set_boundary_threads(team)
-    desc = (soil, dx, dy, seed, nw, nd, ticks, mode, team, warm)
+    sub, slots = rng.choice([4096, 4096, 97, 33]), rng.choice([1024, 1024, 160, 128])   # round 4: sub-phase size / nested-slot budget (small values force the hand-over)
+    h.L.hs_set_spec_sub(sub); h.L.hs_set_spec_maxnest(slots)
+    desc = (soil, dx, dy, seed, nw, nd, ticks, mode, team, warm, sub, slots)
     try:
         for t in range(ticks):
             h.spec_tick(nw, nd, True, nd > 0, nthreads=rng.choice([2, 8]), scout=rng.choice([0, 1]) | (mode << 4), shuffle=rng.randrange(50))
@@ -32,6 +34,6 @@ while time.time() < t_end:
             if bad:
                 print("MISMATCH", desc, "tick", t, bad[:3]); sys.exit(1)
     finally:
-        HostSim.set_boundary_threads(1)
+        HostSim.set_boundary_threads(1); h.L.hs_set_spec_sub(4096); h.L.hs_set_spec_maxnest(1024)
     n += 1
 print("ok", n, "cases")
