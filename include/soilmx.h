@@ -213,7 +213,7 @@ int smx_set_grid_interleave(smx_ctx* ctx, int32_t k);
  * +-seam_halfwidth cells around a strip boundary). nstrips == 1 (default) = the single-strip schedule. The result is a
  * function of (nstrips, inset, seam_halfwidth) only -- not of how many devices run the strips. */
 int smx_set_batch_strips(smx_ctx* ctx, int32_t nstrips, int32_t inset, int32_t seam_halfwidth);
-/* ---- column strips on SEVERAL devices, step by step (driver: soilmachine_amd/strips.py; one context per strip, each with
+/* ---- column strips on SEVERAL devices, step by step (library driver: smx_strips_*; its Python restatement over these entry points: tests/strips_ref.py; one context per strip, each with
  * the full-size map of which it keeps its strip + right halo current). A generation of a particle phase:
  *   smx_d_gen_begin   draws the generation's rand() values (identical on every rank) and, for nested particles
  *                     (`children` = BChild records: u64 key, i32 tx,ty,bx,by,spill,pad, f64 volume), answers what this rank

@@ -2,7 +2,7 @@
 //
 // north_star: "Shard the heightmap across up to 8 MI355X as column strips with RCCL halo exchange ... over xGMI". The schedule
 // (INTERIOR / SEAM chunks, soil_batch.h BStrips) and the step functions smx_d_* are those of round 2; what moves here is the
-// DRIVER (round 2: soilmachine_amd/strips.py) and the TRANSPORT: halo columns and migrating particles stay in device memory from
+// DRIVER (round 2: a Python driver, now tests/strips_ref.py) and the TRANSPORT: halo columns and migrating particles stay in device memory from
 // the pack kernel to the unpack kernel on the other rank --
 //   RcclTransport   ncclSend / ncclRecv / ncclAllReduce / ncclAllGather on this context's stream (librccl is loaded with dlopen:
 //                   the library itself has no link-time dependency on it). One message = a 32-byte header (sizes) followed by up

@@ -543,7 +543,7 @@ __global__ void k_batch_grid_finish(DevState s, unsigned long long visited0) {  
   s.ctr[C_WCASCADE_CALLS] += n - v;
 }
 
-// ---------------- column strips on several devices: halo columns, migrating particles (driver: soilmachine_amd/strips.py) ----------------
+// ---------------- column strips on several devices: halo columns, migrating particles (library driver: soil_strips_host.h; Python restatement: tests/strips_ref.py) ----------------
 __global__ void __launch_bounds__(64) k_batch_child_contains(DevState s, BatchShared bs, uint32_t nslots, uint32_t* out) {
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   if (i < nslots) out[i] = batch_child_contains(s, s.soils, bs, i);
