@@ -91,6 +91,11 @@ typedef struct smx_timing {
    * colour passes (k_batch_grid), water.h:358-365 (k_map_frequency) */
   double ms_kernel_classify, ms_kernel_gridtiles, ms_kernel_mapfreq;
   uint64_t launches_kernel_classify, launches_kernel_gridtiles, launches_kernel_mapfreq;
+  /* round 5 (smx_get_timing_sized only): ALL launches of the throughput engines' step kernels (k_relax_step / k_batch_epoch), whether
+   * bracketed by events or not. The relaxed water step kernel is bracketed every 8th launch (SMX_STEP_EVENT_SAMPLE): ms_kernel_water /
+   * launches_kernel_water is then the average duration over the bracketed launches, and the algorithmic bytes per launch are the
+   * steps of ALL launches over launches_step_water (bench.py). */
+  uint64_t launches_step_water, launches_step_wind;
 } smx_timing;
 
 /* ---- life cycle: replaces Layermap::Layermap + secpool::reserve (layermap.h:64-119,218-226) ---- */
@@ -180,6 +185,12 @@ int smx_heights_bilinear(smx_ctx* ctx, const float* pos2, int32_t n, double* out
  * cells in x-outer / y-inner order (sequential double accumulation), number of sections, and the 64-bit hash
  * h = (h ^ type) * 1099511628211 (start 1469598103934665603) over every column walked top -> bottom, same cell order. */
 int smx_digest(smx_ctx* ctx, double* sumh, uint64_t* nsec, uint64_t* typehash);
+/* The sized getters write min(struct_size, sizeof) bytes: pass sizeof(smx_counters) / sizeof(smx_timing) of the header you compiled
+ * against. The unsized ones keep the layouts they were introduced with (smx_counters: the first 16 words, i.e. without
+ * spec_subphases_cut / spec_serial_particles; smx_timing: the first 144 bytes) so that older binaries are never written past their
+ * struct -- an ABI note for callers of rounds 1-4: INTEGRATION.md "ABI notes". */
+int smx_get_counters_sized(smx_ctx* ctx, smx_counters* out, uint64_t struct_size);
+int smx_get_timing_sized(smx_ctx* ctx, smx_timing* out, uint64_t struct_size);
 int smx_get_counters(smx_ctx* ctx, smx_counters* out);
 int smx_get_timing(smx_ctx* ctx, smx_timing* out);
 int smx_timing_reset(smx_ctx* ctx);

@@ -47,7 +47,7 @@ class secpool {                               // layermap.h:64-119: capacity POO
     smx_ctx** ctx = nullptr;
     size_t size() const {
       smx_counters c;
-      if (!ctx || !*ctx || smx_get_counters(*ctx, &c) != 0) return 0;
+      if (!ctx || !*ctx || smx_get_counters_sized(*ctx, &c, sizeof(c)) != 0) return 0;
       return (size_t)c.pool_free;
     }
     bool empty() const { return size() == 0; }

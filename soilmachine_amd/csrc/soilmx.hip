@@ -1819,6 +1819,7 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
           // that lasts a few hundred; the average launch duration bench.py reports is over the bracketed launches only)
           static const int sample = [] { const char* e = getenv("SMX_STEP_EVENT_SAMPLE"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : v; }();
           const bool timed = sample > 0 && (k % sample) == 0;
+          if (wind) ctx->timing.launches_step_wind++; else ctx->timing.launches_step_water++;   // (every launch, bracketed or not)
           if (timed) { PhaseTimer tk(ctx, wind ? 5 : 4, 1u);
             if (wind) hipLaunchKernelGGL(k_relax_step<true>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
             else hipLaunchKernelGGL(k_relax_step<false>, dim3(nbl), dim3(64), 0, st, ctx->d, bs, nlive, epoch, lpw);
@@ -1833,6 +1834,7 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     }
   } else if (nlive) {
     PhaseTimer tk(ctx, wind ? 5 : 4, (uint32_t)CHUNK);   // CHUNK back-to-back launches of the epoch kernel, nothing else
+    if (wind) ctx->timing.launches_step_wind += (uint64_t)CHUNK; else ctx->timing.launches_step_water += (uint64_t)CHUNK;
     const uint32_t lpw = batch_lanes_per_wave(nlive);
     const unsigned nbl = (nlive + lpw - 1u) / lpw;
     // more wavefronts than SIMDs (> 65 536 running particles): the 256-register build, two wavefronts per SIMD -- +5 % at 16384^2,
@@ -2333,29 +2335,37 @@ int smx_digest(smx_ctx* ctx, double* sumh, uint64_t* nsec, uint64_t* typehash) {
   if (typehash) *typehash = h;
   return 0;
 }
-int smx_get_counters(smx_ctx* ctx, smx_counters* out) {
+// The structs behind the two getters have grown (round 2: three streaming-kernel timers; round 4: two speculative-engine counters;
+// round 5: step-kernel launch totals). A caller says how large ITS struct is and gets exactly that prefix; the unsized entry points
+// keep writing the layout they had when they were introduced (16 / 18 words), so a binary built against an older header is never
+// written past its struct.
+int smx_get_counters_sized(smx_ctx* ctx, smx_counters* out, uint64_t struct_size) {
   unsigned long long c[C_COUNT];
   RandState r;
   HIPCHK(hipMemcpyAsync(c, ctx->d.ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  memset(out, 0, sizeof(*out));
-  out->steps_water_top = c[C_STEPS_WATER_TOP]; out->steps_water_all = c[C_STEPS_WATER_ALL]; out->steps_wind = c[C_STEPS_WIND];
-  out->nested_particles = c[C_NESTED]; out->floods = c[C_FLOODS]; out->cascade_calls = c[C_CASCADE_CALLS];
-  out->cascade_transfers = c[C_CASCADE_TRANSFERS]; out->wcascade_calls = c[C_WCASCADE_CALLS];
-  out->grid_active_cells = c[C_GRID_ACTIVE]; out->rand_calls = r.calls;
-  out->pool_free = ctx->cfg.pool_capacity - c[C_LIVE_SECTIONS]; out->pool_overflow = c[C_POOL_OVERFLOW];
-  out->spec_rounds = ctx->spec_rounds; out->spec_aborts = ctx->spec_aborts;
-  out->reserved[0] = ctx->spec_fallbacks; out->reserved[1] = ctx->spec_executed;
-  out->spec_subphases_cut = ctx->spec_subphases_cut; out->spec_serial_particles = ctx->spec_serial_particles;
+  smx_counters t;
+  memset(&t, 0, sizeof(t));
+  t.steps_water_top = c[C_STEPS_WATER_TOP]; t.steps_water_all = c[C_STEPS_WATER_ALL]; t.steps_wind = c[C_STEPS_WIND];
+  t.nested_particles = c[C_NESTED]; t.floods = c[C_FLOODS]; t.cascade_calls = c[C_CASCADE_CALLS];
+  t.cascade_transfers = c[C_CASCADE_TRANSFERS]; t.wcascade_calls = c[C_WCASCADE_CALLS];
+  t.grid_active_cells = c[C_GRID_ACTIVE]; t.rand_calls = r.calls;
+  t.pool_free = ctx->cfg.pool_capacity - c[C_LIVE_SECTIONS]; t.pool_overflow = c[C_POOL_OVERFLOW];
+  t.spec_rounds = ctx->spec_rounds; t.spec_aborts = ctx->spec_aborts;
+  t.reserved[0] = ctx->spec_fallbacks; t.reserved[1] = ctx->spec_executed;
+  t.spec_subphases_cut = ctx->spec_subphases_cut; t.spec_serial_particles = ctx->spec_serial_particles;
+  memcpy(out, &t, struct_size < sizeof(t) ? (size_t)struct_size : sizeof(t));
   return 0;
 }
-int smx_get_timing(smx_ctx* ctx, smx_timing* out) {
+int smx_get_counters(smx_ctx* ctx, smx_counters* out) { return smx_get_counters_sized(ctx, out, 16 * sizeof(uint64_t)); }   // the layout of rounds 1-3
+int smx_get_timing_sized(smx_ctx* ctx, smx_timing* out, uint64_t struct_size) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   drain_events(ctx);
-  *out = ctx->timing;
+  memcpy(out, &ctx->timing, struct_size < sizeof(ctx->timing) ? (size_t)struct_size : sizeof(ctx->timing));
   return 0;
 }
+int smx_get_timing(smx_ctx* ctx, smx_timing* out) { return smx_get_timing_sized(ctx, out, 144); }   // the layout of rounds 2-4
 int smx_timing_reset(smx_ctx* ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   drain_events(ctx);

@@ -170,7 +170,7 @@ class Layermap:
 
     def counters(self) -> dict:
         c = capi.Counters()
-        self._chk(self.L.smx_get_counters(self.h, C.byref(c)))
+        self._chk(self.L.smx_get_counters_sized(self.h, C.byref(c), C.sizeof(c)))
         return c.as_dict()
 
     def set_batch_dilate(self, tiles: int):
@@ -198,7 +198,7 @@ class Layermap:
 
     def timing(self) -> dict:
         t = capi.Timing()
-        self._chk(self.L.smx_get_timing(self.h, C.byref(t)))
+        self._chk(self.L.smx_get_timing_sized(self.h, C.byref(t), C.sizeof(t)))
         return t.as_dict()
 
     def timing_reset(self):
