@@ -660,7 +660,7 @@ struct so_ctx {
   // Acting order inside an epoch is irrelevant by construction (winners own disjoint tiles); this
   // restatement walks slots in ascending order.
   // =====================================================================================================
-  static constexpr int B_GRID = 2, B_MAXCHILD = 24, B_CHUNK = 32;   // grid pass: 4x4-cell tiles
+  static constexpr int B_GRID = 2, B_MAXCHILD = 250, B_CHUNK = 32;   // grid pass: 4x4-cell tiles
   int B_TILE = 2;                                   // claim granularity of the running chunk (b_schedule): tiles of 2^B_TILE cells
   struct BRect { int tx0, tx1, ty0, ty1; bool empty() const { return tx1 < tx0; } };
   struct BChild { uint64_t key; int tx, ty, bx, by, spill; double volume; };

@@ -33,7 +33,10 @@ constexpr int GRID_SHIFT = 2;                 // the grid pass works on 4x4-cell
 constexpr uint32_t B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3;   // B_NEW: top-level particle that has not acted yet
 constexpr uint32_t B_AWAY = 4;               // column strips on several devices: the particle currently lives on another device
 constexpr int B_CHUNK = 32;                   // epochs between two looks at the number of running particles (schedule, compaction)
-constexpr int B_MAXCHILD = 24;                // nested particles one flood / one grid tile may emit per pass
+constexpr int B_MAXCHILD = 250;               // nested particles one flood / one grid tile may emit per pass (the key keeps 8 bits for the sequence). Round 5: 24 -> 250:
+                                              // a 4x4 tile of lake cells spawns more than 24 (every sweep position can send off its own film and those of its eight
+                                              // neighbours, water.h:246-264), and a refused spawn leaves its water standing -- the cap alone put the grid pass +33 %
+                                              // cells under water outside the reference (profiles/r05_p2_child_cap.md)
 
 struct BRect { int tx0, tx1, ty0, ty1; };     // inclusive tile ranges; tx1 < tx0: empty
 

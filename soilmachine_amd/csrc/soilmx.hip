@@ -342,20 +342,21 @@ __global__ void __launch_bounds__(64) k_relax_filter(DevState s, BatchShared bs,
   sim.flush_counters(); pol.finish(s);
   relax_commit_cascade_counters(s, pol.a_casc, pol.a_tr);
 }
+// (a fixed, small grid with a grid-stride loop: the colour lists hold the residue of crowded cells -- a few hundred entries, often none --
+//  and a launch sized for the worst case spends its ~13 us dispatching a thousand workgroups that read the count and leave; round 5)
 __global__ void __launch_bounds__(64) k_relax_cascade(DevState s, BatchShared bs, uint32_t epoch, uint32_t colour) {
   const uint32_t par = epoch & 1u;
   uint32_t n = bs.ctrl[BC_NCASC + 9u * par + colour];
   if (n > bs.clist_cap) n = bs.clist_cap;
   if (blockIdx.x * 64u >= n) return;
   SMX_LOAD_SOILS(sh)
-  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   unsigned long long nc = 0, nt = 0;
-  if (i < n) {
+  for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
     BatchPolicy pol(s, bs);
     Sim<BatchPolicy> sim(s, sh, pol);
     relax_cascade(sim, bs.clist[par][(size_t)colour * bs.clist_cap + i]);
     sim.flush_counters(); pol.finish(s);
-    nc = pol.a_casc; nt = pol.a_tr;
+    nc += pol.a_casc; nt += pol.a_tr;
   }
   relax_commit_cascade_counters(s, nc, nt);
 }
@@ -1828,7 +1829,9 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
         }
         hipLaunchKernelGGL(k_relax_apply, dim3(nb64), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
         hipLaunchKernelGGL(k_relax_filter, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch);
-        for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch, col);
+        static const unsigned casc_blocks = [] { const char* e = getenv("SMX_RELAX_CASC_BLOCKS"); return e ? (unsigned)atoi(e) : 64u; }();
+        const unsigned ncc = std::min(ncb, std::max(1u, casc_blocks));
+        for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncc), dim3(64), 0, st, ctx->d, bs, epoch, col);
         if (!wind) hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch);
       }
     }

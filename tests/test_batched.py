@@ -203,26 +203,37 @@ def test_statistics_in_the_wet_regime_track_the_reference():
     must reproduce the reference's AMOUNTS -- floods, nested particles, standing water, total height -- not just look
     plausible. (Round 2 tried running floods as a sub-phase after every 32-epoch chunk: 18 % faster on the device, but a
     flood is a feedback -- the puddle it leaves ends the particles that arrive next -- and delaying it cost 17 % of the
-    floods and 25 % of the nested particles, +21 % standing water. tools/experiments/r02_flood_subphase.patch; this test is
-    what such a change has to pass.)"""
+    floods and 25 % of the nested particles, +21 % standing water; this test is what such a change has to pass.)
+    Round 5: the amounts are judged as z-scores against the reference's OWN spread (six control streams: the same terrain,
+    another rand() stream), not against hand-set floors."""
+    from concurrent.futures import ThreadPoolExecutor
     cfg = load_cfg("default.soil")
     n = 256
     a = Oracle(cfg, n, n, seed=0); a.initialize()
+    s0 = a.snapshot()
     b = Oracle(cfg, n, n, seed=0); b.initialize()
-    for _ in range(150):
-        a.tick(250, 0, True, False)
-        b.batched_tick(250, 0, True, False)
-    ca, cb = a.counters(), b.counters()
-    sa, sb = a.snapshot(), b.snapshot()
-    water_a, water_b = float(sa.size[sa.type == 0].sum()), float(sb.size[sb.type == 0].sum())
+    ctl = []
+    for k in range(6):
+        c = Oracle(cfg, n, n, seed=0); c.load(s0); c.L.so_srand(c.h, 1000 + 7919 * k); ctl.append(c)
+    def run(x, batched=False):
+        for _ in range(150):
+            (x.batched_tick if batched else x.tick)(250, 0, True, False)
+    with ThreadPoolExecutor(max_workers=8) as ex:          # (ctypes releases the GIL)
+        futs = [ex.submit(run, a), ex.submit(run, b, True)] + [ex.submit(run, c) for c in ctl]
+        for f in futs: f.result()
+    def figs(x):
+        c, s = x.counters(), x.snapshot()
+        return {"floods": c["floods"], "nested": c["nested_particles"], "water": float(s.size[s.type == 0].sum()), "sections": int(s.count.sum()),
+                "sumh": float(np.asarray(x.heights()).sum())}
+    fa, fb, fc = figs(a), figs(b), [figs(c) for c in ctl]
+    assert fa["floods"] > 50000 and fa["nested"] > 250000
+    for k in fa:
+        v = np.array([f[k] for f in fc], float)
+        z = (fb[k] - v.mean()) / v.std(ddof=1)
+        assert abs(z) < 2.5, (k, z, fb[k], fa[k], v.min(), v.max())
     ha, hb = np.asarray(a.heights()), np.asarray(b.heights())
-    assert ca["floods"] > 50000 and ca["nested_particles"] > 250000
-    assert abs(cb["floods"] / ca["floods"] - 1) < 0.03
-    assert abs(cb["nested_particles"] / ca["nested_particles"] - 1) < 0.05
-    assert abs(water_b / water_a - 1) < 0.12
-    assert abs(hb.sum() - ha.sum()) < 5.0 and abs(float((hb - ha).mean())) < 1e-4
-    assert float(np.sqrt(((ha - hb) ** 2).mean())) < 3e-3
-    assert abs(int(sb.count.sum()) / int(sa.count.sum()) - 1) < 0.01
+    rm = max(float(np.sqrt(((np.asarray(c.heights()) - ha) ** 2).mean())) for c in ctl)
+    assert float(np.sqrt(((ha - hb) ** 2).mean())) < 1.25 * rm          # no further from SEED 0 than another stream of the reference is
 
 
 def test_random_configurations_host_sim_equals_restatement():
