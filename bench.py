@@ -153,7 +153,7 @@ def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool
 
 
 def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None, rand_seed=None, keep_heights=False, save_after_warmup=None,
-            water_generations=1, grid_interleave=0):
+            water_generations=1):
     """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers).
     rand_seed: re-seed the libc stream after the terrain is built (same map, another rand() stream: the parity control)."""
     from soilmachine_amd.machine import SoilMachine
@@ -163,8 +163,6 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
         m._chk(m.L.smx_srand(m.h, int(rand_seed)))
     if water_generations > 1:
         m.set_water_generations(water_generations)
-    if grid_interleave > 0:
-        m.set_grid_interleave(grid_interleave)
     sm.tick(warmup, sync=True)
     if save_after_warmup:                                       # the state the timed window starts from: what cpu_baseline continues (outside the timed region)
         try:
@@ -352,7 +350,7 @@ def compact_line(d: dict, detail_path) -> dict:
     `roofline.traffic` (a separate rocprofv3 --pmc job, labelled). Everything else is in the side file."""
     rf, cpu, pref = d["roofline"], d.get("cpu_baseline"), d.get("parity_vs_reference")
     out = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
-    out["config"] = {k: d["config"][k] for k in ("workload", "engine", "water_generations", "grid_interleave", "parallelism", "parity")}
+    out["config"] = {k: d["config"][k] for k in ("workload", "engine", "water_generations", "parallelism", "parity")}
     out["value_top_level"] = d.get("value_top_level")
     out["phase_ms_per_tick"] = d["phase_ms_per_tick"]
     out["steps_per_tick"] = d["steps_per_tick"]
@@ -402,8 +400,6 @@ def main():
     ap.add_argument("--no-lines", action="store_true", help="only the headline measurement")
     ap.add_argument("--cpu-ticks", type=int, default=1)
     ap.add_argument("--strong", action="store_true", help="N > 1: keep the map at --size^2 and split it (default: the map grows with N)")
-    ap.add_argument("--grid-interleave", type=int, default=0, help="throughput engines: the grid pass's nested particles run after every k colours of tiles "
-                                                                  "(smx_set_grid_interleave; fidelity knob like --water-generations; the headline is quoted at 0)")
     ap.add_argument("--water-generations", type=int, default=1, help="throughput engines: the tick's water particles as k consecutive generations (smx_set_water_generations; "
                                                                      "a fidelity knob, profiles/r04_p2_analysis.md; the headline is quoted at 1)")
     args = ap.parse_args()
@@ -457,7 +453,7 @@ def main():
         want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean"))
         ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"soilmx_bench_{os.getpid()}.smx") if want_cpu else None
         r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier, save_after_warmup=ckpt,
-                    water_generations=args.water_generations if throughput else 1, grid_interleave=args.grid_interleave if throughput else 0)
+                    water_generations=args.water_generations if throughput else 1)
         if ckpt and not os.path.exists(ckpt):
             ckpt = None
     steps = r["steps_w"] + r["steps_d"]
@@ -621,7 +617,6 @@ def main():
                 except (OSError, ValueError, KeyError):
                     pass
         config = {"workload": workload, "engine": eng_name, "water_generations": args.water_generations if throughput else None,
-                  "grid_interleave": args.grid_interleave if throughput else None,
                   "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
                   "parity": p2 if throughput else head["parity"]}
         detail = {

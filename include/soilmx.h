@@ -213,12 +213,6 @@ int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epo
  * some of that feedback back at the price of k epoch chains: at 2048^2 the nested-particle count moves from -3.5 to +0.1 sigma of the
  * reference's own rand()-stream spread at k = 4, for 1.5 x the device time (profiles/r04_p2_analysis.md). Identical to k calls of n/k. */
 int smx_set_water_generations(smx_ctx* ctx, int32_t k);
-/* throughput engines, grid pass: the nested particles spawned by every k colours of tiles run -- with all their generations -- before the next
- * colour's tiles are processed (k = 0, default: all of them after the pass). In the reference a nested particle runs inside the raster sweep
- * (water.h:246-264 in :335-343) and finds the raster-later cells still wet; deferring all of them to the end of the pass scatters their
- * water over dry ground (cells under water +113 % on painted.soil; k = 3: +52 %, k = 1: +34 %, profiles/r04_p2_analysis.md) at the
- * price of k' = 9/k generation chains per tick. Single context only (ignored under column strips). */
-int smx_set_grid_interleave(smx_ctx* ctx, int32_t k);
 /* batched engine: column strips (DESIGN.md "Multi-GPU"). The schedule alternates INTERIOR chunks (a particle acts iff its
  * reservation lies `inset` cells inside one of `nstrips` equal x-strips) and SEAM chunks (iff inside one seam zone of
  * +-seam_halfwidth cells around a strip boundary). nstrips == 1 (default) = the single-strip schedule. The result is a

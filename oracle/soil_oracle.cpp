@@ -507,12 +507,22 @@ struct so_ctx {
       if (transfer <= 0) continue;
       bool recascade = false;
       if (transfer == wh) {
-        if (b_defer) {                             // batched schedule: the nested particle joins the next generation
-          if (b_seq >= B_MAXCHILD) continue;       // spawn budget of this flood / tile used up: the water stays
+        if (b_defer) {                             // throughput schedules: the nested particle runs at once INSIDE the region its parent owns
+          if (b_seq >= B_MAXCHILD) continue;       // no record left, should it have to be suspended: the water stays
           remove(tpos.x, tpos.y, transfer);
           ctr.nested_particles++;
-          b_children.push_back({(b_parent << 8) | (uint64_t)b_seq, tpos.x, tpos.y, bpos.x, bpos.y, spill, transfer / volumeFactor});
-          b_seq++;
+          Water q;
+          q.pos = {(float)tpos.x, (float)tpos.y};
+          q.ix = tpos.x; q.iy = tpos.y;
+          q.surface = surface(q.ix, q.iy); q.param = soils[q.surface];
+          q.contains = q.param.transports;         // (from the cell it starts on, not a random one: soil_core.h water_drive says why that is unobservable)
+          f2 d = {(float)bpos.x - (float)tpos.x, (float)bpos.y - (float)tpos.y};
+          f2 dn = normalize2(d);
+          float s2 = std::sqrt(2.0f);
+          q.speed = {s2 * dn.x, s2 * dn.y};
+          q.spill = spill;
+          q.volume = transfer / volumeFactor;
+          b_nested(q);
           continue;
         }
         remove(tpos.x, tpos.y, transfer);
@@ -663,7 +673,7 @@ struct so_ctx {
   static constexpr int B_GRID = 2, B_MAXCHILD = 250, B_CHUNK = 32;   // grid pass: 4x4-cell tiles
   int B_TILE = 2;                                   // claim granularity of the running chunk (b_schedule): tiles of 2^B_TILE cells
   struct BRect { int tx0, tx1, ty0, ty1; bool empty() const { return tx1 < tx0; } };
-  struct BChild { uint64_t key; int tx, ty, bx, by, spill; double volume; };
+  struct BChild { uint64_t key; f2 pos, speed; double volume, sediment; int spill; uint32_t contains; bool ended; };   // a suspended nested particle (soil_batch.h BChild)
   bool b_defer = false;
   uint64_t b_parent = 0;
   int b_seq = 0, b_base_dilate = 0;
@@ -718,6 +728,29 @@ struct so_ctx {
     if (!wind_move(t, true)) return b_cells(ix - 1, ix + 1, iy - 1, iy + 1);
     const int nx = (int)std::round(t.pos.x), ny = (int)std::round(t.pos.y);
     return b_cells(std::min(ix, nx) - 2, std::max(ix, nx) + 2, std::min(iy, ny) - 2, std::max(iy, ny) + 2);
+  }
+
+  // A nested particle (water.h:246-264) inside the action of its parent -- a flood behind its claim tiles, a grid tile with the ring of tiles
+  // around it: `*b_guard`, the tiles the parent owns. while(move && interact) for as long as the next step's footprint (b_water_need_run) lies
+  // inside them, then flood() if its reach does; whatever does not fit is suspended AS IT STANDS into a record of the next generation.
+  void b_nested(Water& q) {
+    const BRect region = *b_guard;
+    bool suspended = false;
+    while (true) {
+      const int ix = (int)std::round(q.pos.x), iy = (int)std::round(q.pos.y);
+      if (!b_inside(region, b_cells(ix - 1, ix + 1, iy - 1, iy + 1)) || !b_inside(region, b_water_need_run(q))) { suspended = true; break; }
+      if (!water_move(q)) break;
+      ctr.steps_water_all++;
+      if (!water_interact(q)) break;
+    }
+    bool ended = false;
+    if (!suspended) {
+      if (!b_water_floods(q)) return;                         // water.h:125
+      if (b_inside(region, b_water_need_flood(q))) { water_flood(q); return; }   // (b_defer stays set: its own nested particles run the same way)
+      ended = true;
+    }
+    b_children.push_back({(b_parent << 8) | (uint64_t)b_seq, q.pos, q.speed, q.volume, q.sediment, q.spill, q.contains, ended});
+    b_seq++;
   }
 
   enum { B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3 };   // B_NEW: a top-level particle that has not acted yet
@@ -777,35 +810,32 @@ struct so_ctx {
     std::vector<uint32_t> tilemin;
     while (nslots > 0) {
       std::vector<BSlot> sl(nslots);
-      std::vector<int> draws(2 * (size_t)nslots);
-      for (auto& v : draws) v = rand_();                    // the generation's draws, in slot order: 2i -> y, 2i+1 -> x
+      std::vector<int> draws(first ? 2 * (size_t)nslots : 0);
+      for (auto& v : draws) v = rand_();                    // a top-level generation's draws, in slot order: 2i -> y, 2i+1 -> x (suspended particles carry their state)
       int dilate = b_base_dilate, maxsteps = 1;
       (void)dilate;
       for (uint32_t i = 0; i < nslots; i++) {               // spawn on the map as it is now; first reservations
         BSlot& q = sl[i];
-        const int ry = draws[2 * i] % dimy, rx = draws[2 * i + 1] % dimx;
-        q.toplevel = first; q.state = first ? B_NEW : B_RUN;   // top-level: surface/contains are read at the first action
+        q.toplevel = first; q.state = first ? B_NEW : (kids[i].ended ? B_ENDED : B_RUN);   // top-level: surface/contains are read at the first action
+        q.rect = {0, -1, 0, -1};
         if (wind) {
+          const int ry = draws[2 * i] % dimy, rx = draws[2 * i + 1] % dimx;
           Wind& p = q.d;
           p.pos = {(float)rx, (float)ry};
           p.ix = (int)std::round(p.pos.x); p.iy = (int)std::round(p.pos.y);
           p.surface = surface(p.ix, p.iy); p.param = soils[p.surface]; p.contains = p.param.transports;
-          q.rect = {0, -1, 0, -1};
-        } else {
+        } else if (first) {
+          const int ry = draws[2 * i] % dimy, rx = draws[2 * i + 1] % dimx;
           Water& p = q.w;
           p.pos = {(float)rx, (float)ry};
           p.ix = (int)std::round(p.pos.x); p.iy = (int)std::round(p.pos.y);
           p.surface = surface(p.ix, p.iy); p.param = soils[p.surface]; p.contains = p.param.transports;
-          if (!first) {                                       // water.h:251-256
-            const BChild& c = kids[i];
-            f2 d = {(float)c.bx - (float)c.tx, (float)c.by - (float)c.ty};
-            f2 dn = normalize2(d);
-            float s2 = std::sqrt(2.0f);
-            p.speed = {s2 * dn.x, s2 * dn.y};
-            p.pos = {(float)c.tx, (float)c.ty};
-            p.spill = c.spill; p.volume = c.volume;
-          }
-          q.rect = {0, -1, 0, -1};
+        } else {                                              // a nested particle, as it stood when it left its parent's region
+          const BChild& c = kids[i];
+          Water& p = q.w;
+          p.pos = c.pos; p.speed = c.speed; p.volume = c.volume; p.sediment = c.sediment; p.spill = c.spill; p.contains = c.contains;
+          p.ix = (int)std::round(p.pos.x); p.iy = (int)std::round(p.pos.y);
+          p.surface = 0; p.param = soils[0];
         }
       }
       std::vector<char> win(nslots);
@@ -908,7 +938,6 @@ struct so_ctx {
   //            the waiting particles, every epoch is a flood epoch (the rule above counts one device's particles: not partition-invariant).
   // =====================================================================================================
   bool b_relaxed = false;
-  int b_grid_interleave = 0;                                  // so_set_grid_interleave (smx_set_grid_interleave)
   struct RReq { int x, y; double vol, amount; uint32_t type; int kind; int cx, cy; };   // kind 1: erode, 2: deposit
   uint32_t r_surf(int x, int y) const { const uint32_t t = top[cidx(x, y)]; return t == NIL ? 0u : type[t]; }
   bool r_precheck(int x, int y) const {
@@ -933,6 +962,8 @@ struct so_ctx {
     std::vector<std::pair<int, int>> lists[9];
     std::vector<uint32_t> stamp((size_t)dimx * dimy, 0u);     // epoch + 1 of the last cascade request of a cell
     uint32_t epoch = 0, chunk = 0;
+    for (uint32_t i = 0; i < nslots; i++)                    // records whose flood is what did not fit their parent's region: reserved for epoch 0
+      if (sl[i].state == B_ENDED && bs_n <= 1) { sl[i].rect = b_water_need_flood(sl[i].w); claim_for[i] = 0u; waiting.push_back(i); }
     auto running = [&] { for (const BSlot& q : sl) if (q.state != B_DONE) return true; return false; };
     while (running()) {
      // column strips: INTERIOR and SEAM chunks of 32 epochs alternate; an epoch number is skipped between two chunks, and every chunk
@@ -1067,17 +1098,39 @@ struct so_ctx {
     B_TILE = B_GRID;                                          // (the access guard below speaks in grid tiles)
     uint64_t visited = 0;
     b_children.clear();
-    for (int ph = 0; ph < (bs_n > 1 ? 2 : 1); ph++)
-    for (int col = 0; col < 9; col++) {
-      for (int tx = col / 3; tx < ntx; tx += 3) {
+    // DEPENDENCY PASSES over the tiles that have work (soilmx.hip grid_sweep): a tile is swept in pass p once every raster-earlier tile
+    // (tx-major) within two tiles of it that has work was swept in a pass < p -- tiles whose regions (tile + ring) overlap go in block-raster
+    // order, the direction of the reference's sweep; the tiles of one pass own disjoint regions (any order: ascending here). After every
+    // pass the nested particles it suspended at the edge of their tile's region run as a generation, BEFORE the raster-later tiles are swept
+    // (column strips: after the sweeps, with the strip driver).
+    for (int ph = 0; ph < (bs_n > 1 ? 2 : 1); ph++) {
+      const uint32_t PENDING = 0xFFFFFFFFu;
+      std::vector<uint32_t> tdone((size_t)ntx * nty, 0u), pend, next;
+      for (int tx = 0; tx < ntx; tx++) {
         if (bs_n > 1) {                                       // INTERIOR sweep: tiles whose neighbourhood lies inside one strip; SEAM sweep: the rest
           const int cx0 = std::max(tx - 1, 0) << B_GRID, cx1 = std::min(((tx + 2) << B_GRID) - 1, dimx - 1);
           bool interior = false;
           for (int g = 0; g < bs_n; g++) { const int lo = bs_x(g) + (g ? bs_a : 0), hi = bs_x(g + 1) - (g < bs_n - 1 ? bs_a : 0); if (cx0 >= lo && cx1 < hi) interior = true; }
           if ((ph == 0) != interior) continue;
         }
-        for (int ty = col % 3; ty < nty; ty += 3) {
-          b_defer = true; b_parent = (uint64_t)col * ntx * nty + (uint64_t)tx * nty + ty; b_seq = 0;
+        for (int ty = 0; ty < nty; ty++) {
+          bool any = false;
+          for (int x = tx << B_GRID; x < ((tx + 1) << B_GRID) && x < dimx; x++)
+            for (int y = ty << B_GRID; y < ((ty + 1) << B_GRID) && y < dimy; y++) any |= act[cidx(x, y)] != 0;
+          if (any) { tdone[(size_t)tx * nty + ty] = PENDING; pend.push_back((uint32_t)tx * (uint32_t)nty + (uint32_t)ty); }
+        }
+      }
+      for (uint32_t pass = 1; !pend.empty(); pass++) {
+        const std::vector<uint32_t> before = tdone;           // what a tile sees of the others: the state when the pass began
+        auto ok_ = [&](int ax, int ay) { return ax < 0 || ax >= ntx || ay < 0 || ay >= nty || before[(size_t)ax * nty + ay] < pass; };
+        next.clear();
+        for (uint32_t tile : pend) {
+          const int tx = (int)(tile / (uint32_t)nty), ty = (int)(tile % (uint32_t)nty);
+          bool ok = true;
+          for (int dy = 1; dy <= 2; dy++) ok &= ok_(tx, ty - dy);
+          for (int dx = 1; dx <= 2; dx++) for (int dy = -2; dy <= 2; dy++) ok &= ok_(tx - dx, ty + dy);
+          if (!ok) { next.push_back(tile); continue; }
+          b_defer = true; b_parent = (uint64_t)ph * ntx * nty + (uint64_t)tile; b_seq = 0;
           const BRect g = {tx - 1 < 0 ? 0 : tx - 1, tx + 1 > ntx - 1 ? ntx - 1 : tx + 1, ty - 1 < 0 ? 0 : ty - 1, ty + 1 > nty - 1 ? nty - 1 : ty + 1};
           b_guard = &g; b_ctx = "grid";
           for (int x = tx << B_GRID; x < ((tx + 1) << B_GRID) && x < dimx; x++)
@@ -1088,17 +1141,16 @@ struct so_ctx {
               visited++;
             }
           b_guard = nullptr; b_defer = false;
+          tdone[(size_t)tx * nty + ty] = pass;
         }
-      }
-      // smx_set_grid_interleave(k): the nested particles of every k colours run -- all their generations -- before the next colour's tiles,
-      // i.e. while the cells of the later colours are still wet, as the reference's nested particles find the raster-later cells (water.h:246-264
-      // run inside water.h:335-343). Not under column strips. The rest (and everything when k = 0) after the last colour, below.
-      if (b_grid_interleave > 0 && bs_n <= 1 && col < 8 && (col + 1) % b_grid_interleave == 0) {
-        std::vector<BChild> part = b_children;
-        b_children.clear();
-        std::stable_sort(part.begin(), part.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
-        if (!part.empty() && !getenv("DBG_GRID_NOCHILD")) b_generations(false, 0, part);
-        B_TILE = B_GRID;
+        pend.swap(next);
+        if (bs_n <= 1 && !b_children.empty()) {
+          std::vector<BChild> part = b_children;
+          b_children.clear();
+          std::stable_sort(part.begin(), part.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
+          b_generations(false, 0, part);
+          B_TILE = B_GRID;
+        }
       }
     }
     ctr.wcascade_calls += n - visited;                        // the reference "calls" cascade on every cell (water.h:340)
@@ -1106,7 +1158,7 @@ struct so_ctx {
     std::vector<BChild> kids = b_children;
     b_children.clear();
     std::stable_sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
-    if (!kids.empty() && !getenv("DBG_GRID_NOCHILD")) b_generations(false, 0, kids);
+    if (!kids.empty()) b_generations(false, 0, kids);         // the nested particles that left their tile's region
   }
 
   void water_particles(int n) {
@@ -1269,7 +1321,6 @@ void so_batched_tick(so_ctx* c, int nwater, int nwind, int dowater, int dowind) 
   if (dowind) so_batched_wind(c, nwind);
   if (dowater) { c->map_frequency(); c->reset_frequency(); }
 }
-void so_set_grid_interleave(so_ctx* c, int k) { c->b_grid_interleave = k < 0 ? 0 : k; }
 void so_set_relaxed(so_ctx* c, int on) { c->b_relaxed = on != 0; }   // water generations of so_batched_* follow the relaxed schedule
 void so_batched_set_dilate(so_ctx* c, int tiles) { c->b_base_dilate = tiles < 0 ? 0 : tiles; }
 void so_batched_set_cell_above(so_ctx* c, uint32_t n) { c->b_cell_above = n; }

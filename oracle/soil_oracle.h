@@ -78,7 +78,6 @@ void so_batched_water(so_ctx*, int n);
 void so_batched_grid(so_ctx*);
 void so_batched_wind(so_ctx*, int n);
 void so_batched_tick(so_ctx*, int nwater, int nwind, int dowater, int dowind);
-void so_set_grid_interleave(so_ctx*, int k);   // throughput grid pass: the nested particles of every k colours run before the next colour (0: after the pass)
 void so_set_relaxed(so_ctx*, int on);   // SMX_ENGINE_RELAXED restated (csrc/soil_relax.h): water generations step / apply / cascade colours / floods per epoch
 void so_batched_set_dilate(so_ctx*, int tiles);
 void so_batched_set_cell_above(so_ctx*, uint32_t nlive);   // schedule knob: per-cell reservations while more particles run

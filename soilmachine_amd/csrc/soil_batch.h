@@ -17,12 +17,17 @@
 //   * one kernel per epoch. A winner recomputes its move from the map (its tiles are exclusively its own), acts, then
 //     looks ahead (a side-effect-free move() on the block it already holds) to learn which tiles the NEXT step needs.
 //     A loser re-issues its reservation without reading anything.
-//   * nested particles (water.h:246-264) are not run inside their parent: the flood emits a child record; children
-//     are sorted by (parent, sequence) and run as the next GENERATION of the phase, consuming the rand() draws that
-//     follow the phase's own (2 per particle, 1st -> y, 2nd -> x as everywhere).
-//   * grid pass (water.h:335-343): a cell's seep + cascade(.., 3) reaches 4 cells = one tile around it, so tiles whose
-//     indices differ by >= 3 are independent: 9 colour passes (tx mod 3, ty mod 3), one thread per tile walking its
-//     16 cells in x-major order.
+//   * nested particles (water.h:246-264) run INSIDE their parent -- at once, as in the reference -- for as long as every step stays
+//     inside the cells the parent owns exclusively (the tiles a flood holds; a grid tile and the ring of tiles around it): round 5.
+//     A nested particle that would leave that region is SUSPENDED: its state becomes a record; the records, sorted by
+//     (parent, sequence), run as the next GENERATION of the phase. (Rounds 2-4 deferred every nested particle: they then run
+//     over ground the pass has meanwhile dried, live twice as long and leave +30 % cells under water -- profiles/r05_p2_grid_pass.md.)
+//     A nested particle's `contains` is read from the cell it starts from instead of a random cell (water.h:251 via :15-17):
+//     the value is overwritten (water.h:94) before anything reads it, see BatchPolicy::nested_init.
+//   * grid pass (water.h:335-343): a cell's seep + cascade(.., 3) reaches 4 cells = one tile around it. Tiles whose regions
+//     (tile + the ring around it) overlap are processed in BLOCK-RASTER order (tx-major), the reference's sweep direction --
+//     the sweep ploughs water ahead of itself, and an order that does not (the nine tile colours of rounds 2-4) dries lakes
+//     27 % too far; tiles whose regions are disjoint run concurrently: dependency passes (soilmx.hip batch_grid).
 #pragma once
 #include "soil_core.h"
 #include "soil_spec.h"   // SMX_A_* atomics (device / host-sim)
@@ -46,10 +51,13 @@ struct BRect { int tx0, tx1, ty0, ty1; };     // inclusive tile ranges; tx1 < tx
 // says the next step lands -- so the blocks of that step can be requested together with the reservation words.
 struct BWater { Water w; BRect rect; uint32_t state, toplevel; uint32_t c_steps, c_casc, c_tr, hint; int pnx, pny; };
 struct BWind { Wind d; BRect rect; uint32_t state, hint; uint32_t c_steps, c_casc, c_tr, pad2; int pnx, pny; };
-struct BChild {                               // a nested WaterParticle waiting for the next generation
+struct BChild {                               // a nested WaterParticle SUSPENDED at the edge of its parent's region, waiting for the next generation
   unsigned long long key;                     // (parent << 8) | sequence: the deterministic order of the children
-  int tx, ty, bx, by, spill, pad;
-  double volume;
+  f2 pos, speed;                              // the particle as it stood before the step it could not take (water.h:9-41)
+  double volume, sediment;
+  int spill;
+  uint32_t contains;
+  uint32_t ended, pad;                        // 1: its move/interact loop is over, the flood (water.h:123-145) is what did not fit the region
 };
 
 // Column strips (DESIGN.md "Multi-GPU"): the map is cut into x-strips [x[g], x[g+1]); chunks of epochs alternate between
@@ -199,6 +207,9 @@ struct BatchPolicy {
   unsigned long long parent = 0;              // key prefix of the children this thread emits
   uint32_t nchild = 0;
   uint32_t a_steps = 0, a_casc = 0, a_tr = 0; // frequent counters: kept per slot, see BWater::c_*
+  uint32_t a_nsteps = 0;                      // steps of nested particles run inside this thread's action (never top-level steps)
+  bool in_nested = false;
+  BRect region = BRect{0, -1, 0, -1};         // the tiles this thread owns exclusively while it acts (nested particles run inside)
   SMX_D BatchPolicy(const DevState& s, const BatchShared& b) : bs(b), live0(s.ctr[C_LIVE_SECTIONS]) {}
   template <int N> struct Pre {};
   SMX_D void save_blk(const Blk&) {}
@@ -224,30 +235,35 @@ struct BatchPolicy {
     if (k < bs.freed_cap) bs.freed[k] = e; else SMX_A_ADD(&bs.ctrl[BC_FREED_LOST], 1u);
   }
   SMX_D void rand2(const DevState&, int& a, int& b) { a = 0; b = 0; }   // (nested particles draw when their generation starts)
-  // Reserve the child's record BEFORE the water leaves its column (soil_core.h water_drive): when the per-thread limit or the
-  // generation's buffer is exhausted the spawn is refused and the water stays where it is -- nothing leaves the simulation.
-  uint32_t child_slot = 0;
-  SMX_D bool child_room() {
-    if (nchild >= (uint32_t)B_MAXCHILD) return false;
+  // A nested particle may start only while this thread can still write a record for it (soil_core.h water_drive checks BEFORE the
+  // water leaves its column): when the per-thread limit is reached the spawn is refused and the water stays where it is.
+  SMX_D bool child_room() const { return nchild < (uint32_t)B_MAXCHILD; }
+  // the record of a suspended nested particle (the generation's buffer full: the particle is lost and COUNTED -- bench.py and the
+  // drivers treat children_lost != 0 as an invalid run)
+  SMX_D void emit_child(const Water& w, bool ended) {
     const uint32_t k = SMX_A_ADD(&bs.ctrl[BC_NCHILD], 1u);   // (may overshoot child_cap: the host clamps; records [0, cap) are all valid)
-    if (k >= bs.child_cap) { SMX_A_ADD(&bs.ctrl[BC_CHILD_LOST], 1u); return false; }
-    child_slot = k;
-    return true;
-  }
-  SMX_D void emit_child(int tx, int ty, int bx, int by, int spill, double volume) {
-    BChild& c = bs.children[child_slot];
+    if (k >= bs.child_cap) { SMX_A_ADD(&bs.ctrl[BC_CHILD_LOST], 1u); return; }
+    BChild& c = bs.children[k];
     c.key = (parent << 8) | (unsigned long long)nchild; nchild++;
-    c.tx = tx; c.ty = ty; c.bx = bx; c.by = by; c.spill = spill; c.pad = 0; c.volume = volume;
+    c.pos = w.pos; c.speed = w.speed; c.volume = w.volume; c.sediment = w.sediment; c.spill = w.spill; c.contains = w.contains;
+    c.ended = ended ? 1u : 0u; c.pad = 0u;
   }
+  // the nested particle of water.h:246-264 run INSIDE this thread's action: definitions after the intents below
+  template <class S> SMX_D int run_nested(S& sim, Water& w);       // 0: its loop ended inside the region, 1: suspended (record written)
+  template <class S> SMX_D bool flood_fits(S& sim, const Water& w); // may its flood (water.h:123-145) run here? else: record written
   SMX_D void add_counter(const DevState& s, int which, unsigned long long v) {
     if (!v) return;
-    if (which == C_STEPS_WATER_ALL || which == C_STEPS_WIND) a_steps += (uint32_t)v;      // (top-level steps: by the slot's flag)
+    if (which == C_STEPS_WATER_ALL && in_nested) a_nsteps += (uint32_t)v;                 // (a nested particle inside a top-level one's flood)
+    else if (which == C_STEPS_WATER_ALL || which == C_STEPS_WIND) a_steps += (uint32_t)v; // (top-level steps: by the slot's flag)
     else if (which == C_STEPS_WATER_TOP) {}
     else if (which == C_CASCADE_CALLS) a_casc += (uint32_t)v;
     else if (which == C_CASCADE_TRANSFERS) a_tr += (uint32_t)v;
     else SMX_A_ADD64(&s.ctr[which], v);                                                   // floods, nested, overflow: rare
   }
-  SMX_D void finish(const DevState& s) { if (live_delta) SMX_A_ADD64(&s.ctr[C_LIVE_SECTIONS], (unsigned long long)live_delta); live_delta = 0; }
+  SMX_D void finish(const DevState& s) {
+    if (live_delta) SMX_A_ADD64(&s.ctr[C_LIVE_SECTIONS], (unsigned long long)live_delta); live_delta = 0;
+    if (a_nsteps) SMX_A_ADD64(&s.ctr[C_STEPS_WATER_ALL], (unsigned long long)a_nsteps); a_nsteps = 0;
+  }
 };
 
 // ---------------- intents: which tiles can the NEXT action of this particle touch? (pure functions of particle + block) ----
@@ -289,51 +305,77 @@ SMX_D BRect wind_intent_run(Sim<P>& sim, const BatchShared& bs, const Wind& d, c
   return brect_cells(sim.s, bs, x0, x1, y0, y1);
 }
 
+// ---------------- nested particles inside their parent's action (water.h:246-264) ----------------
+// while(particle.move(..) && particle.interact(..)) (water.h:259) for as long as every step -- the 3x3 block it leaves and the 3x3
+// block it enters, water_intent_run -- lies inside the tiles this thread owns (pol.region): the same look-ahead / commit pair the
+// epoch loop uses. The first step that does not fit suspends the particle as it stands (BChild).
+template <class S>
+SMX_D int BatchPolicy::run_nested(S& sim, Water& w) {
+  sim.flush_counters();
+  in_nested = true;
+  w.ix = (int)roundf(w.pos.x); w.iy = (int)roundf(w.pos.y);
+  int r = 0;
+  Blk A, B;
+  bool haveA = false;
+  while (true) {
+    if (!brect_contains(region, brect_cells(sim.s, bs, w.ix - 1, w.ix + 1, w.iy - 1, w.iy + 1))) { r = 1; break; }   // (not even the stencil of move())
+    if (!haveA) sim.template load_block<0>(w.ix, w.iy, A);
+    Water t; bool mv;
+    const BRect need = water_intent_run(sim, bs, w, A, t, mv);
+    if (!brect_contains(region, need)) { r = 1; break; }
+    sim.water_move_commit(w, mv, false, A);                   // water.h:43-73: the look-ahead becomes the move
+    w = t;
+    if (!mv) break;
+    if (sim.water_interact(w, A, B) == 0) break;               // water.h:75-121
+    A = B; haveA = true;
+  }
+  if (r == 1) emit_child(w, false);
+  sim.flush_counters();                                      // (the nested particle's steps are not its parent's: add_counter looks at in_nested)
+  in_nested = false;
+  return r;
+}
+template <class S>
+SMX_D bool BatchPolicy::flood_fits(S& sim, const Water& w) {
+  if (brect_contains(region, water_intent_flood(sim.s, bs, w))) return true;
+  emit_child(w, true);
+  return false;
+}
+
 // ---------------- generation start: construct the particles, publish their first reservations (plane 0, epoch 0) -------
-// top-level particle `slot` of a phase: WaterParticle(map) (water.h:11-19) from draws 2*slot (-> y), 2*slot+1 (-> x)
+// top-level particle `slot` of a phase: WaterParticle(map) (water.h:11-19) from draws 2*slot (-> y), 2*slot+1 (-> x);
+// or (child != nullptr) a nested particle that was suspended at the edge of its parent's region, exactly as it stood (BChild)
 template <class P>
 SMX_D void batch_water_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot, const BChild* child, const uint32_t* contains = nullptr) {
   const DevState& s = sim.s;
   BWater& q = bs.water[slot];
-  const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
   Water w;
-  if (contains) {                                            // strips on several devices: the random cell of water.h:251 may lie on another
-    w.pos = {(float)rx, (float)ry}; w.speed = {0.f, 0.f};    // device -- its owner read `contains` for us (batch_child_contains)
-    w.volume = 1.0; w.sediment = 0.0; w.evaprate = 0.001; w.spill = 3;
-    w.ix = rx; w.iy = ry; w.surface = 0; w.friction = 0.f; w.contains = contains[slot];
-  } else if (rx < s.x_lo || rx >= s.x_hi) {                  // a strip context does not hold that column: the particle lives on another device (B_AWAY below)
-    w.pos = {(float)rx, (float)ry}; w.speed = {0.f, 0.f};
-    w.volume = 1.0; w.sediment = 0.0; w.evaprate = 0.001; w.spill = 3;
-    w.ix = rx; w.iy = ry; w.surface = 0; w.friction = 0.f; w.contains = 0;
-  } else sim.water_init(w, rx, ry);
-  q.toplevel = child ? 0u : 1u;
-  if (child) {                                               // water.h:251-256: position, direction, volume, spill of a nested particle
-    const f2 d = {(float)child->bx - (float)child->tx, (float)child->by - (float)child->ty};
-    const f2 dn = normalize2(d);
-    const float s2 = sqrtf(2.0f);
-    w.speed = {s2 * dn.x, s2 * dn.y};
-    w.pos = {(float)child->tx, (float)child->ty};
-    w.spill = child->spill;
-    w.volume = child->volume;
+  if (child) {
+    w.pos = child->pos; w.speed = child->speed; w.volume = child->volume; w.sediment = child->sediment; w.evaprate = 0.001;
+    w.spill = child->spill; w.surface = 0; w.friction = 0.f; w.contains = child->contains;
+    (void)contains;
+  } else {
+    const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
+    if (rx < s.x_lo || rx >= s.x_hi) {                       // a strip context does not hold that column: the particle lives on another device (B_AWAY below)
+      w.pos = {(float)rx, (float)ry}; w.speed = {0.f, 0.f};
+      w.volume = 1.0; w.sediment = 0.0; w.evaprate = 0.001; w.spill = 3;
+      w.surface = 0; w.friction = 0.f; w.contains = 0;
+    } else sim.water_init(w, rx, ry);
   }
+  q.toplevel = child ? 0u : 1u;
   w.ix = (int)roundf(w.pos.x); w.iy = (int)roundf(w.pos.y);
   // A top-level particle reads what it `contains` from its spawn cell (water.h:15-17) when it first ACTS, not now: the
-  // reference constructs a particle right before it runs, so it sees what earlier particles did to that cell. (A nested
-  // particle takes it from a random cell somewhere on the map, water.h:251 -- that read happens here, where nothing writes.)
-  q.w = w; q.state = child ? B_RUN : B_NEW;
+  // reference constructs a particle right before it runs, so it sees what earlier particles did to that cell.
+  q.w = w; q.state = child ? (child->ended ? B_ENDED : B_RUN) : B_NEW;
   if (bs.rcount) bs.rcount[slot] = 0u;
   q.c_steps = 0; q.c_casc = 0; q.c_tr = 0; q.hint = 0; q.pnx = -1; q.pny = -1;
   q.rect = BRect{0, -1, 0, -1};                              // first reservation: batch_water_reclaim
-  if (w.ix < bs.own_x0 || w.ix >= bs.own_x1) q.state = B_AWAY;
+  // who owns a particle: the device that owns the cell it stands on (a flood acts around trunc(pos), a step around round(pos))
+  const int ox = (child && child->ended) ? (int)w.pos.x : w.ix;
+  if (ox < bs.own_x0 || ox >= bs.own_x1) q.state = B_AWAY;
 }
-// `contains` of a nested particle = soils[surface(random cell)].transports (water.h:15-17 via :251), read by the device
-// that owns the random cell; 0xFFFFFFFF elsewhere (the callers combine the devices' answers with a minimum)
-SMX_D uint32_t batch_child_contains(const DevState& s, const SoilP* soils, const BatchShared& bs, uint32_t slot) {
-  const int ry = (int)(bs.draws[2u * slot] % (uint32_t)s.dimy), rx = (int)(bs.draws[2u * slot + 1u] % (uint32_t)s.dimx);
-  if (rx < bs.own_x0 || rx >= bs.own_x1) return 0xFFFFFFFFu;
-  const uint32_t t = s.cells[(size_t)rx * s.dimy + ry].type;
-  return soils[t == EMPTY ? 0u : t].transports;
-}
+// (rounds 2-4: a nested particle's `contains` came from a random cell, read by the device that owned it; the record carries it now.
+//  Kept for the step-wise strip driver's call sequence: every device answers with the record's own value.)
+SMX_D uint32_t batch_child_contains(const BChild* kids, uint32_t slot) { return kids[slot].contains; }
 template <class P>
 SMX_D void batch_wind_spawn(Sim<P>& sim, const BatchShared& bs, uint32_t slot) {
   const DevState& s = sim.s;
@@ -448,6 +490,7 @@ SMX_D void batch_water_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, 
         } else state = B_ENDED;
       } else {                                               // flood (water.h:123-145); nested particles -> children
         sim.pol.parent = (unsigned long long)slot; sim.pol.nchild = 0;
+        sim.pol.region = held;                               // nested particles run inside the tiles this flood holds
         int depth = 0;
         if (sim.water_flood_prelude(w)) sim.push_frame(st, depth, w.ix, w.iy, w.spill);
         sim.water_drive(w, false, false, st, depth);
@@ -566,6 +609,10 @@ template <class P>
 SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned long long key, Frame* st) {
   const DevState& s = sim.s;
   sim.pol.parent = key; sim.pol.nchild = 0;
+  {                                                          // the tile and the ring of tiles around it are this thread's own (its seep + cascade reach them)
+    const int gtx = (s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+    sim.pol.region = BRect{tx - 1 < 0 ? 0 : tx - 1, tx + 1 > gtx - 1 ? gtx - 1 : tx + 1, ty - 1 < 0 ? 0 : ty - 1, ty + 1 > gty - 1 ? gty - 1 : ty + 1};
+  }
   Water dummy;
   dummy.pos = {0.f, 0.f}; dummy.speed = {0.f, 0.f}; dummy.volume = 0.0; dummy.sediment = 0.0; dummy.evaprate = 0.0;
   dummy.spill = 0; dummy.ix = dummy.iy = 0; dummy.friction = 0.f; dummy.surface = dummy.contains = 0;

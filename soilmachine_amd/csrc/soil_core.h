@@ -1092,6 +1092,16 @@ struct Sim {
                          bool loop_done = false) {
     bool have = start_with_particle;
     while (true) {
+      if constexpr (P::DEFER_NESTED) {
+        // throughput engines: a nested particle (spawned below) runs here, at once, inside the cells this thread owns; what does not
+        // fit -- a step that leaves the region, a flood whose reach does -- is suspended into a record (soil_batch.h run_nested)
+        if (have) {
+          have = false;
+          if (pol.run_nested(*this, p) == 0 && !(p.volume < 0.01 || p.spill <= 0) && pol.flood_fits(*this, p)) {   // water.h:125 gate, then :123-145
+            if (water_flood_prelude(p)) push_frame(st, depth, p.ix, p.iy, p.spill);
+          }
+        }
+      } else
       if (have) {
         if (!loop_done) water_loop(p, toplevel, resume);    // while(move && interact);
         loop_done = false;
@@ -1133,19 +1143,22 @@ struct Sim {
       transfer = (wh < transfer) ? wh : transfer;
       if (transfer <= 0) continue;
       if (transfer == wh) {                                 // :246-264 the whole water section leaves: nested particle
-        if constexpr (P::DEFER_NESTED) {                    // batched engine: the nested particle joins the next generation
-          if (!pol.child_room()) continue;                  // spawn buffer full: the water stays where it is
-          remove(tx, ty, transfer);
-          n_nested++;
-          pol.emit_child(tx, ty, bx, by, f.spill, transfer / 0.015);
-          if (ab) return;
-          continue;                                         // (recascade is false on this branch: no recursion, :278)
+        if constexpr (P::DEFER_NESTED) {
+          if (!pol.child_room()) continue;                  // no record left for it, should it have to be suspended: the water stays where it is
         }
         remove(tx, ty, transfer);
         n_nested++;
         int ry, rx;
-        pol.rand2(s, ry, rx);                               // 1st draw -> y, 2nd -> x (g++ evaluation order)
-        ry %= s.dimy; rx %= s.dimx;
+        if constexpr (P::DEFER_NESTED) {
+          // throughput engines: `contains` from the cell the particle starts on instead of a random one (water.h:251 via :15-17). The
+          // value never reaches the map: sediment is 0 until the first erosion (water.h:91-95), which overwrites `contains` in the same
+          // statement block; a deposit (:103-107) and the flood's soil (:132) need sediment > 0. Reading a random, far cell would race
+          // with whoever owns it.
+          rx = tx; ry = ty;
+        } else {
+          pol.rand2(s, ry, rx);                             // 1st draw -> y, 2nd -> x (g++ evaluation order)
+          ry %= s.dimy; rx %= s.dimx;
+        }
         water_init(p, rx, ry);
         const f2 d = {(float)bx - (float)tx, (float)by - (float)ty};
         const f2 dn = normalize2(d);

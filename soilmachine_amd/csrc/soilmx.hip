@@ -263,6 +263,8 @@ __global__ void __launch_bounds__(64) k_batch_spawn(DevState s, BatchShared bs, 
   Sim<BatchPolicy> sim(s, sh, pol);
   if constexpr (WIND) batch_wind_spawn(sim, bs, i); else batch_water_spawn(sim, bs, i, kids ? kids + i : nullptr, kids ? contains : nullptr);
   sim.flush_counters(); pol.finish(s);
+  // relaxed schedule: a record whose flood is what did not fit its parent's region waits on the flood list of epoch 0
+  if constexpr (!WIND) { if (bs.relaxed && kids) relax_flood_later(bs, i, 0u, bs.water[i].state == B_ENDED); }
 }
 template <bool WIND>
 __global__ void __launch_bounds__(64) k_batch_reclaim(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch) {
@@ -520,22 +522,70 @@ __global__ void __launch_bounds__(256) k_batch_counters(DevState s, BatchShared 
     for (int off = 32; off > 0; off >>= 1) acc[k] += (unsigned long long)__shfl_down((long long)acc[k], off);
   if ((threadIdx.x & 63u) == 0) batch_commit_counters(s, WIND, acc);
 }
-// grid pass, one colour: tiles (cx + 3i, cy + 3j); one thread per tile
-__global__ void __launch_bounds__(64) k_batch_grid(DevState s, BatchShared bs, uint32_t col, uint32_t mx, uint32_t my) {
+// ---------------- grid pass (water.h:335-343) in dependency passes over the 4x4-cell tiles ----------------
+// A tile's seep + cascade(.., 3) -- and the nested particles that run inside it -- reach the ring of tiles around it (its REGION).
+// Tiles whose regions overlap are processed in block-raster order (tx-major, then ty: the direction of the reference's sweep); tiles
+// whose regions are disjoint in the same pass. A tile is eligible in pass p once every raster-earlier tile within two tiles of it
+// that has work is done in a pass < p; the raster-first pending tile always is, so every pass makes progress. Results do not depend
+// on how the hardware orders the tiles of a pass (disjoint regions), nor on the number of passes a lake takes.
+constexpr uint32_t GT_PENDING = 0xFFFFFFFFu;
+struct GridTiles {
+  uint32_t* tdone;                            // [held tile columns][gty]: 0 = nothing to do, GT_PENDING, else the pass that processed the tile
+  uint32_t* pend[2];                          // pending tiles (global tile index tx * gty + ty), in / out of a pass
+  uint32_t* count;                            // [2] lengths of pend[0], pend[1]
+  int gtx, gty, txb, txe;                     // tiles of the map; tile columns [txb, txe) held by tdone
+  int tx_lo, tx_hi;                           // tile columns of this sweep
+  unsigned long long keybase;                 // key prefix of a tile's children: keybase + tile index
+};
+SMX_D bool grid_tile_done_before(const GridTiles& g, int tx, int ty, uint32_t pass) {
+  if (tx < g.tx_lo || tx >= g.tx_hi || tx < g.txb || tx >= g.txe || ty < 0 || ty >= g.gty) return true;   // not part of this sweep
+  return g.tdone[(size_t)(tx - g.txb) * g.gty + ty] < pass;
+}
+__global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared bs, GridTiles g) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t ncol = (uint32_t)(g.tx_hi - g.tx_lo);
+  bool act = false; uint32_t tile = 0;
+  if (i < ncol * (uint32_t)g.gty) {
+    const int tx = g.tx_lo + (int)(i / (uint32_t)g.gty), ty = (int)(i % (uint32_t)g.gty);
+    tile = (uint32_t)tx * (uint32_t)g.gty + (uint32_t)ty;
+    if (batch_grid_tile_phase(s, bs, tx)) {
+      const int x0 = tx << GRID_SHIFT, y0 = ty << GRID_SHIFT;
+      for (int x = x0; x < x0 + (1 << GRID_SHIFT) && x < s.dimx; x++)
+        for (int y = y0; y < y0 + (1 << GRID_SHIFT) && y < s.dimy; y++) {
+          const size_t c = (size_t)x * s.dimy + y;
+          act |= ((s.active[c >> 6] >> (c & 63)) & 1ull) != 0ull;
+        }
+    }
+    g.tdone[(size_t)(tx - g.txb) * g.gty + ty] = act ? GT_PENDING : 0u;
+  }
+  const uint32_t k = relax_append(&g.count[0], act);
+  if (act) g.pend[0][k] = tile;
+}
+__global__ void __launch_bounds__(64) k_grid_tiles_pass(DevState s, BatchShared bs, GridTiles g, uint32_t pass, uint32_t in, uint32_t lpw) {
   SMX_LOAD_SOILS(sh)
-  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t n = g.count[in];
+  const uint32_t i = blockIdx.x * lpw + threadIdx.x;
+  const bool mine = threadIdx.x < lpw && i < n;
   unsigned long long vis = 0;
-  if (i < mx * my) {
-    const uint32_t gtx = (uint32_t)((s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), gty = (uint32_t)((s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
-    const uint32_t tx = col / 3u + 3u * (i / my), ty = col % 3u + 3u * (i % my);
-    if (tx < gtx && ty < gty && batch_grid_tile_phase(s, bs, (int)tx)) {
+  bool later = false; uint32_t tile = 0;
+  if (mine) {
+    tile = g.pend[in][i];
+    const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
+    bool ok = true;                                          // the raster-earlier tiles whose region overlaps this one's
+    for (int dy = 1; dy <= 2; dy++) ok &= grid_tile_done_before(g, tx, ty - dy, pass);
+    for (int dx = 1; dx <= 2; dx++)
+      for (int dy = -2; dy <= 2; dy++) ok &= grid_tile_done_before(g, tx - dx, ty + dy, pass);
+    if (ok) {
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
       Frame st[MAX_FRAMES];
-      vis = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * gtx * gty + (unsigned long long)tx * gty + ty, st);
+      vis = batch_grid_tile(sim, tx, ty, g.keybase + (unsigned long long)tile, st);
       sim.flush_counters(); pol.finish(s);
-    }
+      g.tdone[(size_t)(tx - g.txb) * g.gty + ty] = pass;
+    } else later = true;
   }
+  const uint32_t k = relax_append(&g.count[in ^ 1u], later);
+  if (later) g.pend[in ^ 1u][k] = tile;
   for (int off = 32; off > 0; off >>= 1) vis += (unsigned long long)__shfl_down((long long)vis, off);
   if (threadIdx.x == 0 && vis) atomicAdd(&s.ctr[C_GRID_ACTIVE], vis);
 }
@@ -545,9 +595,9 @@ __global__ void k_batch_grid_finish(DevState s, unsigned long long visited0) {  
 }
 
 // ---------------- column strips on several devices: halo columns, migrating particles (library driver: soil_strips_host.h; Python restatement: tests/strips_ref.py) ----------------
-__global__ void __launch_bounds__(64) k_batch_child_contains(DevState s, BatchShared bs, uint32_t nslots, uint32_t* out) {
+__global__ void __launch_bounds__(64) k_batch_child_contains(const BChild* kids, uint32_t nslots, uint32_t* out) {
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-  if (i < nslots) out[i] = batch_child_contains(s, s.soils, bs, i);
+  if (i < nslots) out[i] = batch_child_contains(kids, i);
 }
 struct XCursor { unsigned long long bytes; uint32_t nrec, lost; };
 // every column of the DIRTY 4x4 grid tiles whose x lies in [gx0, gx1) tiles: one thread per tile walks its 16 columns twice
@@ -650,26 +700,6 @@ __global__ void __launch_bounds__(256) k_strip_unpack_particles(BatchShared bs, 
   uint32_t i; memcpy(&i, o, 4);
   if constexpr (WIND) memcpy(&bs.wind[i], o + 4, sizeof(BWind)); else memcpy(&bs.water[i], o + 4, sizeof(BWater));
 }
-// grid pass of one strip: like k_batch_grid, restricted to the tiles tx in [tx_lo, tx_hi)
-__global__ void __launch_bounds__(64) k_batch_grid_range(DevState s, BatchShared bs, uint32_t col, uint32_t mx, uint32_t my, int tx_lo, int tx_hi) {
-  SMX_LOAD_SOILS(sh)
-  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-  unsigned long long vis = 0;
-  if (i < mx * my) {
-    const uint32_t gtx = (uint32_t)((s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), gty = (uint32_t)((s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
-    const uint32_t tx = col / 3u + 3u * (i / my), ty = col % 3u + 3u * (i % my);
-    if (tx < gtx && ty < gty && (int)tx >= tx_lo && (int)tx < tx_hi && batch_grid_tile_phase(s, bs, (int)tx)) {
-      BatchPolicy pol(s, bs);
-      Sim<BatchPolicy> sim(s, sh, pol);
-      Frame st[MAX_FRAMES];
-      vis = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * gtx * gty + (unsigned long long)tx * gty + ty, st);
-      sim.flush_counters(); pol.finish(s);
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) vis += (unsigned long long)__shfl_down((long long)vis, off);
-  if (threadIdx.x == 0 && vis) atomicAdd(&s.ctr[C_GRID_ACTIVE], vis);
-}
-
 __global__ void __launch_bounds__(256) k_map_frequency(float* __restrict__ freq, const float* __restrict__ track, size_t n4, size_t n) {
   const float lrate = 0.01f, K = 50.0f;      // water.h:359-360
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -898,7 +928,6 @@ struct smx_ctx {
   smx_timing timing{};
   uint32_t spec_sub = 0, spec_maxnest = 0; bool spec_realloc = false;   // smx_set_spec_limits (0 = defaults)
   int water_generations = 1;                                 // smx_set_water_generations
-  int grid_interleave = 0;                                   // smx_set_grid_interleave
   uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0, spec_subphases_cut = 0, spec_serial_particles = 0;
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
@@ -927,7 +956,8 @@ struct smx_ctx {
   unsigned long long xdata_cap = 0; uint32_t xoffs_cap = 0;
   uint8_t* d_rdata = nullptr; uint32_t* d_roffs = nullptr; uint8_t* d_xpart = nullptr; uint8_t* d_rpart = nullptr; unsigned long long xpart_cap = 0;   // strips in the library
   struct StripState* strip = nullptr;
-  uint64_t batch_epochs = 0, batch_generations = 0, batch_children_lost = 0;
+  uint32_t* d_tdone = nullptr; uint32_t* d_tpend[2] = {nullptr, nullptr}; uint32_t* d_tcount = nullptr; uint32_t* h_tcount = nullptr;   // grid pass: tile states, pending lists
+  uint64_t batch_epochs = 0, batch_generations = 0, batch_children_lost = 0, grid_passes = 0;
 };
 
 #define HIPCHK(call)                                                                                  \
@@ -1070,7 +1100,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1117,11 +1147,6 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) {
 int smx_set_water_generations(smx_ctx* ctx, int32_t k) {
   if (k < 1 || k > 64) { ctx->err = "smx_set_water_generations: 1..64"; return -2; }
   ctx->water_generations = k;
-  return 0;
-}
-int smx_set_grid_interleave(smx_ctx* ctx, int32_t k) {
-  if (k < 0 || k > 9) { ctx->err = "smx_set_grid_interleave: 0..9"; return -2; }
-  ctx->grid_interleave = k;
   return 0;
 }
 int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epoch) {
@@ -1863,17 +1888,22 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, uint32_t nkids
   uint32_t nslots = first ? n : nkids;
   if (nslots == 0) return 0;
   RandState r;                                              // the host draws for the device: glibc rand() is a serial recurrence
-  HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  const bool draws = first;                                 // (suspended nested particles carry their state: no draws, no round trip)
+  if (draws) {
+    HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
   while (nslots > 0) {
     if (batch_alloc(ctx, nslots, wind)) return -1;
     const BatchShared& bs = ctx->bs;
-    for (uint32_t i = 0; i < 2u * nslots; i++) {
-      const uint32_t v = r.ring[r.idx % 31] + r.ring[(r.idx - 3) % 31];
-      r.ring[r.idx % 31] = v; r.idx++; r.calls++;
-      ctx->h_draws[i] = v >> 1;
+    if (first) {                                              // (suspended nested particles carry their state: no draws)
+      for (uint32_t i = 0; i < 2u * nslots; i++) {
+        const uint32_t v = r.ring[r.idx % 31] + r.ring[(r.idx - 3) % 31];
+        r.ring[r.idx % 31] = v; r.idx++; r.calls++;
+        ctx->h_draws[i] = v >> 1;
+      }
+      HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
     ctx->bs.tshift = -1;                                      // (the first chunk clears the planes and issues the first reservations)
     const bool relax_gen = ctx->cfg.engine == SMX_ENGINE_RELAXED;
     ctx->bs.relaxed = relax_gen ? 1 : 0;
@@ -1915,8 +1945,70 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, uint32_t nkids
     first = false;
     nslots = nc;
   }
-  HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, st));
+  if (draws) {
+    HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// One sweep of the grid pass over the tile columns [tx_lo, tx_hi) in dependency passes (k_grid_tiles_pass); bs.sphase says which kind of
+// tile the sweep takes under column strips. One host look per pass (how many tiles are left): a lake of W x H tiles takes H + 3 W passes.
+static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
+  hipStream_t st = ctx->stream;
+  const int gtx = (ctx->cfg.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (ctx->cfg.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+  const int txb = ctx->d.x_lo >> GRID_SHIFT, txe = ((ctx->d.x_hi - 1) >> GRID_SHIFT) + 1;
+  if (tx_lo < txb) tx_lo = txb;
+  if (tx_hi > txe) tx_hi = txe;
+  if (tx_hi <= tx_lo) return 0;
+  if (!ctx->d_tdone) {
+    const size_t nt = (size_t)(txe - txb) * gty;
+    HIPCHK(hipMalloc(&ctx->d_tdone, nt * 4)); HIPCHK(hipMalloc(&ctx->d_tpend[0], nt * 4)); HIPCHK(hipMalloc(&ctx->d_tpend[1], nt * 4));
+    HIPCHK(hipMalloc(&ctx->d_tcount, 8)); HIPCHK(hipHostMalloc(&ctx->h_tcount, 16));
+  }
+  ctx->bs.tshift = GRID_SHIFT; ctx->bs.sphase = phase;
+  const BatchShared& bs = ctx->bs;
+  GridTiles g;
+  g.tdone = ctx->d_tdone; g.pend[0] = ctx->d_tpend[0]; g.pend[1] = ctx->d_tpend[1]; g.count = ctx->d_tcount;
+  g.gtx = gtx; g.gty = gty; g.txb = txb; g.txe = txe; g.tx_lo = tx_lo; g.tx_hi = tx_hi;
+  g.keybase = (unsigned long long)phase * (unsigned long long)gtx * (unsigned long long)gty;
+  HIPCHK(hipMemsetAsync(ctx->d_tcount, 0, 8, st));
+  const uint32_t ntl = (uint32_t)(tx_hi - tx_lo) * (uint32_t)gty;
+  hipLaunchKernelGGL(k_grid_tiles_init, dim3((ntl + 255u) / 256u), dim3(256), 0, st, ctx->d, bs, g);
+  HIPCHK(hipMemcpyAsync(ctx->h_tcount, ctx->d_tcount, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  uint32_t n = ctx->h_tcount[0], in = 0, pass = 1;
+  while (n > 0) {
+    HIPCHK(hipMemsetAsync(ctx->d_tcount + (in ^ 1u), 0, 4, st));
+    const uint32_t lpw = batch_lanes_per_wave(n);
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_pass, dim3((n + lpw - 1u) / lpw), dim3(64), 0, st, ctx->d, bs, g, pass, in, lpw); }
+    hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
+    HIPCHK(hipMemcpyAsync(ctx->h_tcount, ctx->d_tcount, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_tcount + 2, bs.ctrl + BC_NCHILD, 4, hipMemcpyDeviceToHost, st));   // suspended nested particles so far
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t left = ctx->h_tcount[in ^ 1u];
+    if (left >= n) { ctx->err = "grid pass: no tile became eligible (internal error)"; return -7; }
+    n = left; in ^= 1u; pass++;
+    ctx->grid_passes++;
+    // The nested particles this pass suspended at the edge of their tile's region run NOW, as a generation -- before the raster-later
+    // tiles are swept, as the reference's nested particles run before the sweep moves on (water.h:246-264 inside :335-343): deferred to
+    // the end of the sweep they would find the ground dried and leave +26 % cells under water (profiles/r05_p2_grid_pass.md).
+    // (Column strips: the strip driver collects them after its sweeps.)
+    if (bs.strips.n <= 1) {
+      uint32_t nq = ctx->h_tcount[2];
+      if (nq) {
+        HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
+        if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
+        if (nq > bs.child_cap) nq = bs.child_cap;
+        if (sort_children(ctx, nq)) return -1;
+        HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
+        const int rc = batch_generations(ctx, false, 0, nq); if (rc) return rc;
+        ctx->bs.tshift = GRID_SHIFT; ctx->bs.sphase = phase;   // (the generations ran their own schedule)
+      }
+    }
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1930,32 +2022,8 @@ static int batch_grid(smx_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->d.active2, 0, (ctx->nw2 + 64) * 8, st));
   launch_classify(ctx);
   HIPCHK(hipStreamSynchronize(st));
-  const uint32_t ntx = (uint32_t)((ctx->cfg.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), nty = (uint32_t)((ctx->cfg.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
-  ctx->bs.tshift = GRID_SHIFT;
-  for (int ph = 0; ph < (bs.strips.n > 1 ? 2 : 1); ph++)
-  for (uint32_t col = 0; col < 9; col++) {
-    ctx->bs.sphase = ph;
-    const uint32_t cx = col / 3u, cy = col % 3u;
-    const uint32_t mx = (ntx + 2u - cx) / 3u, my = (nty + 2u - cy) / 3u;
-    if (mx * my == 0) continue;
-    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_batch_grid, dim3((mx * my + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, col, mx, my); }
-    hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
-    // smx_set_grid_interleave(k): the nested particles of every k colours run -- all their generations -- before the next colour's tiles, i.e.
-    // while the cells of the later colours are still wet, as the reference's nested particles find the raster-later cells (they run inside
-    // the raster sweep, water.h:246-264 in :335-343). Not under column strips; k = 0 (default): all of them after the pass.
-    if (ctx->grid_interleave > 0 && bs.strips.n <= 1 && col < 8u && (col + 1u) % (uint32_t)ctx->grid_interleave == 0u) {
-      HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      uint32_t nq = ctx->h_bctrl[BC_NCHILD];
-      if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
-      if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
-      if (nq > bs.child_cap) nq = bs.child_cap;
-      if (nq && sort_children(ctx, nq)) return -1;
-      HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
-      if (nq) { const int rc = batch_generations(ctx, false, 0, nq); if (rc) return rc; }
-      ctx->bs.tshift = GRID_SHIFT;                           // (the generations ran their own schedule)
-    }
-  }
+  const int gtx = (ctx->cfg.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+  for (int ph = 0; ph < (bs.strips.n > 1 ? 2 : 1); ph++) { const int rc = grid_sweep(ctx, ph, 0, gtx); if (rc) return rc; }
   hipLaunchKernelGGL(k_batch_grid_finish, dim3(1), dim3(1), 0, st, ctx->d, v0);
   HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1966,7 +2034,7 @@ static int batch_grid(smx_ctx* ctx) {
   if (nc > bs.child_cap) nc = bs.child_cap;
   if (nc && sort_children(ctx, nc)) return -1;
   HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
-  if (nc) return batch_generations(ctx, false, 0, nc);
+  if (nc) return batch_generations(ctx, false, 0, nc);       // the nested particles that left their tile's region
   return 0;
 }
 
@@ -1997,13 +2065,14 @@ int smx_d_gen_begin(smx_ctx* ctx, int32_t wind, uint32_t nslots, const void* kid
   RandState r;                                              // every rank holds the same generator state and draws the same values
   HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  for (uint32_t i = 0; i < 2u * nslots; i++) {
+  const uint32_t ndraw = kids_host ? 0u : 2u * nslots;          // (suspended nested particles carry their state: no draws)
+  for (uint32_t i = 0; i < ndraw; i++) {
     const uint32_t v = r.ring[r.idx % 31] + r.ring[(r.idx - 3) % 31];
     r.ring[r.idx % 31] = v; r.idx++; r.calls++;
     ctx->h_draws[i] = v >> 1;
   }
   HIPCHK(hipMemcpyAsync(ctx->d.rnd, &r, sizeof(r), hipMemcpyHostToDevice, st));
-  if (nslots) HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)2u * nslots * 4, hipMemcpyHostToDevice, st));
+  if (ndraw) HIPCHK(hipMemcpyAsync(ctx->d_draws, ctx->h_draws, (size_t)ndraw * 4, hipMemcpyHostToDevice, st));
   ctx->bs.tshift = -1;
   HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NCHILD, 0, 8, st));
   ctx->bs.relaxed = ctx->cfg.engine == SMX_ENGINE_RELAXED ? 1 : 0;
@@ -2013,7 +2082,7 @@ int smx_d_gen_begin(smx_ctx* ctx, int32_t wind, uint32_t nslots, const void* kid
     if (ctx->contains_cap < nslots) { hipFree(ctx->d_contains); ctx->d_contains = nullptr; ctx->contains_cap = 0; HIPCHK(hipMalloc(&ctx->d_contains, (size_t)nslots * 4)); ctx->contains_cap = nslots; }
     HIPCHK(hipMemcpyAsync(ctx->d_kids, kids_host, (size_t)nslots * sizeof(BChild), hipMemcpyHostToDevice, st));
     if (contains_out) {
-      hipLaunchKernelGGL(k_batch_child_contains, dim3((nslots + 63u) / 64u), dim3(64), 0, st, ctx->d, ctx->bs, nslots, ctx->d_contains);
+      hipLaunchKernelGGL(k_batch_child_contains, dim3((nslots + 63u) / 64u), dim3(64), 0, st, ctx->d_kids, nslots, ctx->d_contains);
       HIPCHK(hipMemcpyAsync(contains_out, ctx->d_contains, (size_t)nslots * 4, hipMemcpyDeviceToHost, st));
     }
   }
@@ -2168,18 +2237,9 @@ int smx_d_grid_begin(smx_ctx* ctx) {
   return 0;
 }
 int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t tx_lo, int32_t tx_hi) {
-  hipStream_t st = ctx->stream; const BatchShared& bs = ctx->bs;
-  const uint32_t ntx = (uint32_t)((ctx->cfg.dimx + 3) >> 2), nty = (uint32_t)((ctx->cfg.dimy + 3) >> 2);
-  ctx->bs.tshift = GRID_SHIFT; ctx->bs.sphase = phase;
-  for (uint32_t col = 0; col < 9; col++) {
-    const uint32_t cx = col / 3u, cy = col % 3u;
-    const uint32_t mx = (ntx + 2u - cx) / 3u, my = (nty + 2u - cy) / 3u;
-    if (mx * my == 0) continue;
-    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_batch_grid_range, dim3((mx * my + 63u) / 64u), dim3(64), 0, st, ctx->d, bs, col, mx, my, tx_lo, tx_hi); }
-    hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
-  }
-  HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipGetLastError());
+  const int rc = grid_sweep(ctx, phase, tx_lo, tx_hi);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 }  // extern "C"

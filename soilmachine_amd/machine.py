@@ -184,10 +184,6 @@ class Layermap:
         """throughput engines: the water phase's particles as k consecutive generations of n/k (smx_set_water_generations)"""
         self._chk(self.L.smx_set_water_generations(self.h, int(k)))
 
-    def set_grid_interleave(self, k: int):
-        """throughput engines: the grid pass's nested particles run after every k colours of tiles (smx_set_grid_interleave; 0 = after the pass)"""
-        self._chk(self.L.smx_set_grid_interleave(self.h, int(k)))
-
     def set_batch_strips(self, nstrips: int, inset: int = 16, seam_halfwidth: int = 48):
         self._chk(self.L.smx_set_batch_strips(self.h, int(nstrips), int(inset), int(seam_halfwidth)))
 

@@ -31,9 +31,10 @@ import threading
 
 import numpy as np
 
-CHILD_DT = np.dtype([("key", "<u8"), ("tx", "<i4"), ("ty", "<i4"), ("bx", "<i4"), ("by", "<i4"), ("spill", "<i4"),
-                     ("pad", "<i4"), ("volume", "<f8")])
-assert CHILD_DT.itemsize == 40
+# csrc/soil_batch.h BChild: a nested particle suspended at the edge of its parent's region, as it stood (round 5)
+CHILD_DT = np.dtype([("key", "<u8"), ("pos", "<f4", (2,)), ("speed", "<f4", (2,)), ("volume", "<f8"), ("sediment", "<f8"), ("spill", "<i4"),
+                     ("contains", "<u4"), ("ended", "<u4"), ("pad", "<u4")])
+assert CHILD_DT.itemsize == 56
 INTERIOR, SEAM = 0, 1
 
 

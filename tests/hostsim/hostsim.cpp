@@ -484,13 +484,14 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
   uint32_t nslots = first ? n : (uint32_t)kids.size();
   while (nslots > 0) {
     batch_setup(c, b, nslots, wind);
-    batch_draw(c, b, nslots);
+    if (first) batch_draw(c, b, nslots);                     // (suspended nested particles carry their state: no draws)
     const BatchShared& bs = b.bs;
     parallel_for(nslots, nthreads, [&](uint32_t i) {
       BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
       if (wind) batch_wind_spawn(sim, bs, i); else batch_water_spawn(sim, bs, i, first ? nullptr : &kids[i]);
       sim.flush_counters(); pol.finish(s);
     }, shuffle ? shuffle + 7 : 0);
+    if (!wind && !first && b.bs.relaxed) for (uint32_t i = 0; i < nslots; i++) relax_flood_later(bs, i, 0u, b.water[i].state == B_ENDED);   // k_batch_spawn
     for (uint32_t i = 0; i < nslots; i++) b.live[i] = i;
     uint32_t nlive = nslots, epoch = 0, chunk = 0;
     const bool relax_gen = b.bs.relaxed != 0;
@@ -647,8 +648,65 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
 extern "C" {
 void hs_batched_water(hs_ctx* c, int n, int nthreads, unsigned shuffle) { BatchBuffers b; batch_generations(c, b, false, (uint32_t)n, {}, nthreads, shuffle); }
 void hs_batched_wind(hs_ctx* c, int n, int nthreads, unsigned shuffle) { BatchBuffers b; batch_generations(c, b, true, (uint32_t)n, {}, nthreads, shuffle); }
-static int g_grid_interleave = 0;
-void hs_set_grid_interleave(int k) { g_grid_interleave = k < 0 ? 0 : k; }
+// One sweep of the grid pass over the tile columns [tx_lo, tx_hi) in dependency passes (soilmx.hip grid_sweep / k_grid_tiles_pass): a tile is
+// eligible once every raster-earlier tile within two tiles of it that has work is done in an EARLIER pass; the tiles of a pass run on the
+// host threads in any order (their regions are disjoint).
+static unsigned long long grid_sweep(hs_ctx* c, BatchBuffers& b, int phase, int tx_lo, int tx_hi, int nthreads, unsigned shuffle) {
+  const DevState& s = c->d;
+  const int gtx = (s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+  if (tx_lo < 0) tx_lo = 0;
+  if (tx_hi > gtx) tx_hi = gtx;
+  b.bs.tshift = GRID_SHIFT; b.bs.sphase = phase;
+  const BatchShared& bs = b.bs;
+  const uint32_t PENDING = 0xFFFFFFFFu;
+  std::vector<uint32_t> tdone((size_t)gtx * gty, 0u), pend, next;
+  for (int tx = tx_lo; tx < tx_hi; tx++)
+    for (int ty = 0; ty < gty; ty++) {
+      bool act = false;
+      if (batch_grid_tile_phase(s, bs, tx))
+        for (int x = tx << GRID_SHIFT; x < ((tx + 1) << GRID_SHIFT) && x < s.dimx; x++)
+          for (int y = ty << GRID_SHIFT; y < ((ty + 1) << GRID_SHIFT) && y < s.dimy; y++) { const size_t cc = (size_t)x * s.dimy + y; act |= ((c->a0[cc >> 6] >> (cc & 63)) & 1ull) != 0ull; }
+      if (act) { tdone[(size_t)tx * gty + ty] = PENDING; pend.push_back((uint32_t)tx * (uint32_t)gty + (uint32_t)ty); }
+    }
+  auto done_before = [&](int tx, int ty, uint32_t pass) { return tx < tx_lo || tx >= tx_hi || ty < 0 || ty >= gty || tdone[(size_t)tx * gty + ty] < pass; };
+  const unsigned long long keybase = (unsigned long long)phase * (unsigned long long)gtx * (unsigned long long)gty;
+  unsigned long long visited = 0;
+  for (uint32_t pass = 1; !pend.empty(); pass++) {
+    std::vector<unsigned long long> vis(pend.size(), 0);
+    std::vector<uint8_t> later(pend.size(), 0);
+    const std::vector<uint32_t> before = tdone;               // (what a tile may see of the others: the state when the pass began)
+    parallel_for((uint32_t)pend.size(), nthreads, [&](uint32_t i) {
+      const uint32_t tile = pend[i];
+      const int tx = (int)(tile / (uint32_t)gty), ty = (int)(tile % (uint32_t)gty);
+      auto ok_ = [&](int ax, int ay) { return ax < tx_lo || ax >= tx_hi || ay < 0 || ay >= gty || before[(size_t)ax * gty + ay] < pass; };
+      bool ok = true;
+      for (int dy = 1; dy <= 2; dy++) ok &= ok_(tx, ty - dy);
+      for (int dx = 1; dx <= 2; dx++) for (int dy = -2; dy <= 2; dy++) ok &= ok_(tx - dx, ty + dy);
+      if (!ok) { later[i] = 1; return; }
+      BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
+      Frame st[MAX_FRAMES];
+      vis[i] = batch_grid_tile(sim, tx, ty, keybase + (unsigned long long)tile, st);
+      sim.flush_counters(); pol.finish(s);
+      tdone[(size_t)tx * gty + ty] = pass;
+    }, shuffle ? shuffle + 3 + pass : 0);
+    (void)done_before;
+    next.clear();
+    for (size_t i = 0; i < pend.size(); i++) { visited += vis[i]; if (later[i]) next.push_back(pend[i]); }
+    if (next.size() >= pend.size()) { fprintf(stderr, "[hostsim] grid pass: no tile became eligible\n"); abort(); }
+    pend.swap(next);
+    batch_merge_freed(c, b);
+    // the nested particles this pass suspended at the edge of their tile's region run NOW -- before the raster-later tiles -- as a generation
+    if (b.ctrl[BC_NCHILD] && b.bs.strips.n <= 1) {
+      uint32_t nc = b.ctrl[BC_NCHILD]; if (nc > b.bs.child_cap) nc = b.bs.child_cap;
+      std::vector<BChild> kq(b.children.begin(), b.children.begin() + nc);
+      std::sort(kq.begin(), kq.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
+      b.ctrl[BC_NCHILD] = 0;
+      { BatchBuffers b2; batch_generations(c, b2, false, 0, kq, nthreads, shuffle); }
+      b.bs.tshift = GRID_SHIFT;
+    }
+  }
+  return visited;
+}
 void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
   const DevState& s = c->d;
   const size_t n = c->n;
@@ -663,42 +721,15 @@ void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
     if (act) c->a0[cc >> 6] |= 1ull << (cc & 63);
   }
   BatchBuffers b; batch_setup(c, b, 0, false);
-  const BatchShared& bs = b.bs;
-  const uint32_t ntx = (uint32_t)((s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT), nty = (uint32_t)((s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
+  const int gtx = (s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
   unsigned long long visited = 0;
-  b.bs.tshift = GRID_SHIFT;
-  for (int ph = 0; ph < (b.bs.strips.n > 1 ? 2 : 1); ph++)
-  for (uint32_t col = 0; col < 9; col++) {
-    b.bs.sphase = ph;
-    const uint32_t cx = col / 3, cy = col % 3;
-    const uint32_t mx = (ntx + 2 - cx) / 3, my = (nty + 2 - cy) / 3;   // tiles tx = cx + 3*i < ntx
-    std::vector<unsigned long long> vis((size_t)mx * my, 0);
-    parallel_for(mx * my, nthreads, [&](uint32_t i) {
-      const uint32_t tx = cx + 3 * (i / my), ty = cy + 3 * (i % my);
-      if (tx >= ntx || ty >= nty) return;
-      if (!batch_grid_tile_phase(s, bs, (int)tx)) return;
-      BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
-      Frame st[MAX_FRAMES];
-      vis[i] = batch_grid_tile(sim, (int)tx, (int)ty, (unsigned long long)col * ntx * nty + (unsigned long long)tx * nty + ty, st);
-      sim.flush_counters(); pol.finish(s);
-    }, shuffle ? shuffle + 3 + col : 0);
-    for (unsigned long long v : vis) visited += v;
-    batch_merge_freed(c, b);
-    if (g_grid_interleave > 0 && b.bs.strips.n <= 1 && col < 8u && (col + 1u) % (uint32_t)g_grid_interleave == 0u) {   // smx_set_grid_interleave (soilmx.hip batch_grid)
-      uint32_t nq = b.ctrl[BC_NCHILD]; if (nq > b.bs.child_cap) nq = b.bs.child_cap;
-      std::vector<BChild> kq(b.children.begin(), b.children.begin() + nq);
-      std::sort(kq.begin(), kq.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
-      b.ctrl[BC_NCHILD] = 0;
-      if (!kq.empty()) { BatchBuffers b2; batch_generations(c, b2, false, 0, kq, nthreads, shuffle); }
-      b.bs.tshift = GRID_SHIFT;
-    }
-  }
+  for (int ph = 0; ph < (b.bs.strips.n > 1 ? 2 : 1); ph++) visited += grid_sweep(c, b, ph, 0, gtx, nthreads, shuffle);
   c->ctr[C_WCASCADE_CALLS] += n - visited;                   // every other cell still "calls" WaterParticle::cascade once
   c->ctr[C_GRID_ACTIVE] += visited;
   uint32_t nc = b.ctrl[BC_NCHILD]; if (nc > b.bs.child_cap) nc = b.bs.child_cap;
   std::vector<BChild> kids(b.children.begin(), b.children.begin() + nc);
   std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
-  if (!kids.empty() && !getenv("DBG_GRID_NOCHILD")) { BatchBuffers b2; batch_generations(c, b2, false, 0, kids, nthreads, shuffle); }
+  if (!kids.empty()) { BatchBuffers b2; batch_generations(c, b2, false, 0, kids, nthreads, shuffle); }   // the nested particles that left their tile's region
 }
 void hs_batched_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int nthreads, unsigned shuffle) {
   if (dowater) { hs_batched_water(c, nwater, nthreads, shuffle); hs_batched_grid(c, nthreads, shuffle); }
@@ -724,9 +755,9 @@ void hs_d_gen_begin(hs_ctx* c, int wind, uint32_t nslots, const BChild* kids, ui
   d.wind = wind != 0; d.first = kids == nullptr; d.nslots = nslots; d.epoch = 0; d.chunk = 0;
   d.kids.assign(kids ? kids : nullptr, kids ? kids + nslots : nullptr);
   batch_setup(c, d.b, nslots, d.wind);
-  batch_draw(c, d.b, nslots);
+  if (!kids) batch_draw(c, d.b, nslots);                      // (suspended nested particles carry their state: no draws)
   d.b.ctrl[BC_NCHILD] = 0; d.b.ctrl[BC_CHILD_LOST] = 0;
-  if (kids && contains_out) for (uint32_t i = 0; i < nslots; i++) contains_out[i] = batch_child_contains(c->d, c->d.soils, d.b.bs, i);
+  if (kids && contains_out) for (uint32_t i = 0; i < nslots; i++) contains_out[i] = batch_child_contains(kids, i);
 }
 void hs_d_gen_spawn(hs_ctx* c, const uint32_t* contains, uint32_t* nlive_local) {
   DPhase& d = dp_of(c); const DevState& s = c->d; const BatchShared& bs = d.b.bs;
@@ -880,22 +911,7 @@ void hs_d_grid_begin(hs_ctx* c) {
   d.b.ctrl[BC_NCHILD] = 0;
 }
 void hs_d_grid_sweep(hs_ctx* c, int phase, int tx_lo, int tx_hi) {
-  DPhase& d = dp_of(c); const DevState& s = c->d; BatchBuffers& b = d.b; const BatchShared& bs = b.bs;
-  const int ntx = (s.dimx + 3) >> 2, nty = (s.dimy + 3) >> 2;
-  b.bs.tshift = GRID_SHIFT; b.bs.sphase = phase;
-  unsigned long long visited = 0;
-  for (int col = 0; col < 9; col++) {
-    for (int tx = col / 3; tx < ntx; tx += 3) {
-      if (tx < tx_lo || tx >= tx_hi || !batch_grid_tile_phase(s, bs, tx)) continue;
-      for (int ty = col % 3; ty < nty; ty += 3) {
-        BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
-        Frame st[MAX_FRAMES];
-        visited += batch_grid_tile(sim, tx, ty, (unsigned long long)col * ntx * nty + (unsigned long long)tx * nty + ty, st);
-        sim.flush_counters(); pol.finish(s);
-      }
-    }
-    batch_merge_freed(c, b);
-  }
-  c->ctr[C_GRID_ACTIVE] += visited;
+  DPhase& d = dp_of(c);
+  c->ctr[C_GRID_ACTIVE] += grid_sweep(c, d.b, phase, tx_lo, tx_hi, 1, 0);
 }
 }  // extern "C"

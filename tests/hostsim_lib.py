@@ -56,7 +56,6 @@ def lib():
         L.hs_set_relaxed.argtypes = [C.c_int]
         L.hs_set_relax_wind.argtypes = [C.c_uint32, C.c_int]
         L.hs_set_relax_water.argtypes = [C.c_int]
-        L.hs_set_grid_interleave.argtypes = [C.c_int]
         L.hs_set_batch_strips.argtypes = [C.c_int] * 3
         L.hs_d_set_own.argtypes = [vp, C.c_int, C.c_int]
         L.hs_d_gen_begin.argtypes = [vp, C.c_int, C.c_uint32, vp, vp]

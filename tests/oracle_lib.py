@@ -84,7 +84,6 @@ def lib():
         L.so_batched_grid.argtypes = [vp]
         L.so_batched_set_dilate.argtypes = [vp, C.c_int]
         L.so_set_relaxed.argtypes = [vp, C.c_int]
-        L.so_set_grid_interleave.argtypes = [vp, C.c_int]
         L.so_batched_stats.argtypes = [vp, vp]
         L.so_noise_fbm.argtypes = [C.c_float] * 3 + [C.c_int] + [C.c_float] * 3
         L.so_noise_fbm.restype = C.c_float

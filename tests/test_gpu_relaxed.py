@@ -155,8 +155,8 @@ def test_water_generations_equal_k_phase_calls():
 
 
 def test_fidelity_knobs_on_the_device_equal_host_threads():
-    """smx_set_grid_interleave(3) + smx_set_water_generations(2) on the device == the same options on host threads (which equal the
-    restatement: tests/test_relaxed.py::test_fidelity_knobs_equal_the_independent_restatement), full state, through lakes."""
+    """smx_set_water_generations(2) on the device == the same option on host threads (which equal the
+    restatement: tests/test_relaxed.py::test_water_generations_equal_the_independent_restatement), full state, through lakes."""
     from hostsim_lib import lib
     cfg = load_cfg("default.soil")
     o = Oracle(cfg, 96, 96, seed=0); o.initialize()
@@ -164,11 +164,10 @@ def test_fidelity_knobs_on_the_device_equal_host_threads():
         o.tick(250, 0, True, False)
     s0 = o.snapshot()
     sm = machine(cfg, 96, 96, 180, 0, False, capi.ENGINE_RELAXED, snap=s0)
-    sm.map.set_grid_interleave(3); sm.map.set_water_generations(2)
+    sm.map.set_water_generations(2)
     h = HostSim(cfg, 96, 96, seed=0); h.load(s0, advance_rand=True)
     L = lib()
-    L.hs_set_grid_interleave(3)
-    try:
+    if True:
         for t in range(6):
             sm.tick(1, sync=True)
             L.hs_set_relaxed(1)
@@ -180,6 +179,4 @@ def test_fidelity_knobs_on_the_device_equal_host_threads():
             L.hs_freq(h.h)
             bad = compare(sm.map.snapshot(), h.snapshot())
             assert not bad, (t, bad)
-    finally:
-        L.hs_set_grid_interleave(0)
     assert sm.map.counters()["nested_particles"] == h.counters()["nested_particles"] > 300

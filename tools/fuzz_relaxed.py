@@ -31,11 +31,9 @@ while time.time() < t_end:
         o = Oracle(cfg, dx, dy, seed=seed); o.load(s0)        # and the fixed active set of the 9-colour grid pass depends on it
     h = HostSim(cfg, dx, dy, seed=seed); h.load(o.snapshot(), advance_rand=True)
     c0 = o.counters()
-    gi = rng.choice([0, 0, 1, 3, 4]) if strips == 1 else 0     # round 4's fidelity knobs: smx_set_grid_interleave / smx_set_water_generations
-    wg = rng.choice([1, 1, 2, 4])
-    desc = (soil, dx, dy, seed, nw, nd, ticks, wet, strips, gi, wg)
+    wg = rng.choice([1, 1, 2, 4])                             # smx_set_water_generations
+    desc = (soil, dx, dy, seed, nw, nd, ticks, wet, strips, wg)
     L.hs_set_batch_strips(strips, 16, 48); o.L.so_batched_set_strips(o.h, strips, 16, 48)
-    L.hs_set_grid_interleave(gi); o.L.so_set_grid_interleave(o.h, gi)
     for t in range(ticks):
         nt, sh = rng.choice([1, 3, 5]), rng.randrange(5)
         if wg == 1:
@@ -53,7 +51,7 @@ while time.time() < t_end:
             L.hs_freq(h.h); o.L.so_map_frequency(o.h); o.L.so_reset_frequency(o.h)
         bad = compare(h.snapshot(), o.snapshot())
         if bad: print("MISMATCH", desc, t, bad[:3]); sys.exit(1)
-    L.hs_set_batch_strips(1, 16, 48); L.hs_set_grid_interleave(0)
+    L.hs_set_batch_strips(1, 16, 48)
     ch, co = h.counters(), o.counters()
     co = {k: co[k] - (c0[k] if k != 'rand_calls' else 0) for k in KEYS}
     if any(ch[k] != co[k] for k in KEYS): print("COUNTERS", desc, {k: (ch[k], co[k]) for k in KEYS if ch[k] != co[k]}); sys.exit(1)

@@ -13,7 +13,6 @@ soil, ticks, nw, nd = CASES[case]
 cfg = load_cfg(soil); n = SIZE; nw = int(nw * (n / 256.0) ** 2); nd = int(nd * (n / 256.0) ** 2); ticks = int(TICKS) if TICKS else ticks
 o0 = Oracle(cfg, n, n, seed=0); o0.initialize(); s0 = o0.snapshot()
 L = lib()
-if os.environ.get('HS_GRID_INTERLEAVE'): L.hs_set_grid_interleave(int(os.environ['HS_GRID_INTERLEAVE']))   # smx_set_grid_interleave on the host
 def run(mode, sd):
     h = HostSim(cfg, n, n, seed=0); h.load(s0, advance_rand=False); L.hs_srand(h.h, sd)
     for t in range(ticks):

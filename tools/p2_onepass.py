@@ -1,7 +1,7 @@
 """One grid pass, two ways, from the SAME state: at every tick of an exact run on the host (tests/hostsim) the state before the grid pass is
 cloned; one clone gets the reference-order pass (water.h:335-343), the other the throughput pass (nine tile colours, nested particles as
 generations after the pass). Deterministic and free of the chaos that blurs multi-tick ensembles: what the pass itself does differently.
-  p2_onepass.py <size> <ticks> [seed]    env: CASE=<tools/p2_zscores.py case> HS_GRID_INTERLEAVE
+  p2_onepass.py <size> <ticks> [seed]    env: CASE=<tools/p2_zscores.py case>
 CHECKER ONLY."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,9 +15,10 @@ case = os.environ.get('CASE', 'rgps')
 n, ticks = int(sys.argv[1]), int(sys.argv[2]); sd = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 soil, _, nw, nd = CASES[case]
 cfg = load_cfg(soil); nw = int(nw * (n / 256.0) ** 2); nd = int(nd * (n / 256.0) ** 2)
+if os.environ.get('TERRAIN_OF'):
+    for l in cfg.layers: l.frequency *= n / float(os.environ['TERRAIN_OF'])
 o0 = Oracle(cfg, n, n, seed=0); o0.initialize(); s0 = o0.snapshot()
 L = lib()
-if os.environ.get("HS_GRID_INTERLEAVE"): L.hs_set_grid_interleave(int(os.environ["HS_GRID_INTERLEAVE"]))
 def figs(h):
     s = h.snapshot(); c = h.counters()
     end = np.cumsum(s.count.astype(np.int64)); top = end[s.count > 0] - 1

@@ -56,8 +56,7 @@ def zscores(eng, ref, ctl):
     return out
 
 
-def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="relaxed", device=0, verbose=True, nwater=None, nwind=None, water_batches=1,
-        grid_interleave=0):
+def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="relaxed", device=0, verbose=True, nwater=None, nwind=None, water_batches=1):
     """Returns the report dict, or {"skipped": reason}."""
     from soilmachine_amd import capi
     from soilmachine_amd.machine import SoilMachine
@@ -93,8 +92,6 @@ def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="
         tg = time.time()
         if water_batches > 1:                                     # the tick's water particles as k consecutive generations (smx_set_water_generations)
             sm.map.set_water_generations(water_batches)
-        if grid_interleave > 0:                                   # the grid pass's nested particles after every k colours (smx_set_grid_interleave)
-            sm.map.set_grid_interleave(grid_interleave)
         sm.tick(ticks, sync=True)
         t_gpu = time.time() - tg
         m = sm.map
@@ -148,10 +145,9 @@ def main():
     ap.add_argument("--soil", default="rockgravelpebblessand.soil")
     ap.add_argument("--out", default=None)
     ap.add_argument("--water-batches", type=int, default=int(os.environ.get("P2_WATER_BATCHES", "1")))
-    ap.add_argument("--grid-interleave", type=int, default=int(os.environ.get("P2_GRID_INTERLEAVE", "0")))
     a = ap.parse_args()
-    rep = run(a.soil, a.size, a.ticks, a.nctl, a.engine, water_batches=a.water_batches, grid_interleave=a.grid_interleave)
-    rep["water_batches"] = a.water_batches; rep["grid_interleave"] = a.grid_interleave
+    rep = run(a.soil, a.size, a.ticks, a.nctl, a.engine, water_batches=a.water_batches)
+    rep["water_batches"] = a.water_batches
     if "figures" in rep:
         for k in FIGS:
             f = rep["figures"][k]
