@@ -153,7 +153,7 @@ def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool
 
 
 def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None, rand_seed=None, keep_heights=False, save_after_warmup=None,
-            water_generations=1):
+            water_generations=None):
     """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers).
     rand_seed: re-seed the libc stream after the terrain is built (same map, another rand() stream: the parity control)."""
     from soilmachine_amd.machine import SoilMachine
@@ -161,7 +161,7 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
     m = sm.map
     if rand_seed is not None:
         m._chk(m.L.smx_srand(m.h, int(rand_seed)))
-    if water_generations > 1:
+    if water_generations is not None:
         m.set_water_generations(water_generations)
     sm.tick(warmup, sync=True)
     if save_after_warmup:                                       # the state the timed window starts from: what cpu_baseline continues (outside the timed region)
@@ -400,8 +400,9 @@ def main():
     ap.add_argument("--no-lines", action="store_true", help="only the headline measurement")
     ap.add_argument("--cpu-ticks", type=int, default=1)
     ap.add_argument("--strong", action="store_true", help="N > 1: keep the map at --size^2 and split it (default: the map grows with N)")
-    ap.add_argument("--water-generations", type=int, default=1, help="throughput engines: the tick's water particles as k consecutive generations (smx_set_water_generations; "
-                                                                     "a fidelity knob, profiles/r04_p2_analysis.md; the headline is quoted at 1)")
+    ap.add_argument("--water-generations", type=int, default=None, help="throughput engines: the tick's water particles as k consecutive generations (smx_set_water_generations; "
+                                                                        "default: the engine's own, 4 -- the configuration whose water-cycle figures are inside the reference's spread; "
+                                                                        "1 = round 4's schedule, faster and outside it, profiles/r05_p2_*.json)")
     args = ap.parse_args()
 
     import torch
@@ -453,7 +454,7 @@ def main():
         want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean"))
         ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"soilmx_bench_{os.getpid()}.smx") if want_cpu else None
         r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier, save_after_warmup=ckpt,
-                    water_generations=args.water_generations if throughput else 1)
+                    water_generations=args.water_generations if throughput else None)
         if ckpt and not os.path.exists(ckpt):
             ckpt = None
     steps = r["steps_w"] + r["steps_d"]
@@ -616,7 +617,7 @@ def main():
                     break
                 except (OSError, ValueError, KeyError):
                     pass
-        config = {"workload": workload, "engine": eng_name, "water_generations": args.water_generations if throughput else None,
+        config = {"workload": workload, "engine": eng_name, "water_generations": (args.water_generations or 4) if throughput else None,
                   "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
                   "parity": p2 if throughput else head["parity"]}
         detail = {

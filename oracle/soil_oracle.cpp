@@ -938,6 +938,7 @@ struct so_ctx {
   //            the waiting particles, every epoch is a flood epoch (the rule above counts one device's particles: not partition-invariant).
   // =====================================================================================================
   bool b_relaxed = false;
+  int b_water_generations = 4;                                // so_set_water_generations (smx_set_water_generations; the engine's default)
   struct RReq { int x, y; double vol, amount; uint32_t type; int kind; int cx, cy; };   // kind 1: erode, 2: deposit
   uint32_t r_surf(int x, int y) const { const uint32_t t = top[cidx(x, y)]; return t == NIL ? 0u : type[t]; }
   bool r_precheck(int x, int y) const {
@@ -1098,14 +1099,13 @@ struct so_ctx {
     B_TILE = B_GRID;                                          // (the access guard below speaks in grid tiles)
     uint64_t visited = 0;
     b_children.clear();
-    // DEPENDENCY PASSES over the tiles that have work (soilmx.hip grid_sweep): a tile is swept in pass p once every raster-earlier tile
-    // (tx-major) within two tiles of it that has work was swept in a pass < p -- tiles whose regions (tile + ring) overlap go in block-raster
-    // order, the direction of the reference's sweep; the tiles of one pass own disjoint regions (any order: ascending here). After every
-    // pass the nested particles it suspended at the edge of their tile's region run as a generation, BEFORE the raster-later tiles are swept
-    // (column strips: after the sweeps, with the strip driver).
-    for (int ph = 0; ph < (bs_n > 1 ? 2 : 1); ph++) {
-      const uint32_t PENDING = 0xFFFFFFFFu;
-      std::vector<uint32_t> tdone((size_t)ntx * nty, 0u), pend, next;
+    // Tiles in BLOCK-RASTER order (tx-major, then ty: the direction of the reference's sweep). The engine sweeps a tile once every
+    // raster-earlier tile that has work and whose REGION overlaps its own is done (dependency passes, soilmx.hip grid_sweep), and tiles with
+    // disjoint regions concurrently; a tile touches nothing outside its region (nested particles are suspended at its edge), so sweeps of
+    // disjoint regions commute and this sequential loop IS the result. Region = the tile and `ring` rings of tiles around it: 4 (36 x 36
+    // cells), 1 under column strips (the region of a seam tile has to stay inside the seam zone).
+    const int ring = bs_n > 1 ? 1 : 4;
+    for (int ph = 0; ph < (bs_n > 1 ? 2 : 1); ph++)
       for (int tx = 0; tx < ntx; tx++) {
         if (bs_n > 1) {                                       // INTERIOR sweep: tiles whose neighbourhood lies inside one strip; SEAM sweep: the rest
           const int cx0 = std::max(tx - 1, 0) << B_GRID, cx1 = std::min(((tx + 2) << B_GRID) - 1, dimx - 1);
@@ -1114,24 +1114,8 @@ struct so_ctx {
           if ((ph == 0) != interior) continue;
         }
         for (int ty = 0; ty < nty; ty++) {
-          bool any = false;
-          for (int x = tx << B_GRID; x < ((tx + 1) << B_GRID) && x < dimx; x++)
-            for (int y = ty << B_GRID; y < ((ty + 1) << B_GRID) && y < dimy; y++) any |= act[cidx(x, y)] != 0;
-          if (any) { tdone[(size_t)tx * nty + ty] = PENDING; pend.push_back((uint32_t)tx * (uint32_t)nty + (uint32_t)ty); }
-        }
-      }
-      for (uint32_t pass = 1; !pend.empty(); pass++) {
-        const std::vector<uint32_t> before = tdone;           // what a tile sees of the others: the state when the pass began
-        auto ok_ = [&](int ax, int ay) { return ax < 0 || ax >= ntx || ay < 0 || ay >= nty || before[(size_t)ax * nty + ay] < pass; };
-        next.clear();
-        for (uint32_t tile : pend) {
-          const int tx = (int)(tile / (uint32_t)nty), ty = (int)(tile % (uint32_t)nty);
-          bool ok = true;
-          for (int dy = 1; dy <= 2; dy++) ok &= ok_(tx, ty - dy);
-          for (int dx = 1; dx <= 2; dx++) for (int dy = -2; dy <= 2; dy++) ok &= ok_(tx - dx, ty + dy);
-          if (!ok) { next.push_back(tile); continue; }
-          b_defer = true; b_parent = (uint64_t)ph * ntx * nty + (uint64_t)tile; b_seq = 0;
-          const BRect g = {tx - 1 < 0 ? 0 : tx - 1, tx + 1 > ntx - 1 ? ntx - 1 : tx + 1, ty - 1 < 0 ? 0 : ty - 1, ty + 1 > nty - 1 ? nty - 1 : ty + 1};
+          b_defer = true; b_parent = (uint64_t)ph * ntx * nty + (uint64_t)tx * nty + ty; b_seq = 0;
+          const BRect g = {tx - ring < 0 ? 0 : tx - ring, tx + ring > ntx - 1 ? ntx - 1 : tx + ring, ty - ring < 0 ? 0 : ty - ring, ty + ring > nty - 1 ? nty - 1 : ty + ring};
           b_guard = &g; b_ctx = "grid";
           for (int x = tx << B_GRID; x < ((tx + 1) << B_GRID) && x < dimx; x++)
             for (int y = ty << B_GRID; y < ((ty + 1) << B_GRID) && y < dimy; y++) {
@@ -1141,18 +1125,8 @@ struct so_ctx {
               visited++;
             }
           b_guard = nullptr; b_defer = false;
-          tdone[(size_t)tx * nty + ty] = pass;
-        }
-        pend.swap(next);
-        if (bs_n <= 1 && !b_children.empty()) {
-          std::vector<BChild> part = b_children;
-          b_children.clear();
-          std::stable_sort(part.begin(), part.end(), [](const BChild& a, const BChild& b) { return a.key < b.key; });
-          b_generations(false, 0, part);
-          B_TILE = B_GRID;
         }
       }
-    }
     ctr.wcascade_calls += n - visited;                        // the reference "calls" cascade on every cell (water.h:340)
     ctr.grid_active_cells += visited;
     std::vector<BChild> kids = b_children;
@@ -1316,8 +1290,13 @@ void so_seep(so_ctx* c, int x, int y) { c->seep(x, y); }
 void so_batched_water(so_ctx* c, int n) { c->b_generations(false, (uint32_t)(n > 0 ? n : 0), {}); }
 void so_batched_wind(so_ctx* c, int n) { c->b_generations(true, (uint32_t)(n > 0 ? n : 0), {}); }
 void so_batched_grid(so_ctx* c) { c->batched_grid(); }
+void so_set_water_generations(so_ctx* c, int k) { c->b_water_generations = k < 1 ? 1 : k; }
 void so_batched_tick(so_ctx* c, int nwater, int nwind, int dowater, int dowind) {
-  if (dowater) { so_batched_water(c, nwater); so_batched_grid(c); }
+  if (dowater) {                                              // smx_tick_water: k consecutive top-level generations of n/k (soil_batch.h SMX_WATER_GENERATIONS)
+    uint32_t left = nwater > 0 ? (uint32_t)nwater : 0u;
+    for (uint32_t q = 0, k = (uint32_t)c->b_water_generations; q < k && left > 0; q++) { const uint32_t nq = left / (k - q); left -= nq; if (nq) so_batched_water(c, (int)nq); }
+    so_batched_grid(c);
+  }
   if (dowind) so_batched_wind(c, nwind);
   if (dowater) { c->map_frequency(); c->reset_frequency(); }
 }

@@ -34,9 +34,16 @@
 
 namespace smx {
 
+constexpr int GRID_RING = 4;                  // ... and a tile's REGION is the tile and GRID_RING rings of tiles around it (36 x 36 cells): where its nested particles may run.
+                                              // Measured (tools/p2_proxy.py, profiles/r05_p2_grid_pass.md): one ring (the seep / cascade reach) suspends so many that the
+                                              // pass leaves +26 % cells under water; four rings suspend 0.4 % of them. Under column strips: one ring (grid_ring).
 constexpr int GRID_SHIFT = 2;                 // the grid pass works on 4x4-cell tiles (one cascade reaches 4 cells)
 constexpr uint32_t B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3;   // B_NEW: top-level particle that has not acted yet
 constexpr uint32_t B_AWAY = 4;               // column strips on several devices: the particle currently lives on another device
+constexpr int SMX_WATER_GENERATIONS = 4;      // a tick's water particles run as this many consecutive top-level generations of n/k (smx_set_water_generations): the particles of
+                                              // one generation advance together and do not see the lakes their own generation makes -- in the reference particle i sees what
+                                              // every particle < i did (SoilMachine.cpp:287-298). One generation loses 20 % of the nested particles and doubles the standing
+                                              // water while lakes are seeded; four are inside the reference's own spread (profiles/r05_p2_*.json)
 constexpr int B_CHUNK = 32;                   // epochs between two looks at the number of running particles (schedule, compaction)
 constexpr int B_MAXCHILD = 250;               // nested particles one flood / one grid tile may emit per pass (the key keeps 8 bits for the sequence). Round 5: 24 -> 250:
                                               // a 4x4 tile of lake cells spawns more than 24 (every sweep position can send off its own film and those of its eight
@@ -107,6 +114,8 @@ struct BatchShared {
 };
 struct RReq { double amount, vol; uint32_t cell, type, kind, casc; };   // kind: R_* bits; casc: cell whose cascade this step asks for (NIL: none)
 
+// rings of tiles in a grid tile's region: under column strips the region of a seam tile has to stay inside the seam zone the halo exchange covers
+SMX_D int grid_ring(const BatchShared& bs) { return bs.strips.n > 1 ? 1 : GRID_RING; }
 SMX_D unsigned long long btag(uint32_t epoch, uint32_t slot) { return ((unsigned long long)(epoch + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - slot); }
 SMX_D bool brect_empty(const BRect& r) { return r.tx1 < r.tx0; }
 SMX_D bool brect_contains(const BRect& a, const BRect& b) {   // b inside a
@@ -568,6 +577,7 @@ SMX_D void batch_wind_epoch(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
 //          lone particle up to 32 steps per kernel launch.
 // `fine_above`: water reserves single cells while more particles than this are running (default: never; the tests lower it).
 struct BSched { int tshift, dilate, maxsteps; };
+
 #ifdef SMX_HOSTSIM
 #define SMX_HD inline
 #else
@@ -611,7 +621,8 @@ SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned l
   sim.pol.parent = key; sim.pol.nchild = 0;
   {                                                          // the tile and the ring of tiles around it are this thread's own (its seep + cascade reach them)
     const int gtx = (s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
-    sim.pol.region = BRect{tx - 1 < 0 ? 0 : tx - 1, tx + 1 > gtx - 1 ? gtx - 1 : tx + 1, ty - 1 < 0 ? 0 : ty - 1, ty + 1 > gty - 1 ? gty - 1 : ty + 1};
+    const int R = grid_ring(sim.pol.bs);
+    sim.pol.region = BRect{tx - R < 0 ? 0 : tx - R, tx + R > gtx - 1 ? gtx - 1 : tx + R, ty - R < 0 ? 0 : ty - R, ty + R > gty - 1 ? gty - 1 : ty + R};
   }
   Water dummy;
   dummy.pos = {0.f, 0.f}; dummy.speed = {0.f, 0.f}; dummy.volume = 0.0; dummy.sediment = 0.0; dummy.evaprate = 0.0;
@@ -647,7 +658,7 @@ SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned l
 SMX_D bool batch_grid_tile_phase(const DevState& s, const BatchShared& bs, int tx) {
   const BStrips& st = bs.strips;
   if (st.n <= 1) return bs.sphase == STRIP_INTERIOR;
-  const int cx0 = (tx - 1 < 0 ? 0 : tx - 1) << GRID_SHIFT;
+  const int cx0 = (tx - 1 < 0 ? 0 : tx - 1) << GRID_SHIFT;   // (the columns of the tile's region: one ring under strips, grid_ring)
   int cx1 = ((tx + 2) << GRID_SHIFT) - 1; if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
   bool interior = false;
   for (int g = 0; g < st.n; g++) {

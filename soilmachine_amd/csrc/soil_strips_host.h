@@ -394,7 +394,13 @@ int smx_strips_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater
   StripState& S = *ctx->strip;
   if (dowater) {
     roctx_range rw("soilmx:strips:water");
-    if (st_phase(ctx, S, false, nwater > 0 ? (uint32_t)nwater : 0u, {}, false)) return -1;
+    uint32_t left = nwater > 0 ? (uint32_t)nwater : 0u;       // as smx_tick_water: k consecutive top-level generations of n/k
+    const uint32_t k = ctx->water_generations < 1 ? 1u : (uint32_t)ctx->water_generations;
+    for (uint32_t q = 0; q < k && left > 0; q++) {
+      const uint32_t nq = left / (k - q);
+      left -= nq;
+      if (nq && st_phase(ctx, S, false, nq, {}, false)) return -1;
+    }
     roctx_range rg("soilmx:strips:grid");
     if (st_grid(ctx, S)) return -1;
   }

@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256) k_batch_counters(DevState s, BatchShared 
 // ---------------- grid pass (water.h:335-343) in dependency passes over the 4x4-cell tiles ----------------
 // A tile's seep + cascade(.., 3) -- and the nested particles that run inside it -- reach the ring of tiles around it (its REGION).
 // Tiles whose regions overlap are processed in block-raster order (tx-major, then ty: the direction of the reference's sweep); tiles
-// whose regions are disjoint in the same pass. A tile is eligible in pass p once every raster-earlier tile within two tiles of it
+// whose regions are disjoint in the same pass. A tile is eligible in pass p once every raster-earlier tile within 2 * grid_ring tiles of it
 // that has work is done in a pass < p; the raster-first pending tile always is, so every pass makes progress. Results do not depend
 // on how the hardware orders the tiles of a pass (disjoint regions), nor on the number of passes a lake takes.
 constexpr uint32_t GT_PENDING = 0xFFFFFFFFu;
@@ -562,8 +562,9 @@ __global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared
   if (act) g.pend[0][k] = tile;
 }
 __global__ void __launch_bounds__(64) k_grid_tiles_pass(DevState s, BatchShared bs, GridTiles g, uint32_t pass, uint32_t in, uint32_t lpw) {
-  SMX_LOAD_SOILS(sh)
   const uint32_t n = g.count[in];
+  if (blockIdx.x * lpw >= n) return;                         // (launches are sized for the first pass of their group: most blocks of the later ones leave here)
+  SMX_LOAD_SOILS(sh)
   const uint32_t i = blockIdx.x * lpw + threadIdx.x;
   const bool mine = threadIdx.x < lpw && i < n;
   unsigned long long vis = 0;
@@ -572,9 +573,10 @@ __global__ void __launch_bounds__(64) k_grid_tiles_pass(DevState s, BatchShared 
     tile = g.pend[in][i];
     const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
     bool ok = true;                                          // the raster-earlier tiles whose region overlaps this one's
-    for (int dy = 1; dy <= 2; dy++) ok &= grid_tile_done_before(g, tx, ty - dy, pass);
-    for (int dx = 1; dx <= 2; dx++)
-      for (int dy = -2; dy <= 2; dy++) ok &= grid_tile_done_before(g, tx - dx, ty + dy, pass);
+    const int W = 2 * grid_ring(bs);
+    for (int dy = 1; dy <= W && ok; dy++) ok = grid_tile_done_before(g, tx, ty - dy, pass);
+    for (int dx = 1; dx <= W && ok; dx++)
+      for (int dy = -W; dy <= W && ok; dy++) ok = grid_tile_done_before(g, tx - dx, ty + dy, pass);
     if (ok) {
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
@@ -927,7 +929,7 @@ struct smx_ctx {
   std::vector<hipEvent_t> evpool;
   smx_timing timing{};
   uint32_t spec_sub = 0, spec_maxnest = 0; bool spec_realloc = false;   // smx_set_spec_limits (0 = defaults)
-  int water_generations = 1;                                 // smx_set_water_generations
+  int water_generations = SMX_WATER_GENERATIONS;             // smx_set_water_generations (throughput engines: 4)
   uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0, spec_subphases_cut = 0, spec_serial_particles = 0;
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
@@ -1964,7 +1966,7 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
   if (!ctx->d_tdone) {
     const size_t nt = (size_t)(txe - txb) * gty;
     HIPCHK(hipMalloc(&ctx->d_tdone, nt * 4)); HIPCHK(hipMalloc(&ctx->d_tpend[0], nt * 4)); HIPCHK(hipMalloc(&ctx->d_tpend[1], nt * 4));
-    HIPCHK(hipMalloc(&ctx->d_tcount, 8)); HIPCHK(hipHostMalloc(&ctx->h_tcount, 16));
+    HIPCHK(hipMalloc(&ctx->d_tcount, 8)); HIPCHK(hipHostMalloc(&ctx->h_tcount, 8));
   }
   ctx->bs.tshift = GRID_SHIFT; ctx->bs.sphase = phase;
   const BatchShared& bs = ctx->bs;
@@ -1978,37 +1980,32 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
   HIPCHK(hipMemcpyAsync(ctx->h_tcount, ctx->d_tcount, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   uint32_t n = ctx->h_tcount[0], in = 0, pass = 1;
+  static const bool trace = [] { const char* e = getenv("SMX_TRACE_BATCH"); return e && atoi(e) != 0; }();
+  const auto t_sweep = std::chrono::steady_clock::now();
+  const uint32_t n_first = n;
+  // passes are launched in groups of GRID_PASS_GROUP between two looks at what is left (the pending list only shrinks, so the group's
+  // launches are sized by its first pass; a pass over an empty list costs a few microseconds): a lake of W x H tiles takes
+  // H + (2 * grid_ring + 1) * W passes, hundreds once lakes span tens of tiles, and a host round trip per pass would double their cost
+  static const uint32_t group = [] { const char* e = getenv("SMX_GRID_PASS_GROUP"); const int v = e ? atoi(e) : 8; return (uint32_t)(v < 1 ? 1 : v); }();
   while (n > 0) {
-    HIPCHK(hipMemsetAsync(ctx->d_tcount + (in ^ 1u), 0, 4, st));
     const uint32_t lpw = batch_lanes_per_wave(n);
-    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_pass, dim3((n + lpw - 1u) / lpw), dim3(64), 0, st, ctx->d, bs, g, pass, in, lpw); }
-    hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
-    HIPCHK(hipMemcpyAsync(ctx->h_tcount, ctx->d_tcount, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_tcount + 2, bs.ctrl + BC_NCHILD, 4, hipMemcpyDeviceToHost, st));   // suspended nested particles so far
-    HIPCHK(hipStreamSynchronize(st));
-    const uint32_t left = ctx->h_tcount[in ^ 1u];
-    if (left >= n) { ctx->err = "grid pass: no tile became eligible (internal error)"; return -7; }
-    n = left; in ^= 1u; pass++;
-    ctx->grid_passes++;
-    // The nested particles this pass suspended at the edge of their tile's region run NOW, as a generation -- before the raster-later
-    // tiles are swept, as the reference's nested particles run before the sweep moves on (water.h:246-264 inside :335-343): deferred to
-    // the end of the sweep they would find the ground dried and leave +26 % cells under water (profiles/r05_p2_grid_pass.md).
-    // (Column strips: the strip driver collects them after its sweeps.)
-    if (bs.strips.n <= 1) {
-      uint32_t nq = ctx->h_tcount[2];
-      if (nq) {
-        HIPCHK(hipMemcpyAsync(ctx->h_bctrl, bs.ctrl, BC_COUNT * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
-        if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
-        if (nq > bs.child_cap) nq = bs.child_cap;
-        if (sort_children(ctx, nq)) return -1;
-        HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
-        const int rc = batch_generations(ctx, false, 0, nq); if (rc) return rc;
-        ctx->bs.tshift = GRID_SHIFT; ctx->bs.sphase = phase;   // (the generations ran their own schedule)
+    const uint32_t in0 = in;
+    { PhaseTimer tk(ctx, 7, group);
+      for (uint32_t q = 0; q < group; q++, in ^= 1u, pass++) {
+        HIPCHK(hipMemsetAsync(ctx->d_tcount + (in ^ 1u), 0, 4, st));
+        hipLaunchKernelGGL(k_grid_tiles_pass, dim3((n + lpw - 1u) / lpw), dim3(64), 0, st, ctx->d, bs, g, pass, in, lpw);
       }
     }
+    hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
+    HIPCHK(hipMemcpyAsync(ctx->h_tcount, ctx->d_tcount, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t left = ctx->h_tcount[in];                 // (`in` now names the list the last pass of the group wrote)
+    if (left >= n) { ctx->err = "grid pass: no tile became eligible (internal error)"; return -7; }
+    n = left;
+    ctx->grid_passes += group;
+    (void)in0;
   }
+  if (trace) fprintf(stderr, "[soilmx] grid sweep (kind %d): %u tiles with work, %u passes  %.3f ms\n", phase, n_first, pass - 1u, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sweep).count());
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -680,8 +680,9 @@ static unsigned long long grid_sweep(hs_ctx* c, BatchBuffers& b, int phase, int 
       const int tx = (int)(tile / (uint32_t)gty), ty = (int)(tile % (uint32_t)gty);
       auto ok_ = [&](int ax, int ay) { return ax < tx_lo || ax >= tx_hi || ay < 0 || ay >= gty || before[(size_t)ax * gty + ay] < pass; };
       bool ok = true;
-      for (int dy = 1; dy <= 2; dy++) ok &= ok_(tx, ty - dy);
-      for (int dx = 1; dx <= 2; dx++) for (int dy = -2; dy <= 2; dy++) ok &= ok_(tx - dx, ty + dy);
+      const int W = 2 * grid_ring(bs);                        // the raster-earlier tiles whose region overlaps this one's
+      for (int dy = 1; dy <= W; dy++) ok &= ok_(tx, ty - dy);
+      for (int dx = 1; dx <= W; dx++) for (int dy = -W; dy <= W; dy++) ok &= ok_(tx - dx, ty + dy);
       if (!ok) { later[i] = 1; return; }
       BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
       Frame st[MAX_FRAMES];
@@ -693,17 +694,9 @@ static unsigned long long grid_sweep(hs_ctx* c, BatchBuffers& b, int phase, int 
     next.clear();
     for (size_t i = 0; i < pend.size(); i++) { visited += vis[i]; if (later[i]) next.push_back(pend[i]); }
     if (next.size() >= pend.size()) { fprintf(stderr, "[hostsim] grid pass: no tile became eligible\n"); abort(); }
+    if (getenv("HS_GRID_TRACE")) fprintf(stderr, "[hostsim] grid pass %u: %zu tiles in, %zu left, %u suspended\n", pass, pend.size(), next.size(), b.ctrl[BC_NCHILD]);
     pend.swap(next);
     batch_merge_freed(c, b);
-    // the nested particles this pass suspended at the edge of their tile's region run NOW -- before the raster-later tiles -- as a generation
-    if (b.ctrl[BC_NCHILD] && b.bs.strips.n <= 1) {
-      uint32_t nc = b.ctrl[BC_NCHILD]; if (nc > b.bs.child_cap) nc = b.bs.child_cap;
-      std::vector<BChild> kq(b.children.begin(), b.children.begin() + nc);
-      std::sort(kq.begin(), kq.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
-      b.ctrl[BC_NCHILD] = 0;
-      { BatchBuffers b2; batch_generations(c, b2, false, 0, kq, nthreads, shuffle); }
-      b.bs.tshift = GRID_SHIFT;
-    }
   }
   return visited;
 }
@@ -731,8 +724,14 @@ void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
   std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
   if (!kids.empty()) { BatchBuffers b2; batch_generations(c, b2, false, 0, kids, nthreads, shuffle); }   // the nested particles that left their tile's region
 }
+static int g_water_generations = SMX_WATER_GENERATIONS;      // smx_set_water_generations
+void hs_set_water_generations(int k) { g_water_generations = k < 1 ? 1 : k; }
 void hs_batched_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int nthreads, unsigned shuffle) {
-  if (dowater) { hs_batched_water(c, nwater, nthreads, shuffle); hs_batched_grid(c, nthreads, shuffle); }
+  if (dowater) {                                              // smx_tick_water: k consecutive top-level generations of n/k
+    uint32_t left = nwater > 0 ? (uint32_t)nwater : 0u;
+    for (uint32_t q = 0, k = (uint32_t)g_water_generations; q < k && left > 0; q++) { const uint32_t nq = left / (k - q); left -= nq; if (nq) hs_batched_water(c, (int)nq, nthreads, shuffle); }
+    hs_batched_grid(c, nthreads, shuffle);
+  }
   if (dowind) hs_batched_wind(c, nwind, nthreads, shuffle);
   if (dowater) hs_freq(c);
 }

@@ -87,6 +87,7 @@ class StripRank:
         backend.set_strips(geom.n, geom.a, geom.b)
         backend.set_own(self.x0, self.x1)
         self.stats = {"chunks": 0, "seam_chunks": 0, "generations": 0}
+        self.water_generations = 4                                # smx_set_water_generations' default (csrc/soil_batch.h SMX_WATER_GENERATIONS)
 
     # -- halo traffic (nearest neighbours only). A rank holds, besides its strip, the b columns right of its right boundary.
     # one message per direction: [u64 length of the column part][columns][particles]
@@ -180,8 +181,12 @@ class StripRank:
             self.sync_halos()
 
     def tick(self, nwater: int, nwind: int, dowater: bool = True, dowind: bool = True):
-        if dowater:
-            self._phase(False, nwater)
+        if dowater:                                               # smx_strips_tick: k consecutive top-level generations of n/k (csrc/soil_batch.h SMX_WATER_GENERATIONS)
+            left, k = nwater, self.water_generations
+            for q in range(k):
+                nq = left // (k - q); left -= nq
+                if nq:
+                    self._phase(False, nq)
             self._grid()
         if dowind:
             self._phase(True, nwind)

@@ -141,7 +141,7 @@ def test_water_generations_equal_k_phase_calls():
     n, nw, nd, k = 192, 900, 200, 4
     a = machine(cfg, n, n, nw, nd, True, capi.ENGINE_RELAXED)
     b = machine(cfg, n, n, nw, nd, True, capi.ENGINE_RELAXED)
-    a.map.set_water_generations(k)
+    a.map.set_water_generations(k); b.map.set_water_generations(1)   # (b's phase calls are single generations)
     for t in range(6):
         a.tick(1, sync=True)
         left = nw

@@ -36,7 +36,7 @@ for s in "$@"; do
     headrelax8) run headrelax8 30 300 env SMX_RELAX_WIND_STEPS=8 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     headrelaxw0) run headrelaxw0 30 300 env SMX_RELAX_WIND_MIN=4000000000 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     drv)       run drv 60 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-lines --no-cpu-baseline; cp $out/drv.log $out/drv.json 2>/dev/null ;;
-    drvk4)     run drvk4 60 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-lines --no-cpu-baseline --water-generations ${WGEN:-4}; cp $out/drvk4.log $out/drvk4.json 2>/dev/null ;;
+    drvk4)     run drvk4 60 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-lines --no-cpu-baseline --water-generations ${WGEN:-1}; cp $out/drvk4.log $out/drvk4.json 2>/dev/null ;;
     gaps)      run gaps 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/gaps -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 2 --warmup ${GWARM:-6}
                python tools/kernel_stats.py $out/gaps | tee $out/gaps.kernels
                python tools/trace_gaps.py $out/gaps --last-ticks ${LASTTICKS:-1} | tee $out/gaps.summary
@@ -77,7 +77,7 @@ for s in "$@"; do
     exactk)    run exactk 60 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/exactk -o t -- python bench.py --only exact_area_scaled
                python tools/kernel_stats.py $out/exactk | tee $out/exactk.kernels; python tools/trace_gaps.py $out/exactk | tee $out/exactk.summary; rm -rf $out/exactk ;;
     exactmode2) run exactmode2 60 600 env SMX_SPEC_MODE=2 python bench.py --only exact_area_scaled ;;
-    p2ref)     run p2ref 60 ${PTO:-900} python tools/p2_reference.py --size ${PSIZE:-4096} --ticks ${PTICKS:-10} --nctl ${PNCTL:-8} --engine ${PENGINE:-relaxed} --water-batches ${PWB:-1} --out $out/p2ref_${PSIZE:-4096}.json; tail -12 $out/p2ref.err ;;
+    p2ref)     run p2ref 60 ${PTO:-900} python tools/p2_reference.py --size ${PSIZE:-4096} --ticks ${PTICKS:-10} --nctl ${PNCTL:-8} --engine ${PENGINE:-relaxed} --water-batches ${PWB:-0} --out $out/p2ref_${PSIZE:-4096}.json; tail -12 $out/p2ref.err ;;
     p2var)     i=0; for kv in ${PV_LIST}; do i=$((i+1)); run p2var_$i 60 ${PTO:-600} env ${kv} python tools/p2_reference.py --size ${PSIZE:-2048} --ticks ${PTICKS:-10} --nctl ${PNCTL:-16} --engine relaxed --out $out/p2var_$i.json; tail -9 $out/p2var_$i.err; done ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
     envelope)  run envelope 60 900 python tools/p2_envelope.py --size ${ESIZE:-1024} --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts ${ECOUNTS:-area} ;;

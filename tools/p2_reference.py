@@ -56,7 +56,7 @@ def zscores(eng, ref, ctl):
     return out
 
 
-def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="relaxed", device=0, verbose=True, nwater=None, nwind=None, water_batches=1):
+def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="relaxed", device=0, verbose=True, nwater=None, nwind=None, water_batches=None):
     """Returns the report dict, or {"skipped": reason}."""
     from soilmachine_amd import capi
     from soilmachine_amd.machine import SoilMachine
@@ -90,7 +90,7 @@ def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="
         ENG = {"relaxed": capi.ENGINE_RELAXED, "batched": capi.ENGINE_BATCHED, "spec": capi.ENGINE_SPECULATIVE}
         sm = SoilMachine(cfg, size, seed=0, nwater=nwater, nwind=nwind, dowind=nwind > 0, pool=pool, device=device, engine=ENG[engine])
         tg = time.time()
-        if water_batches > 1:                                     # the tick's water particles as k consecutive generations (smx_set_water_generations)
+        if water_batches:                                         # the tick's water particles as k consecutive generations (smx_set_water_generations; default: the engine's own 4)
             sm.map.set_water_generations(water_batches)
         sm.tick(ticks, sync=True)
         t_gpu = time.time() - tg
@@ -144,10 +144,10 @@ def main():
     ap.add_argument("--engine", default="relaxed")
     ap.add_argument("--soil", default="rockgravelpebblessand.soil")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--water-batches", type=int, default=int(os.environ.get("P2_WATER_BATCHES", "1")))
+    ap.add_argument("--water-batches", type=int, default=int(os.environ.get("P2_WATER_BATCHES", "0")), help="0 = the engine's default (4)")
     a = ap.parse_args()
     rep = run(a.soil, a.size, a.ticks, a.nctl, a.engine, water_batches=a.water_batches)
-    rep["water_batches"] = a.water_batches
+    rep["water_generations"] = a.water_batches or 4
     if "figures" in rep:
         for k in FIGS:
             f = rep["figures"][k]
