@@ -561,34 +561,42 @@ __global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared
   const uint32_t k = relax_append(&g.count[0], act);
   if (act) g.pend[0][k] = tile;
 }
-__global__ void __launch_bounds__(64) k_grid_tiles_pass(DevState s, BatchShared bs, GridTiles g, uint32_t pass, uint32_t in, uint32_t lpw) {
-  const uint32_t n = g.count[in];
-  if (blockIdx.x * lpw >= n) return;                         // (launches are sized for the first pass of their group: most blocks of the later ones leave here)
+// DATAFLOW over the tiles that have work, in raster order: a wavefront takes the next tile of the (sorted) list, waits until every
+// raster-earlier tile whose region overlaps this one's is done, sweeps it (lane 0) and publishes it. A tile only ever waits for tiles that
+// were taken before it, by wavefronts that are running: no deadlock, and the sweep lasts as long as its longest chain of dependent tiles
+// (a lake of W x H tiles: H + (2 ring + 1) W tiles in a row) -- not the sum, over global passes, of each pass's slowest tile (round 5's
+// first version: 384 passes x 4 ms at the headline). ONE tile per wavefront: lanes of one wavefront cannot wait for each other.
+// The order of conflicting tiles is fixed by the dependencies, so the result is the block-raster sweep's, whatever the timing.
+__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n) {
   SMX_LOAD_SOILS(sh)
-  const uint32_t i = blockIdx.x * lpw + threadIdx.x;
-  const bool mine = threadIdx.x < lpw && i < n;
+  __shared__ uint32_t s_i;
   unsigned long long vis = 0;
-  bool later = false; uint32_t tile = 0;
-  if (mine) {
-    tile = g.pend[in][i];
-    const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
-    bool ok = true;                                          // the raster-earlier tiles whose region overlaps this one's
-    const int W = 2 * grid_ring(bs);
-    for (int dy = 1; dy <= W && ok; dy++) ok = grid_tile_done_before(g, tx, ty - dy, pass);
-    for (int dx = 1; dx <= W && ok; dx++)
-      for (int dy = -W; dy <= W && ok; dy++) ok = grid_tile_done_before(g, tx - dx, ty + dy, pass);
-    if (ok) {
+  const int W = 2 * grid_ring(bs);
+  while (true) {
+    if (threadIdx.x == 0) s_i = atomicAdd(&g.count[1], 1u);
+    __syncthreads();
+    const uint32_t i = s_i;
+    __syncthreads();
+    if (i >= n) break;
+    if (threadIdx.x == 0) {
+      const uint32_t tile = order[i];
+      const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
+      for (int dx = 0; dx <= W; dx++)                          // the raster-earlier tiles whose region overlaps this one's
+        for (int dy = (dx ? -W : 1); dy <= W; dy++) {
+          const int ax = tx - dx, ay = dx ? ty + dy : ty - dy;
+          if (ax < g.tx_lo || ax >= g.tx_hi || ax < g.txb || ax >= g.txe || ay < 0 || ay >= g.gty) continue;
+          const uint32_t* f = &g.tdone[(size_t)(ax - g.txb) * g.gty + ay];
+          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GT_PENDING) __builtin_amdgcn_s_sleep(8);
+        }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // what the tiles before wrote to the map is visible from here on
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
       Frame st[MAX_FRAMES];
-      vis = batch_grid_tile(sim, tx, ty, g.keybase + (unsigned long long)tile, st);
+      vis += batch_grid_tile(sim, tx, ty, g.keybase + (unsigned long long)tile, st);
       sim.flush_counters(); pol.finish(s);
-      g.tdone[(size_t)(tx - g.txb) * g.gty + ty] = pass;
-    } else later = true;
+      __hip_atomic_store(&g.tdone[(size_t)(tx - g.txb) * g.gty + ty], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
-  const uint32_t k = relax_append(&g.count[in ^ 1u], later);
-  if (later) g.pend[in ^ 1u][k] = tile;
-  for (int off = 32; off > 0; off >>= 1) vis += (unsigned long long)__shfl_down((long long)vis, off);
   if (threadIdx.x == 0 && vis) atomicAdd(&s.ctr[C_GRID_ACTIVE], vis);
 }
 __global__ void k_batch_grid_finish(DevState s, unsigned long long visited0) {   // counter parity: every other cell "calls" cascade once
@@ -958,7 +966,7 @@ struct smx_ctx {
   unsigned long long xdata_cap = 0; uint32_t xoffs_cap = 0;
   uint8_t* d_rdata = nullptr; uint32_t* d_roffs = nullptr; uint8_t* d_xpart = nullptr; uint8_t* d_rpart = nullptr; unsigned long long xpart_cap = 0;   // strips in the library
   struct StripState* strip = nullptr;
-  uint32_t* d_tdone = nullptr; uint32_t* d_tpend[2] = {nullptr, nullptr}; uint32_t* d_tcount = nullptr; uint32_t* h_tcount = nullptr;   // grid pass: tile states, pending lists
+  uint32_t* d_tdone = nullptr; uint32_t* d_tpend[2] = {nullptr, nullptr}; uint32_t* d_tcount = nullptr; uint32_t* h_tcount = nullptr; void* d_tsort = nullptr; size_t tsort_bytes = 0; uint32_t tsort_cap = 0;   // grid pass: tile states, pending lists
   uint64_t batch_epochs = 0, batch_generations = 0, batch_children_lost = 0, grid_passes = 0;
 };
 
@@ -1102,7 +1110,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_tsort); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1954,8 +1962,8 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, uint32_t nkids
   HIPCHK(hipGetLastError());
   return 0;
 }
-// One sweep of the grid pass over the tile columns [tx_lo, tx_hi) in dependency passes (k_grid_tiles_pass); bs.sphase says which kind of
-// tile the sweep takes under column strips. One host look per pass (how many tiles are left): a lake of W x H tiles takes H + 3 W passes.
+// One sweep of the grid pass over the tile columns [tx_lo, tx_hi): the tiles with work, in raster order, through the dataflow kernel
+// (k_grid_tiles_flow); bs.sphase says which kind of tile the sweep takes under column strips.
 static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
   hipStream_t st = ctx->stream;
   const int gtx = (ctx->cfg.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (ctx->cfg.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
@@ -1979,33 +1987,28 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
   hipLaunchKernelGGL(k_grid_tiles_init, dim3((ntl + 255u) / 256u), dim3(256), 0, st, ctx->d, bs, g);
   HIPCHK(hipMemcpyAsync(ctx->h_tcount, ctx->d_tcount, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  uint32_t n = ctx->h_tcount[0], in = 0, pass = 1;
+  const uint32_t n = ctx->h_tcount[0];
   static const bool trace = [] { const char* e = getenv("SMX_TRACE_BATCH"); return e && atoi(e) != 0; }();
   const auto t_sweep = std::chrono::steady_clock::now();
-  const uint32_t n_first = n;
-  // passes are launched in groups of GRID_PASS_GROUP between two looks at what is left (the pending list only shrinks, so the group's
-  // launches are sized by its first pass; a pass over an empty list costs a few microseconds): a lake of W x H tiles takes
-  // H + (2 * grid_ring + 1) * W passes, hundreds once lakes span tens of tiles, and a host round trip per pass would double their cost
-  static const uint32_t group = [] { const char* e = getenv("SMX_GRID_PASS_GROUP"); const int v = e ? atoi(e) : 8; return (uint32_t)(v < 1 ? 1 : v); }();
-  while (n > 0) {
-    const uint32_t lpw = batch_lanes_per_wave(n);
-    const uint32_t in0 = in;
-    { PhaseTimer tk(ctx, 7, group);
-      for (uint32_t q = 0; q < group; q++, in ^= 1u, pass++) {
-        HIPCHK(hipMemsetAsync(ctx->d_tcount + (in ^ 1u), 0, 4, st));
-        hipLaunchKernelGGL(k_grid_tiles_pass, dim3((n + lpw - 1u) / lpw), dim3(64), 0, st, ctx->d, bs, g, pass, in, lpw);
-      }
+  if (n > 0) {
+    // the tiles with work in raster order (the init kernel appended them as its wavefronts came); tile indices are unique
+    if (ctx->tsort_cap < n) {
+      hipFree(ctx->d_tsort); ctx->d_tsort = nullptr; ctx->tsort_cap = 0; ctx->tsort_bytes = 0;
+      const uint32_t cap = (uint32_t)((size_t)(txe - txb) * gty);
+      size_t tb = 0;
+      HIPCHK(rocprim::radix_sort_keys(nullptr, tb, ctx->d_tpend[0], ctx->d_tpend[1], (size_t)cap, 0u, 32u, st));
+      HIPCHK(hipMalloc(&ctx->d_tsort, tb)); ctx->tsort_bytes = tb; ctx->tsort_cap = cap;
     }
+    size_t tb = ctx->tsort_bytes;
+    HIPCHK(rocprim::radix_sort_keys(ctx->d_tsort, tb, ctx->d_tpend[0], ctx->d_tpend[1], (size_t)n, 0u, 32u, st));
+    HIPCHK(hipMemsetAsync(ctx->d_tcount + 1, 0, 4, st));     // the cursor of the dataflow kernel
+    static const unsigned flow_waves = [] { const char* e = getenv("SMX_GRID_FLOW_WAVES"); const int v = e ? atoi(e) : 2048; return (unsigned)(v < 1 ? 1 : v); }();
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n); }
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
-    HIPCHK(hipMemcpyAsync(ctx->h_tcount, ctx->d_tcount, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const uint32_t left = ctx->h_tcount[in];                 // (`in` now names the list the last pass of the group wrote)
-    if (left >= n) { ctx->err = "grid pass: no tile became eligible (internal error)"; return -7; }
-    n = left;
-    ctx->grid_passes += group;
-    (void)in0;
+    ctx->grid_passes++;
   }
-  if (trace) fprintf(stderr, "[soilmx] grid sweep (kind %d): %u tiles with work, %u passes  %.3f ms\n", phase, n_first, pass - 1u, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sweep).count());
+  if (trace) fprintf(stderr, "[soilmx] grid sweep (kind %d): %u tiles with work  %.3f ms\n", phase, n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sweep).count());
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -93,7 +93,7 @@ def test_relaxed_z_scores_against_the_reference_streams(soil, size, ticks, nwate
     """The parity gate of the benchmarked engine: the relaxed schedule on the device against THE REFERENCE
     (oracle/_ref/soil_ref_lean, SEED 0) next to EIGHT reference runs of the same terrain under other rand() streams, every figure as a
     z-score against that control distribution (tools/p2_reference.py; the 4096^2 record of the same protocol at the headline's counts:
-    profiles/r04_p2_reference_4096.json). No hand-set floors: |z| < 2 on top-level water steps, wind steps, nested particles, section
+    profiles/r05_p2_reference_4096.json). No hand-set floors: |z| < 2 on top-level water steps, wind steps, nested particles, section
     count, cells under water, water volume and sum of heights; height RMSE one-sided."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -102,7 +102,8 @@ def test_relaxed_z_scores_against_the_reference_streams(soil, size, ticks, nwate
     if "skipped" in rep:
         pytest.skip(rep["skipped"])
     assert rep["controls"] >= 8
-    zs = {k: round(f["z"], 2) for k, f in rep["figures"].items()}
+    zs = " ".join(f"{k}={f['z']:+.2f}" for k, f in rep["figures"].items())
+    print("[z-scores]", soil, size, zs)
     assert not rep["outliers"], zs
 
 
