@@ -240,7 +240,7 @@ int smx_d_unpack_columns(smx_ctx* ctx, const void* buf, uint64_t bytes);
 int smx_d_pack_particles(smx_ctx* ctx, int32_t x0, int32_t x1, void* buf, uint64_t cap, uint64_t* bytes);
 int smx_d_unpack_particles(smx_ctx* ctx, const void* buf, uint64_t bytes);
 int smx_d_grid_begin(smx_ctx* ctx);                                            /* classification of the grid pass       */
-int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t tx_lo, int32_t tx_hi); /* nine colours over this rank's 4x4 tiles */
+int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t x_lo, int32_t x_hi);   /* the grid tiles of the COLUMNS [x_lo, x_hi) that belong to `phase`, colour by colour */
 /* ---- column strips driven INSIDE the library (csrc/soil_strips_host.h): the tick of SoilMachine.cpp:283-329 on this rank's strip of ONE
  * map; halo columns and migrating particles go from the pack kernel to the unpack kernel of the neighbour without leaving device memory.
  *   smx_strips_attach_rccl   transport = RCCL (ncclSend / ncclRecv / ncclAllReduce / ncclAllGather over xGMI) on this context's stream;

@@ -670,7 +670,7 @@ struct so_ctx {
   // Acting order inside an epoch is irrelevant by construction (winners own disjoint tiles); this
   // restatement walks slots in ascending order.
   // =====================================================================================================
-  static constexpr int B_GRID = 2, B_MAXCHILD = 250, B_CHUNK = 32;   // grid pass: 4x4-cell tiles
+  static constexpr int B_GRID = 3, B_MAXCHILD = 250, B_CHUNK = 32;   // grid pass: 8x8-cell tiles
   int B_TILE = 2;                                   // claim granularity of the running chunk (b_schedule): tiles of 2^B_TILE cells
   struct BRect { int tx0, tx1, ty0, ty1; bool empty() const { return tx1 < tx0; } };
   struct BChild { uint64_t key; f2 pos, speed; double volume, sediment; int spill; uint32_t contains; bool ended; };   // a suspended nested particle (soil_batch.h BChild)
@@ -1099,23 +1099,22 @@ struct so_ctx {
     B_TILE = B_GRID;                                          // (the access guard below speaks in grid tiles)
     uint64_t visited = 0;
     b_children.clear();
-    // Tiles in BLOCK-RASTER order (tx-major, then ty: the direction of the reference's sweep). The engine sweeps a tile once every
-    // raster-earlier tile that has work and whose REGION overlaps its own is done (dependency passes, soilmx.hip grid_sweep), and tiles with
-    // disjoint regions concurrently; a tile touches nothing outside its region (nested particles are suspended at its edge), so sweeps of
-    // disjoint regions commute and this sequential loop IS the result. Region = the tile and `ring` rings of tiles around it: 4 (36 x 36
-    // cells), 1 under column strips (the region of a seam tile has to stay inside the seam zone).
-    const int ring = bs_n > 1 ? 1 : 4;
+    // 8x8-cell tiles, colour by colour (tx mod 3, ty mod 3), x-major inside a tile. A tile's REGION -- the tile and the ring of tiles around it,
+    // 24 x 24 cells -- is what its sweep may touch: seep + cascade(.., 3) reach 4 cells, and its nested particles run inside (b_nested) or are
+    // suspended at the edge. Regions of equal colour are disjoint (any order: ascending here); the engine orders tiles of overlapping regions
+    // by colour (soilmx.hip k_grid_tiles_flow).
     for (int ph = 0; ph < (bs_n > 1 ? 2 : 1); ph++)
-      for (int tx = 0; tx < ntx; tx++) {
-        if (bs_n > 1) {                                       // INTERIOR sweep: tiles whose neighbourhood lies inside one strip; SEAM sweep: the rest
+    for (int col = 0; col < 9; col++)
+      for (int tx = col / 3; tx < ntx; tx += 3) {
+        if (bs_n > 1) {                                       // INTERIOR sweep: tiles whose region lies inside one strip; SEAM sweep: the rest
           const int cx0 = std::max(tx - 1, 0) << B_GRID, cx1 = std::min(((tx + 2) << B_GRID) - 1, dimx - 1);
           bool interior = false;
           for (int g = 0; g < bs_n; g++) { const int lo = bs_x(g) + (g ? bs_a : 0), hi = bs_x(g + 1) - (g < bs_n - 1 ? bs_a : 0); if (cx0 >= lo && cx1 < hi) interior = true; }
           if ((ph == 0) != interior) continue;
         }
-        for (int ty = 0; ty < nty; ty++) {
-          b_defer = true; b_parent = (uint64_t)ph * ntx * nty + (uint64_t)tx * nty + ty; b_seq = 0;
-          const BRect g = {tx - ring < 0 ? 0 : tx - ring, tx + ring > ntx - 1 ? ntx - 1 : tx + ring, ty - ring < 0 ? 0 : ty - ring, ty + ring > nty - 1 ? nty - 1 : ty + ring};
+        for (int ty = col % 3; ty < nty; ty += 3) {
+          b_defer = true; b_parent = ((uint64_t)ph * 9 + (uint64_t)col) * ntx * nty + (uint64_t)tx * nty + ty; b_seq = 0;
+          const BRect g = {tx - 1 < 0 ? 0 : tx - 1, tx + 1 > ntx - 1 ? ntx - 1 : tx + 1, ty - 1 < 0 ? 0 : ty - 1, ty + 1 > nty - 1 ? nty - 1 : ty + 1};
           b_guard = &g; b_ctx = "grid";
           for (int x = tx << B_GRID; x < ((tx + 1) << B_GRID) && x < dimx; x++)
             for (int y = ty << B_GRID; y < ((ty + 1) << B_GRID) && y < dimy; y++) {

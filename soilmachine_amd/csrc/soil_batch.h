@@ -34,10 +34,13 @@
 
 namespace smx {
 
-constexpr int GRID_RING = 4;                  // ... and a tile's REGION is the tile and GRID_RING rings of tiles around it (36 x 36 cells): where its nested particles may run.
-                                              // Measured (tools/p2_proxy.py, profiles/r05_p2_grid_pass.md): one ring (the seep / cascade reach) suspends so many that the
-                                              // pass leaves +26 % cells under water; four rings suspend 0.4 % of them. Under column strips: one ring (grid_ring).
-constexpr int GRID_SHIFT = 2;                 // the grid pass works on 4x4-cell tiles (one cascade reaches 4 cells)
+constexpr int GRID_SHIFT = 3;                 // the grid pass works on 8x8-cell tiles. A tile's REGION -- the cells its thread owns while it sweeps the tile: the reach of seep +
+                                              // cascade(.., 3) (4 cells) and the room its nested particles run in -- is the tile and the ring of tiles around it, 24 x 24 cells;
+                                              // tiles whose regions overlap have different colours (tx mod 3, ty mod 3) and are swept in colour order. Measured
+                                              // (tools/p2_proxy.py, profiles/r05_p2_analysis.md): 4x4-cell tiles dry lakes 14 % too far in colour order (the reference's raster
+                                              // sweep ploughs water ahead of itself; inside an 8x8 tile the order IS the raster order) and leave their nested particles 4 cells of
+                                              // room (+26 % cells under water when the suspended ones run after the pass); 8x8: every figure within 1 sigma of the reference.
+constexpr int DIRTY_SHIFT = 2;                // column strips: the halo exchange tracks changes in 4x4-cell tiles (bs.dirty)
 constexpr uint32_t B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3;   // B_NEW: top-level particle that has not acted yet
 constexpr uint32_t B_AWAY = 4;               // column strips on several devices: the particle currently lives on another device
 constexpr int SMX_WATER_GENERATIONS = 4;      // a tick's water particles run as this many consecutive top-level generations of n/k (smx_set_water_generations): the particles of
@@ -114,8 +117,6 @@ struct BatchShared {
 };
 struct RReq { double amount, vol; uint32_t cell, type, kind, casc; };   // kind: R_* bits; casc: cell whose cascade this step asks for (NIL: none)
 
-// rings of tiles in a grid tile's region: under column strips the region of a seam tile has to stay inside the seam zone the halo exchange covers
-SMX_D int grid_ring(const BatchShared& bs) { return bs.strips.n > 1 ? 1 : GRID_RING; }
 SMX_D unsigned long long btag(uint32_t epoch, uint32_t slot) { return ((unsigned long long)(epoch + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - slot); }
 SMX_D bool brect_empty(const BRect& r) { return r.tx1 < r.tx0; }
 SMX_D bool brect_contains(const BRect& a, const BRect& b) {   // b inside a
@@ -175,22 +176,22 @@ SMX_D bool beligible_x(const DevState& s, const BatchShared& bs, int cx0, int cx
 // strips: remember which 4x4 grid tiles a particle that acted may have changed (its whole reservation), for the halo exchange
 SMX_D void bmark_dirty(const DevState& s, const BatchShared& bs, const BRect& r) {
   if (bs.strips.n <= 1 || !bs.dirty || brect_empty(r)) return;
-  const int gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+  const int gty = (s.dimy + (1 << DIRTY_SHIFT) - 1) >> DIRTY_SHIFT;
   const int cx0 = r.tx0 << bs.tshift, cy0 = r.ty0 << bs.tshift;
   int cx1 = ((r.tx1 + 1) << bs.tshift) - 1, cy1 = ((r.ty1 + 1) << bs.tshift) - 1;
   if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
   if (cy1 > s.dimy - 1) cy1 = s.dimy - 1;
-  for (int gx = cx0 >> GRID_SHIFT; gx <= (cx1 >> GRID_SHIFT); gx++)
-    for (int gy = cy0 >> GRID_SHIFT; gy <= (cy1 >> GRID_SHIFT); gy++) bs.dirty[(size_t)gx * gty + gy] = 1;
+  for (int gx = cx0 >> DIRTY_SHIFT; gx <= (cx1 >> DIRTY_SHIFT); gx++)
+    for (int gy = cy0 >> DIRTY_SHIFT; gy <= (cy1 >> DIRTY_SHIFT); gy++) bs.dirty[(size_t)gx * gty + gy] = 1;
 }
 SMX_D void bmark_dirty_cells(const DevState& s, const BatchShared& bs, int cx0, int cx1, int cy0, int cy1) {   // the same, for a rectangle of cells
   if (bs.strips.n <= 1 || !bs.dirty) return;
-  const int gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
+  const int gty = (s.dimy + (1 << DIRTY_SHIFT) - 1) >> DIRTY_SHIFT;
   if (cx0 < 0) cx0 = 0; if (cy0 < 0) cy0 = 0;
   if (cx1 > s.dimx - 1) cx1 = s.dimx - 1;
   if (cy1 > s.dimy - 1) cy1 = s.dimy - 1;
-  for (int gx = cx0 >> GRID_SHIFT; gx <= (cx1 >> GRID_SHIFT); gx++)
-    for (int gy = cy0 >> GRID_SHIFT; gy <= (cy1 >> GRID_SHIFT); gy++) bs.dirty[(size_t)gx * gty + gy] = 1;
+  for (int gx = cx0 >> DIRTY_SHIFT; gx <= (cx1 >> DIRTY_SHIFT); gx++)
+    for (int gy = cy0 >> DIRTY_SHIFT; gy <= (cy1 >> DIRTY_SHIFT); gy++) bs.dirty[(size_t)gx * gty + gy] = 1;
 }
 // (a reservation that reaches past the columns a strip context holds -- a resident particle's old rectangle after the strips were
 //  re-cut, a wide dilate -- is neither written nor ever held: the planes end at [txb, txe))
@@ -621,7 +622,7 @@ SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned l
   sim.pol.parent = key; sim.pol.nchild = 0;
   {                                                          // the tile and the ring of tiles around it are this thread's own (its seep + cascade reach them)
     const int gtx = (s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
-    const int R = grid_ring(sim.pol.bs);
+    const int R = 1;
     sim.pol.region = BRect{tx - R < 0 ? 0 : tx - R, tx + R > gtx - 1 ? gtx - 1 : tx + R, ty - R < 0 ? 0 : ty - R, ty + R > gty - 1 ? gty - 1 : ty + R};
   }
   Water dummy;
@@ -639,13 +640,7 @@ SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned l
       sim.water_drive(dummy, false, false, st, depth);
       visited++;
     }
-  if (visited && sim.pol.bs.strips.n > 1 && sim.pol.bs.dirty) {   // strips: the tile and its neighbours may have changed
-    const BatchShared& bs = sim.pol.bs;
-    const int gtx = (s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
-    for (int ax = tx - 1; ax <= tx + 1; ax++)
-      for (int ay = ty - 1; ay <= ty + 1; ay++)
-        if (ax >= 0 && ay >= 0 && ax < gtx && ay < gty) bs.dirty[(size_t)ax * gty + ay] = 1;
-  }
+  if (visited) bmark_dirty_cells(s, sim.pol.bs, x0 - (1 << GRID_SHIFT), x0 + 2 * (1 << GRID_SHIFT) - 1, y0 - (1 << GRID_SHIFT), y0 + 2 * (1 << GRID_SHIFT) - 1);   // strips: the region may have changed
   sim.flush_counters();                                      // (cascade counters of the grid pass go straight to DevState::ctr)
   if (sim.pol.a_casc) SMX_A_ADD64(&s.ctr[C_CASCADE_CALLS], (unsigned long long)sim.pol.a_casc);
   if (sim.pol.a_tr) SMX_A_ADD64(&s.ctr[C_CASCADE_TRANSFERS], (unsigned long long)sim.pol.a_tr);

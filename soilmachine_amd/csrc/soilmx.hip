@@ -522,56 +522,49 @@ __global__ void __launch_bounds__(256) k_batch_counters(DevState s, BatchShared 
     for (int off = 32; off > 0; off >>= 1) acc[k] += (unsigned long long)__shfl_down((long long)acc[k], off);
   if ((threadIdx.x & 63u) == 0) batch_commit_counters(s, WIND, acc);
 }
-// ---------------- grid pass (water.h:335-343) in dependency passes over the 4x4-cell tiles ----------------
-// A tile's seep + cascade(.., 3) -- and the nested particles that run inside it -- reach the ring of tiles around it (its REGION).
-// Tiles whose regions overlap are processed in block-raster order (tx-major, then ty: the direction of the reference's sweep); tiles
-// whose regions are disjoint in the same pass. A tile is eligible in pass p once every raster-earlier tile within 2 * grid_ring tiles of it
-// that has work is done in a pass < p; the raster-first pending tile always is, so every pass makes progress. Results do not depend
-// on how the hardware orders the tiles of a pass (disjoint regions), nor on the number of passes a lake takes.
+// ---------------- grid pass (water.h:335-343) over the 8x8-cell tiles (soil_batch.h GRID_SHIFT) ----------------
+// A tile's seep + cascade(.., 3) -- and the nested particles that run inside it -- stay in the tile and the ring of tiles around it (its
+// REGION). Regions of tiles two or less apart overlap; such tiles have different colours (tx mod 3, ty mod 3) and are swept in colour
+// order. The sweep is a DATAFLOW over the tiles that have work, sorted by (colour, tile): a wavefront takes the next entry, waits until
+// every tile of a smaller colour within two tiles of its own that has work is done, sweeps its tile (lane 0) and publishes it. A tile only
+// waits for entries before its own, taken by wavefronts that are running: no deadlock; chains of waiting tiles are at most nine long, and
+// a tile in a quiet corner never waits for the slowest tile of a colour somewhere else (nine launches with a barrier each: 9 x 5 ms in
+// round 4, with 16-cell tiles and no nested particles inside). One tile per wavefront: a tile is a long, branchy path, and lanes of one
+// wavefront cannot wait for each other. The order of conflicting tiles is fixed, so the result is the colour-by-colour sweep's.
 constexpr uint32_t GT_PENDING = 0xFFFFFFFFu;
 struct GridTiles {
-  uint32_t* tdone;                            // [held tile columns][gty]: 0 = nothing to do, GT_PENDING, else the pass that processed the tile
-  uint32_t* pend[2];                          // pending tiles (global tile index tx * gty + ty), in / out of a pass
-  uint32_t* count;                            // [2] lengths of pend[0], pend[1]
+  uint32_t* tdone;                            // [held tile columns][gty]: 0 = nothing to do here, GT_PENDING, 1 = swept
+  uint32_t* pend[2];                          // entries colour * (gtx * gty) + tile (tile = tx * gty + ty): as appended / sorted
+  uint32_t* count;                            // [0] entries, [1] the dataflow kernel's cursor
   int gtx, gty, txb, txe;                     // tiles of the map; tile columns [txb, txe) held by tdone
   int tx_lo, tx_hi;                           // tile columns of this sweep
-  unsigned long long keybase;                 // key prefix of a tile's children: keybase + tile index
+  unsigned long long keybase;                 // key prefix of a tile's children: keybase + entry
 };
-SMX_D bool grid_tile_done_before(const GridTiles& g, int tx, int ty, uint32_t pass) {
-  if (tx < g.tx_lo || tx >= g.tx_hi || tx < g.txb || tx >= g.txe || ty < 0 || ty >= g.gty) return true;   // not part of this sweep
-  return g.tdone[(size_t)(tx - g.txb) * g.gty + ty] < pass;
-}
 __global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared bs, GridTiles g) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t ncol = (uint32_t)(g.tx_hi - g.tx_lo);
-  bool act = false; uint32_t tile = 0;
+  bool act = false; uint32_t entry = 0;
   if (i < ncol * (uint32_t)g.gty) {
     const int tx = g.tx_lo + (int)(i / (uint32_t)g.gty), ty = (int)(i % (uint32_t)g.gty);
-    tile = (uint32_t)tx * (uint32_t)g.gty + (uint32_t)ty;
+    entry = (uint32_t)((tx % 3) * 3 + (ty % 3)) * ((uint32_t)g.gtx * (uint32_t)g.gty) + (uint32_t)tx * (uint32_t)g.gty + (uint32_t)ty;
     if (batch_grid_tile_phase(s, bs, tx)) {
       const int x0 = tx << GRID_SHIFT, y0 = ty << GRID_SHIFT;
-      for (int x = x0; x < x0 + (1 << GRID_SHIFT) && x < s.dimx; x++)
-        for (int y = y0; y < y0 + (1 << GRID_SHIFT) && y < s.dimy; y++) {
-          const size_t c = (size_t)x * s.dimy + y;
-          act |= ((s.active[c >> 6] >> (c & 63)) & 1ull) != 0ull;
-        }
+      for (int x = x0; x < x0 + (1 << GRID_SHIFT) && x < s.dimx; x++) {   // (a tile row = 8 consecutive bits of the bitmap)
+        const size_t c = (size_t)x * s.dimy + y0;
+        int len = s.dimy - y0; if (len > (1 << GRID_SHIFT)) len = 1 << GRID_SHIFT;
+        for (int y = 0; y < len; y++) act |= ((s.active[(c + y) >> 6] >> ((c + y) & 63)) & 1ull) != 0ull;
+      }
     }
     g.tdone[(size_t)(tx - g.txb) * g.gty + ty] = act ? GT_PENDING : 0u;
   }
   const uint32_t k = relax_append(&g.count[0], act);
-  if (act) g.pend[0][k] = tile;
+  if (act) g.pend[0][k] = entry;
 }
-// DATAFLOW over the tiles that have work, in raster order: a wavefront takes the next tile of the (sorted) list, waits until every
-// raster-earlier tile whose region overlaps this one's is done, sweeps it (lane 0) and publishes it. A tile only ever waits for tiles that
-// were taken before it, by wavefronts that are running: no deadlock, and the sweep lasts as long as its longest chain of dependent tiles
-// (a lake of W x H tiles: H + (2 ring + 1) W tiles in a row) -- not the sum, over global passes, of each pass's slowest tile (round 5's
-// first version: 384 passes x 4 ms at the headline). ONE tile per wavefront: lanes of one wavefront cannot wait for each other.
-// The order of conflicting tiles is fixed by the dependencies, so the result is the block-raster sweep's, whatever the timing.
 __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n) {
   SMX_LOAD_SOILS(sh)
   __shared__ uint32_t s_i;
   unsigned long long vis = 0;
-  const int W = 2 * grid_ring(bs);
+  const uint32_t nt = (uint32_t)g.gtx * (uint32_t)g.gty;
   while (true) {
     if (threadIdx.x == 0) s_i = atomicAdd(&g.count[1], 1u);
     __syncthreads();
@@ -579,20 +572,21 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
     __syncthreads();
     if (i >= n) break;
     if (threadIdx.x == 0) {
-      const uint32_t tile = order[i];
+      const uint32_t entry = order[i], col = entry / nt, tile = entry - col * nt;
       const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
-      for (int dx = 0; dx <= W; dx++)                          // the raster-earlier tiles whose region overlaps this one's
-        for (int dy = (dx ? -W : 1); dy <= W; dy++) {
-          const int ax = tx - dx, ay = dx ? ty + dy : ty - dy;
-          if (ax < g.tx_lo || ax >= g.tx_hi || ax < g.txb || ax >= g.txe || ay < 0 || ay >= g.gty) continue;
-          const uint32_t* f = &g.tdone[(size_t)(ax - g.txb) * g.gty + ay];
+      for (int dx = -2; dx <= 2; dx++)                         // the tiles whose region overlaps this one's and whose colour comes first
+        for (int dy = -2; dy <= 2; dy++) {
+          const int ax = tx + dx, ay = ty + dy;
+          if ((!dx && !dy) || ax < g.tx_lo || ax >= g.tx_hi || ax < g.txb || ax >= g.txe || ay < 0 || ay >= g.gty) continue;
+          if ((uint32_t)((ax % 3) * 3 + (ay % 3)) >= col) continue;
+          uint32_t* f = &g.tdone[(size_t)(ax - g.txb) * g.gty + ay];
           while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GT_PENDING) __builtin_amdgcn_s_sleep(8);
         }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // what the tiles before wrote to the map is visible from here on
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
       Frame st[MAX_FRAMES];
-      vis += batch_grid_tile(sim, tx, ty, g.keybase + (unsigned long long)tile, st);
+      vis += batch_grid_tile(sim, tx, ty, g.keybase + (unsigned long long)entry, st);
       sim.flush_counters(); pol.finish(s);
       __hip_atomic_store(&g.tdone[(size_t)(tx - g.txb) * g.gty + ty], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1962,8 +1956,8 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, uint32_t nkids
   HIPCHK(hipGetLastError());
   return 0;
 }
-// One sweep of the grid pass over the tile columns [tx_lo, tx_hi): the tiles with work, in raster order, through the dataflow kernel
-// (k_grid_tiles_flow); bs.sphase says which kind of tile the sweep takes under column strips.
+// One sweep of the grid pass over the tile columns [tx_lo, tx_hi): the tiles with work, in (colour, tile) order, through the dataflow
+// kernel (k_grid_tiles_flow); bs.sphase says which kind of tile the sweep takes under column strips.
 static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
   hipStream_t st = ctx->stream;
   const int gtx = (ctx->cfg.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (ctx->cfg.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
@@ -1981,7 +1975,7 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
   GridTiles g;
   g.tdone = ctx->d_tdone; g.pend[0] = ctx->d_tpend[0]; g.pend[1] = ctx->d_tpend[1]; g.count = ctx->d_tcount;
   g.gtx = gtx; g.gty = gty; g.txb = txb; g.txe = txe; g.tx_lo = tx_lo; g.tx_hi = tx_hi;
-  g.keybase = (unsigned long long)phase * (unsigned long long)gtx * (unsigned long long)gty;
+  g.keybase = (unsigned long long)phase * 9ull * (unsigned long long)gtx * (unsigned long long)gty;   // key prefix = (phase * 9 + colour) * tiles + tile
   HIPCHK(hipMemsetAsync(ctx->d_tcount, 0, 8, st));
   const uint32_t ntl = (uint32_t)(tx_hi - tx_lo) * (uint32_t)gty;
   hipLaunchKernelGGL(k_grid_tiles_init, dim3((ntl + 255u) / 256u), dim3(256), 0, st, ctx->d, bs, g);
@@ -1991,7 +1985,7 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
   static const bool trace = [] { const char* e = getenv("SMX_TRACE_BATCH"); return e && atoi(e) != 0; }();
   const auto t_sweep = std::chrono::steady_clock::now();
   if (n > 0) {
-    // the tiles with work in raster order (the init kernel appended them as its wavefronts came); tile indices are unique
+    // the tiles with work in (colour, tile) order (the init kernel appended them as its wavefronts came); entries are unique
     if (ctx->tsort_cap < n) {
       hipFree(ctx->d_tsort); ctx->d_tsort = nullptr; ctx->tsort_cap = 0; ctx->tsort_bytes = 0;
       const uint32_t cap = (uint32_t)((size_t)(txe - txb) * gty);
@@ -2236,8 +2230,8 @@ int smx_d_grid_begin(smx_ctx* ctx) {
   launch_classify(ctx);
   return 0;
 }
-int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t tx_lo, int32_t tx_hi) {
-  const int rc = grid_sweep(ctx, phase, tx_lo, tx_hi);
+int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t x_lo, int32_t x_hi) {   // the tiles of the COLUMNS [x_lo, x_hi) (multiples of the tile size)
+  const int rc = grid_sweep(ctx, phase, x_lo >> GRID_SHIFT, (x_hi + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;

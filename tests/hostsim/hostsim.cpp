@@ -648,9 +648,9 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
 extern "C" {
 void hs_batched_water(hs_ctx* c, int n, int nthreads, unsigned shuffle) { BatchBuffers b; batch_generations(c, b, false, (uint32_t)n, {}, nthreads, shuffle); }
 void hs_batched_wind(hs_ctx* c, int n, int nthreads, unsigned shuffle) { BatchBuffers b; batch_generations(c, b, true, (uint32_t)n, {}, nthreads, shuffle); }
-// One sweep of the grid pass over the tile columns [tx_lo, tx_hi) in dependency passes (soilmx.hip grid_sweep / k_grid_tiles_pass): a tile is
-// eligible once every raster-earlier tile within two tiles of it that has work is done in an EARLIER pass; the tiles of a pass run on the
-// host threads in any order (their regions are disjoint).
+// One sweep of the grid pass over the tile columns [tx_lo, tx_hi): the tiles with work colour by colour (tx mod 3, ty mod 3) -- the order the
+// device's dataflow kernel enforces between tiles whose regions overlap (soilmx.hip k_grid_tiles_flow); the tiles of one colour own disjoint
+// regions and run on the host threads in any order.
 static unsigned long long grid_sweep(hs_ctx* c, BatchBuffers& b, int phase, int tx_lo, int tx_hi, int nthreads, unsigned shuffle) {
   const DevState& s = c->d;
   const int gtx = (s.dimx + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, gty = (s.dimy + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT;
@@ -658,44 +658,23 @@ static unsigned long long grid_sweep(hs_ctx* c, BatchBuffers& b, int phase, int 
   if (tx_hi > gtx) tx_hi = gtx;
   b.bs.tshift = GRID_SHIFT; b.bs.sphase = phase;
   const BatchShared& bs = b.bs;
-  const uint32_t PENDING = 0xFFFFFFFFu;
-  std::vector<uint32_t> tdone((size_t)gtx * gty, 0u), pend, next;
-  for (int tx = tx_lo; tx < tx_hi; tx++)
-    for (int ty = 0; ty < gty; ty++) {
-      bool act = false;
-      if (batch_grid_tile_phase(s, bs, tx))
-        for (int x = tx << GRID_SHIFT; x < ((tx + 1) << GRID_SHIFT) && x < s.dimx; x++)
-          for (int y = ty << GRID_SHIFT; y < ((ty + 1) << GRID_SHIFT) && y < s.dimy; y++) { const size_t cc = (size_t)x * s.dimy + y; act |= ((c->a0[cc >> 6] >> (cc & 63)) & 1ull) != 0ull; }
-      if (act) { tdone[(size_t)tx * gty + ty] = PENDING; pend.push_back((uint32_t)tx * (uint32_t)gty + (uint32_t)ty); }
-    }
-  auto done_before = [&](int tx, int ty, uint32_t pass) { return tx < tx_lo || tx >= tx_hi || ty < 0 || ty >= gty || tdone[(size_t)tx * gty + ty] < pass; };
-  const unsigned long long keybase = (unsigned long long)phase * (unsigned long long)gtx * (unsigned long long)gty;
+  const unsigned long long keybase = (unsigned long long)phase * 9ull * (unsigned long long)gtx * (unsigned long long)gty;   // key prefix = (phase * 9 + colour) * tiles + tile
   unsigned long long visited = 0;
-  for (uint32_t pass = 1; !pend.empty(); pass++) {
-    std::vector<unsigned long long> vis(pend.size(), 0);
-    std::vector<uint8_t> later(pend.size(), 0);
-    const std::vector<uint32_t> before = tdone;               // (what a tile may see of the others: the state when the pass began)
-    parallel_for((uint32_t)pend.size(), nthreads, [&](uint32_t i) {
-      const uint32_t tile = pend[i];
-      const int tx = (int)(tile / (uint32_t)gty), ty = (int)(tile % (uint32_t)gty);
-      auto ok_ = [&](int ax, int ay) { return ax < tx_lo || ax >= tx_hi || ay < 0 || ay >= gty || before[(size_t)ax * gty + ay] < pass; };
-      bool ok = true;
-      const int W = 2 * grid_ring(bs);                        // the raster-earlier tiles whose region overlaps this one's
-      for (int dy = 1; dy <= W; dy++) ok &= ok_(tx, ty - dy);
-      for (int dx = 1; dx <= W; dx++) for (int dy = -W; dy <= W; dy++) ok &= ok_(tx - dx, ty + dy);
-      if (!ok) { later[i] = 1; return; }
+  for (uint32_t col = 0; col < 9u; col++) {
+    std::vector<uint32_t> tiles;
+    for (int tx = tx_lo; tx < tx_hi; tx++) {
+      if (tx % 3 != (int)(col / 3u) || !batch_grid_tile_phase(s, bs, tx)) continue;
+      for (int ty = (int)(col % 3u); ty < gty; ty += 3) tiles.push_back((uint32_t)tx * (uint32_t)gty + (uint32_t)ty);
+    }
+    std::vector<unsigned long long> vis(tiles.size(), 0);
+    parallel_for((uint32_t)tiles.size(), nthreads, [&](uint32_t i) {
+      const int tx = (int)(tiles[i] / (uint32_t)gty), ty = (int)(tiles[i] % (uint32_t)gty);
       BatchPolicy pol(s, bs); Sim<BatchPolicy> sim(s, s.soils, pol);
       Frame st[MAX_FRAMES];
-      vis[i] = batch_grid_tile(sim, tx, ty, keybase + (unsigned long long)tile, st);
+      vis[i] = batch_grid_tile(sim, tx, ty, keybase + (unsigned long long)col * (unsigned long long)gtx * gty + (unsigned long long)tiles[i], st);
       sim.flush_counters(); pol.finish(s);
-      tdone[(size_t)tx * gty + ty] = pass;
-    }, shuffle ? shuffle + 3 + pass : 0);
-    (void)done_before;
-    next.clear();
-    for (size_t i = 0; i < pend.size(); i++) { visited += vis[i]; if (later[i]) next.push_back(pend[i]); }
-    if (next.size() >= pend.size()) { fprintf(stderr, "[hostsim] grid pass: no tile became eligible\n"); abort(); }
-    if (getenv("HS_GRID_TRACE")) fprintf(stderr, "[hostsim] grid pass %u: %zu tiles in, %zu left, %u suspended\n", pass, pend.size(), next.size(), b.ctrl[BC_NCHILD]);
-    pend.swap(next);
+    }, shuffle ? shuffle + 3 + col : 0);
+    for (unsigned long long v : vis) visited += v;
     batch_merge_freed(c, b);
   }
   return visited;
@@ -909,8 +888,8 @@ void hs_d_grid_begin(hs_ctx* c) {
   batch_setup(c, d.b, 0, false);
   d.b.ctrl[BC_NCHILD] = 0;
 }
-void hs_d_grid_sweep(hs_ctx* c, int phase, int tx_lo, int tx_hi) {
+void hs_d_grid_sweep(hs_ctx* c, int phase, int x_lo, int x_hi) {   // (cell columns, as smx_d_grid_sweep)
   DPhase& d = dp_of(c);
-  c->ctr[C_GRID_ACTIVE] += grid_sweep(c, d.b, phase, tx_lo, tx_hi, 1, 0);
+  c->ctr[C_GRID_ACTIVE] += grid_sweep(c, d.b, phase, x_lo >> GRID_SHIFT, (x_hi + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, 1, 0);
 }
 }  // extern "C"

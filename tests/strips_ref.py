@@ -164,11 +164,11 @@ class StripRank:
     def _grid(self):
         be, g, r = self.be, self.g, self.comm.rank
         be.grid_begin()
-        be.grid_sweep(INTERIOR, self.x0 >> 2, self.x1 >> 2)
+        be.grid_sweep(INTERIOR, self.x0, self.x1)
         if g.n > 1:
             self.sync_halos()
             if r < g.n - 1:
-                be.grid_sweep(SEAM, (self.x1 - g.b) >> 2, (self.x1 + g.b) >> 2)
+                be.grid_sweep(SEAM, self.x1 - g.b, self.x1 + g.b)
             self._send_band_right(False)
             self._recv_band_from_left(False)
         mine = be.gen_end()
