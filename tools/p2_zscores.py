@@ -20,7 +20,7 @@ from oracle_lib import Oracle
 
 CASES = {"rgps": ("rockgravelpebblessand.soil", 40, 250, 250), "rocksand": ("rocksand.soil", 40, 250, 100), "painted": ("painted.soil", 40, 250, 100),
          "sand": ("sand.soil", 40, 250, 250), "rgpbig": ("rockgravelpebbles_big.soil", 20, 1000, 0), "default_wet": ("default.soil", 150, 250, 0)}
-FIGS = ("steps_water", "nested", "floods", "sections", "standing", "sumh", "height_rmse")
+FIGS = ("steps_water", "steps_top", "nested", "floods", "sections", "standing", "sumh", "height_rmse")
 
 
 def standing(s):
@@ -30,7 +30,7 @@ def standing(s):
 
 def figures(snap, ctr, h0):
     h = snap.heights(); d = h - h0
-    return {"steps_water": ctr["steps_water_all"], "nested": ctr["nested_particles"], "floods": ctr["floods"], "sections": int(snap.nsec),
+    return {"steps_water": ctr["steps_water_all"], "steps_top": ctr["steps_water_top"], "nested": ctr["nested_particles"], "floods": ctr["floods"], "sections": int(snap.nsec),
             "standing": standing(snap), "sumh": float(h.sum()), "height_rmse": float(np.sqrt((d * d).mean()))}
 
 
@@ -56,9 +56,13 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--out", default=None)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 4)
+    ap.add_argument("--water-generations", type=int, default=0, help="0 = the engine's default (4)")
     a = ap.parse_args()
     if a.engine in CASES:
         a.cases.insert(0, a.engine); a.engine = "relaxed"
+    if a.water_generations:
+        from hostsim_lib import lib as _hl
+        _hl().hs_set_water_generations(a.water_generations)
     res = {"engine": a.engine, "size": a.size, "nctl": a.nctl, "protocol": __doc__.split("\n\n")[1], "cases": {}}
     for nm in (a.cases or list(CASES)):
         soil, ticks, nw, nd = CASES[nm]
