@@ -33,9 +33,9 @@ def start_state(kind, n):
     return cfg, Layermap(cfg, n, n, seed=0).snapshot()
 
 
-def device_ctx(cfg, s0, n, engine=capi.ENGINE_BATCHED, x_range=None):
+def device_ctx(cfg, s0, n, engine=capi.ENGINE_BATCHED, x_range=None, device=0):
     """x_range = (lo, hi): a STRIP context that holds only these columns of the map (smx_create_strip): memory follows the strip"""
-    m = Layermap(cfg, n, n, seed=0, initialize=False, engine=engine, x_range=x_range)
+    m = Layermap(cfg, n, n, seed=0, initialize=False, engine=engine, x_range=x_range, device=device)
     m.load(s0, rand_seed=0)
     return m
 
@@ -151,18 +151,23 @@ def test_rccl_transport_with_the_one_rank_a_single_device_allows():
     rk.detach()
 
 
-def _worker(rank, world, port, path, nw, nd, ticks, n, soil, lib_driver=False):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, path, nw, nd, ticks, n, soil, lib_driver=False, rccl=False, engine=None):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # (gloo hands the RCCL unique id around; the halos go over RCCL itself)
     z = np.load(path)
     cfg = load_cfg(soil)
     s0 = Snapshot(n, n, cfg.SCALE, len(cfg.soils), int(z["rand_calls"]), 0, z["count"], z["type"], z["size"], z["floor"], z["sat"],
                   z["wfreq"], z["wtrack"], z["windfreq"])
-    m = device_ctx(cfg, s0, n)
-    rk = LibStripRank(m, TorchComm(dist), StripGeometry(n, world)) if lib_driver else StripRank(DeviceStripBackend(m), TorchComm(dist), StripGeometry(n, world))
+    if rccl:                                                           # one device per rank, the rank's context holds its strip only
+        geom = StripGeometry(n, world)
+        m = device_ctx(cfg, s0, n, engine if engine is not None else capi.ENGINE_BATCHED, x_range=geom.held(rank, n), device=rank)
+        rk = LibStripRank(m, TorchComm(dist), geom, transport="rccl")
+    else:
+        m = device_ctx(cfg, s0, n)
+        rk = LibStripRank(m, TorchComm(dist), StripGeometry(n, world)) if lib_driver else StripRank(DeviceStripBackend(m), TorchComm(dist), StripGeometry(n, world))
     for _ in range(ticks):
         rk.tick(nw, nd, True, nd > 0)
     s = m.snapshot()
@@ -184,6 +189,35 @@ def test_two_processes_torch_distributed_equal_single_context(tmp_path, lib_driv
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, path, nw, nd, ticks, n, soil, lib_driver), nprocs=2, join=True)
     ref, cref = single_context(cfg, s0, n, 2, nw, nd, ticks)
+    snaps, steps = [], 0
+    for r in range(2):
+        z = np.load(path + f".rank{r}.npz")
+        snaps.append(Snapshot(n, n, cfg.SCALE, len(cfg.soils), int(z["rand_calls"]), 0, z["count"], z["type"], z["size"], z["floor"],
+                              z["sat"], z["wfreq"], z["wtrack"], z["windfreq"]))
+        steps += int(z["steps"])
+    assert not compare(merge_owned(StripGeometry(n, 2), snaps, n), ref)
+    assert steps == cref["steps_water_all"] + cref["steps_wind"]
+
+
+@pytest.mark.parametrize("engine", ["batched", "relaxed"])
+def test_rccl_two_ranks_equal_single_context(tmp_path, engine):
+    """The RCCL transport with MORE THAN ONE rank: two processes, one device each, strip contexts
+    (smx_create_strip), smx_strips_attach_rccl -- halo columns and migrating particles by ncclSend / ncclRecv between the devices' own
+    buffers -- against ONE context running the same two-strip schedule, bit for bit. Needs two GPUs: skipped on the one-GPU boxes this
+    suite usually sees, enabled by itself on the multi-GPU node before bench.py --gpus N relies on the transport."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices (RCCL refuses two ranks on one)")
+    eng = capi.ENGINE_RELAXED if engine == "relaxed" else capi.ENGINE_BATCHED
+    n, nw, nd, ticks, soil = 256, 400, 200, 3, "rockgravelpebblessand.soil"
+    cfg, s0 = start_state("dry", n)
+    path = str(tmp_path / "s0.npz")
+    np.savez(path, count=s0.count, type=s0.type, size=s0.size, floor=s0.floor, sat=s0.sat, wfreq=s0.wfreq, wtrack=s0.wtrack,
+             windfreq=s0.windfreq, rand_calls=s0.rand_calls)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, path, nw, nd, ticks, n, soil, True, True, eng), nprocs=2, join=True)
+    ref, cref = single_context(cfg, s0, n, 2, nw, nd, ticks, eng)
     snaps, steps = [], 0
     for r in range(2):
         z = np.load(path + f".rank{r}.npz")
