@@ -85,7 +85,7 @@ constexpr int STRIP_INTERIOR = 0, STRIP_SEAM = 1;
 // relaxed schedule, per epoch parity p = epoch & 1: BC_NFLOOD + p = length of the flood list, BC_NFLAG + p = cells flagged for a cascade,
 // BC_NCASC + 9 * p + colour = length of a colour's cascade list
 // BC_NRUN + p = particles that stepped in the epoch
-enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_LIST_LOST, BC_NFLOOD = 8, BC_NFLAG = 10, BC_NCASC = 12, BC_NRUN = 30, BC_COUNT = 32 };
+enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_LIST_LOST, BC_RANGE_REJECT /* reservations that reach past the held columns (bholds) */, BC_NFLOOD = 8, BC_NFLAG = 10, BC_NCASC = 12, BC_NRUN = 30, BC_COUNT = 32 };
 constexpr int R_MAXSTEPS = 8;                 // relaxed schedule: steps one wind particle may take per epoch (2 request entries each)
 
 struct BatchShared {
@@ -200,7 +200,7 @@ SMX_D void bclaim(const BatchShared& bs, int plane, const BRect& r, unsigned lon
     for (int ty = r.ty0; ty <= r.ty1; ty++) (void)SMX_A_MAX64(&bs.claim[plane][(size_t)(tx - bs.txb) * bs.nty + ty], tag);
 }
 SMX_D bool bholds(const BatchShared& bs, int plane, const BRect& r, unsigned long long tag) {
-  if (r.tx1 >= r.tx0 && (r.tx0 < bs.txb || r.tx1 >= bs.txe)) return false;
+  if (r.tx1 >= r.tx0 && (r.tx0 < bs.txb || r.tx1 >= bs.txe)) { SMX_A_ADD(&bs.ctrl[BC_RANGE_REJECT], 1u); return false; }   // (counted: the strip driver names it when a phase stalls)
   bool ok = true;
   for (int tx = r.tx0; tx <= r.tx1; tx++)
     for (int ty = r.ty0; ty <= r.ty1; ty++) ok &= (bs.claim[plane][(size_t)(tx - bs.txb) * bs.nty + ty] == tag);

@@ -77,15 +77,7 @@ SMX_D void relax_flood_later(const BatchShared& bs, uint32_t slot, uint32_t pari
 // progress when two flood epochs follow each other, i.e. once the threshold holds; with 1/16 the established wet regime ran +11 % water
 // steps against the reference (control <= +5 %), with 1/64 +2 % at equal height RMSE (profiles/r03_flood_rule_cpu.md, r04_p2_*).
 constexpr unsigned long long RELAX_FLOOD_SHARE = 64ull;
-#ifdef SMX_HOSTSIM
-static int g_hs_flood_rule = 0;                               // (host-side experiments only, tools/p2_statistics.py: 0 = the schedule's rule)
-#endif
 SMX_D bool relax_floods_due(const BatchShared& bs, uint32_t epoch, uint32_t nflood, uint32_t nrun) {
-#ifdef SMX_HOSTSIM
-  if (g_hs_flood_rule == 1) return true;                                                                               // every epoch
-  if (g_hs_flood_rule == 2) return bs.strips.n > 1 || (epoch & 1u) == 1u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun;
-  if (g_hs_flood_rule == 16) return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * 16ull >= (unsigned long long)nrun;   // round 3's rule
-#endif
   return bs.strips.n > 1 || (epoch & 3u) == 3u || (unsigned long long)nflood * RELAX_FLOOD_SHARE >= (unsigned long long)nrun;
 }
 // after the epoch's edits are applied: which flagged cells can move anything at all? (Particle::cascade starts with the same

@@ -301,11 +301,12 @@ static int st_phase(smx_ctx* ctx, StripState& S, bool wind, uint32_t n, std::vec
   while (nslots > 0) {
     contains.assign(have_kids ? nslots : 0, 0u);
     if (smx_d_gen_begin(ctx, wind ? 1 : 0, nslots, have_kids ? kids.data() : nullptr, have_kids ? contains.data() : nullptr)) return -1;
-    if (have_kids && S.T->allreduce_min_u32(ctx, contains.data(), contains.size())) return -1;   // each child's `contains` comes from the owner of its random cell
+    // (rounds 2-4: a min-all-reduce of the children's `contains`, read by the owner of each child's random cell; the records carry it since round 5)
     uint32_t local = 0;
     if (smx_d_gen_spawn(ctx, have_kids ? contains.data() : nullptr, &local)) return -1;
     uint64_t nlive = local;
     if (S.T->allreduce_sum(ctx, nlive)) return -1;
+    uint64_t stalled = 0, last = nlive + 1;                   // chunks in a row that ended no particle anywhere
     while (nlive > 0) {
       const bool seam = S.geo.n > 1 && smx_d_next_phase(ctx) == STRIP_SEAM;
       if (seam && st_band_to_left(ctx, S, true)) return -1;
@@ -314,6 +315,12 @@ static int st_phase(smx_ctx* ctx, StripState& S, bool wind, uint32_t n, std::vec
       S.chunks++;
       nlive = local;
       if (S.T->allreduce_sum(ctx, nlive)) return -1;
+      stalled = nlive == last ? stalled + 1 : 0; last = nlive;
+      if (stalled > (1u << 14)) {                              // (the longest particle lives ~13 600 steps = ~425 chunks of progress for somebody)
+        ctx->err = "strips: " + std::to_string(nlive) + " particles made no progress for 16 384 chunks (" + std::to_string(ctx->h_bctrl[BC_RANGE_REJECT]) +
+                   " reservations of this rank reached past the columns it holds: strip geometry and schedule margins do not fit)";
+        return -8;
+      }
     }
     S.generations++;
     if (wind) { uint32_t nc = 0; std::vector<BChild> none; if (d_gen_end_impl(ctx, nullptr, 0, &nc, &none)) return -1; break; }

@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(256) k_normals(DevState s, float* __restrict__
 // stride per thread would scatter every store over two lines).
 // mode -1: no cut (the top section). mode 0: Layermap::update's SLICE cut (layermap.h:477-510). mode 1: Layermap::slice(s)
 // (layermap.h:557-613). thr = the cut height in map units, ycut = the y written for a cut column.
-struct VCut { int mode; double thr; float ycut; unsigned block0 = 0; };   // block0: first 256-cell block of the launch (one column: smx_fill_vertex_cut)
+struct VCut { int mode; double thr; float ycut; unsigned block0 = 0, rel = 0; };   // block0: first 256-cell block of the launch; rel: `out` holds that block only (one column: smx_fill_vertex_cut)
 __global__ void __launch_bounds__(256) k_fill_vertices(DevState s, const float* __restrict__ colors4, uint32_t ncolors,
                                                        float* __restrict__ out, VCut cut) {
   __shared__ float stage[256 * 11];
@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(256) k_fill_vertices(DevState s, const float* 
   }
   __syncthreads();
   const size_t left = n - c0, cells = left < 256 ? left : 256, nf = cells * 11;
-  for (size_t i = threadIdx.x; i < nf; i += 256) out[c0 * 11 + i] = stage[i];
+  for (size_t i = threadIdx.x; i < nf; i += 256) out[(cut.rel ? (size_t)blockIdx.x * 256 : c0) * 11 + i] = stage[i];
 }
 __global__ void __launch_bounds__(256) k_bilinear(DevState s, const float* __restrict__ pos, int n, double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -925,7 +925,8 @@ struct smx_ctx {
   SoilP* d_soils = nullptr;
   int nsoils = 0;
   double* d_scratch = nullptr;        // 1 double for point ops
-  float* d_vtx = nullptr; float* d_vcol = nullptr;   // smx_fill_vertices scratch (kept)
+  float* d_vtx = nullptr; float* d_vcol = nullptr; float* d_vtx1 = nullptr;   // smx_fill_vertices scratch (kept); d_vtx1: one 256-cell block (smx_fill_vertex_cut)
+  float vcol_host[256 * 4]; int vcol_n = -1;          // the colour table on the device
   void* d_plane = nullptr; size_t plane_cap = 0;     // smx_read_heights / _surface / smx_normals scratch (kept)
   std::vector<EvPair> pending;
   std::vector<hipEvent_t> evpool;
@@ -1104,7 +1105,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_tsort); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_vtx1); hipFree(ctx->d_tsort); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1468,18 +1469,23 @@ static int fill_vertices(smx_ctx* ctx, const float* colors4, int32_t ncolors, vo
   FULLMAP("smx_fill_vertices")
   if (!colors4 || ncolors <= 0 || !out_vertices44) { ctx->err = "smx_fill_vertices: colors4/out must be given"; return -2; }
   const size_t bytes = ctx->ncells * 44;
-  if (!ctx->d_vtx) {                                        // scratch kept for the context's lifetime (738 MB at 4096^2)
-    HIPCHK(hipMalloc(&ctx->d_vcol, 256 * 16));
-    if (hipMalloc(&ctx->d_vtx, bytes) != hipSuccess) { ctx->d_vtx = nullptr; ctx->err = "smx_fill_vertices: out of device memory"; return -1; }
-  }
+  if (!ctx->d_vcol) { HIPCHK(hipMalloc(&ctx->d_vcol, 256 * 16)); ctx->vcol_n = -1; }
   if (ncolors > 256) ncolors = 256;
-  HIPCHK(hipMemcpyAsync(ctx->d_vcol, colors4, (size_t)ncolors * 16, hipMemcpyHostToDevice, ctx->stream));
-  if (one_cell >= 0) {                                        // one column (Layermap::update(ivec2, ...)): the block that holds it, 44 bytes back
-    cut.block0 = (unsigned)((size_t)one_cell / 256);
-    hipLaunchKernelGGL(k_fill_vertices, dim3(1), dim3(256), 0, ctx->stream, ctx->d, ctx->d_vcol, (uint32_t)ncolors, ctx->d_vtx, cut);
-    HIPCHK(hipMemcpyAsync(out_vertices44, reinterpret_cast<const char*>(ctx->d_vtx) + (size_t)one_cell * 44, 44, hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->vcol_n != ncolors || memcmp(ctx->vcol_host, colors4, (size_t)ncolors * 16) != 0) {   // (the colour table rarely changes: one upload, not one per call)
+    HIPCHK(hipMemcpyAsync(ctx->d_vcol, colors4, (size_t)ncolors * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->vcol_host, colors4, (size_t)ncolors * 16); ctx->vcol_n = ncolors;
+  }
+  if (one_cell >= 0) {                                        // one column (Layermap::update(ivec2, ...)): the 256-cell block that holds it, into a block-sized scratch
+    if (!ctx->d_vtx1) HIPCHK(hipMalloc(&ctx->d_vtx1, 256 * 44));
+    cut.block0 = (unsigned)((size_t)one_cell / 256); cut.rel = 1u;
+    hipLaunchKernelGGL(k_fill_vertices, dim3(1), dim3(256), 0, ctx->stream, ctx->d, ctx->d_vcol, (uint32_t)ncolors, ctx->d_vtx1, cut);
+    HIPCHK(hipMemcpyAsync(out_vertices44, reinterpret_cast<const char*>(ctx->d_vtx1) + ((size_t)one_cell % 256) * 44, 44, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
+  }
+  if (!ctx->d_vtx) {                                        // whole-map scratch kept for the context's lifetime (738 MB at 4096^2)
+    if (hipMalloc(&ctx->d_vtx, bytes) != hipSuccess) { ctx->d_vtx = nullptr; ctx->err = "smx_fill_vertices: out of device memory"; return -1; }
   }
   hipLaunchKernelGGL(k_fill_vertices, dim3((unsigned)((ctx->ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d, ctx->d_vcol,
                      (uint32_t)ncolors, ctx->d_vtx, cut);

@@ -428,7 +428,6 @@ static int g_relax_wind_steps = 4;                          // ... taking up to 
 static std::atomic<uint32_t> g_relax_tag{0};   // (atomic: several HostSim instances may tick on different threads of one process, tools/p2_ensemble.py)
 extern "C" void hs_set_relaxed(int on) { g_relaxed = on; }
 static int g_relax_water_steps = 1;                         // relaxed water: steps per epoch (smx_set_relax_water)
-extern "C" void hs_set_flood_rule(int r) { g_hs_flood_rule = r; }   // experiments: see soil_relax.h relax_floods_due
 extern "C" void hs_set_relax_water(int steps) { g_relax_water_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
 extern "C" void hs_set_relax_wind(uint32_t n, int steps) { g_relax_wind_min = n; g_relax_wind_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
 static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) {

@@ -36,10 +36,6 @@ def main():
     a = ap.parse_args()
     if a.engine in CASES:
         a.cases.insert(0, a.engine); a.engine = "relaxed"
-    if os.environ.get("HS_FLOOD_RULE"):                       # experiments with the flood-epoch rule (soil_relax.h relax_floods_due; 0 = the schedule's)
-        import ctypes
-        from hostsim_lib import lib
-        lib().hs_set_flood_rule.argtypes = [ctypes.c_int]; lib().hs_set_flood_rule(int(os.environ["HS_FLOOD_RULE"]))
     res = {"engine": a.engine, "size": a.size, "k": a.k, "protocol": __doc__.split("\n\n")[1], "cases": {}}
     for nm in (a.cases or list(CASES)):
         soil, ticks, nw, nd = CASES[nm]

@@ -8,7 +8,7 @@ replaced by its throughput version, K rand() streams per mode in parallel proces
 i.e. in units of the control spread of one run at K x the area (16 x 1024^2 = 4096^2). |z| <~ 2.8 is the noise of this proxy (both means carry it).
 Round 5 found the grid pass's bias with it (the cap of 24 nested particles per tile and pass: profiles/r05_p2_child_cap.md).
 
-  p2_proxy.py <size> <ticks> <K> mode[,mode]     modes: tp_water tp_grid tp_both    env: TERRAIN_OF=<map size whose terrain regime to use> KW=<water generations> CASE=<tools/p2_zscores.py case> HS_FLOOD_RULE
+  p2_proxy.py <size> <ticks> <K> mode[,mode]     modes: tp_water tp_grid tp_both    env: TERRAIN_OF=<map size whose terrain regime to use> KW=<water generations> CASE=<tools/p2_zscores.py case>
 CHECKER ONLY (tests/hostsim, oracle): nothing here is on the product path."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,6 @@ def run(args):
         for l in cfg.layers: l.frequency *= n / float(os.environ["TERRAIN_OF"])   # (the layers' noise is a function of i / dim, layermap.h:183-192)
     o0 = Oracle(cfg, n, n, seed=0); o0.initialize(); s0 = o0.snapshot()
     L = lib()
-    if os.environ.get("HS_FLOOD_RULE"): L.hs_set_flood_rule(int(os.environ["HS_FLOOD_RULE"]))
     if os.environ.get("HS_STAGGER"): L.hs_set_water_stagger(*[int(v) for v in os.environ["HS_STAGGER"].split(",")])
     h = HostSim(cfg, n, n, seed=0); h.load(s0, advance_rand=False); L.hs_srand(h.h, sd)
     kw = int(os.environ.get('KW', '1'))

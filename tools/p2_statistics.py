@@ -13,13 +13,7 @@ CASES = {"rgps": ("rockgravelpebblessand.soil", 40, 250, 250), "rocksand": ("roc
          "sand": ("sand.soil", 40, 250, 250), "rgpbig": ("rockgravelpebbles_big.soil", 20, 1000, 0), "default_wet": ("default.soil", 150, 250, 0)}
 engine = sys.argv[1] if len(sys.argv) > 1 else "relaxed"
 names = sys.argv[2:] or list(CASES)
-if os.environ.get("HS_FLOOD_RULE"):                         # experiments with the flood-epoch rule (profiles/r03_flood_rule_cpu.md); 0 = the schedule's
-    import ctypes
-    from hostsim_lib import lib
-    lib().hs_set_flood_rule.argtypes = [ctypes.c_int]; lib().hs_set_flood_rule(int(os.environ["HS_FLOOD_RULE"]))
-    engine_label = f"relaxed, flood rule {os.environ['HS_FLOOD_RULE']}"
-else:
-    engine_label = None
+engine_label = None
 def standing(s):                                              # water sections on top (type 0)
     end = np.cumsum(s.count.astype(np.int64)); top = end[s.count > 0] - 1
     return int((s.type[top] == 0).sum())
