@@ -41,7 +41,7 @@ for s in "$@"; do
                python tools/kernel_stats.py $out/gaps | tee $out/gaps.kernels
                python tools/trace_gaps.py $out/gaps --last-ticks ${LASTTICKS:-1} | tee $out/gaps.summary
                rm -rf $out/gaps ;;
-    ktrace)    run ktrace 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 3 --warmup 2
+    ktrace)    run ktrace 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps ${KSTEPS:-3} --warmup ${KWARM:-2}
                python tools/kernel_stats.py $out/ktrace | tee $out/ktrace.summary ;;
     ktracew)   run ktracew 30 300 env SMX_RELAX_WIND_MIN=${WMIN:-4096} SMX_RELAX_WIND_STEPS=${WSTEPS:-8} rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktracew -o t -- python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 3 --warmup 2
                python tools/kernel_stats.py $out/ktracew | tee $out/ktracew.summary ;;
@@ -56,6 +56,7 @@ for s in "$@"; do
     stripstest) run stripstest 60 900 python -m pytest tests/test_gpu_strips.py -x -q -m gpu --durations=8 ;;
     bench2gloo) run bench2gloo 60 600 env SMX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --size ${BSIZE:-2048} ;;
     wet)       run wet 30 400 python tools/gpu_wet_exact.py --run ;;
+    wetrelax)  run wetrelax 30 300 python tools/wet_regime.py --engine relaxed --warm 100 --ticks 50 --cpu 0 ;;
     bench)     run bench 60 400 python bench.py; cp $out/bench.log $out/bench.json 2>/dev/null ;;
     benchdrv)  run benchdrv 120 900 python bench.py --gpus 1 --steps 20 --warmup 5; cp $out/benchdrv.log $out/benchdrv.json 2>/dev/null ;;
     benchfull) run benchfull 120 900 python bench.py --full; cp $out/benchfull.log $out/benchfull.json 2>/dev/null ;;

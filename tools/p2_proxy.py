@@ -30,6 +30,7 @@ def run(args):
     o0 = Oracle(cfg, n, n, seed=0); o0.initialize(); s0 = o0.snapshot()
     L = lib()
     if os.environ.get("HS_STAGGER"): L.hs_set_water_stagger(*[int(v) for v in os.environ["HS_STAGGER"].split(",")])
+    if os.environ.get("HS_RELAX_WATER_STEPS"): L.hs_set_relax_water(int(os.environ["HS_RELAX_WATER_STEPS"]))   # steps per epoch of a relaxed water particle (experiment)
     h = HostSim(cfg, n, n, seed=0); h.load(s0, advance_rand=False); L.hs_srand(h.h, sd)
     kw = int(os.environ.get('KW', '1'))
     for t in range(ticks):
