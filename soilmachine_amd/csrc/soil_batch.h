@@ -85,7 +85,7 @@ constexpr int STRIP_INTERIOR = 0, STRIP_SEAM = 1;
 // relaxed schedule, per epoch parity p = epoch & 1: BC_NFLOOD + p = length of the flood list, BC_NFLAG + p = cells flagged for a cascade,
 // BC_NCASC + 9 * p + colour = length of a colour's cascade list
 // BC_NRUN + p = particles that stepped in the epoch
-enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_LIST_LOST, BC_RANGE_REJECT /* reservations that reach past the held columns (bholds) */, BC_NFLOOD = 8, BC_NFLAG = 10, BC_NCASC = 12, BC_NRUN = 30, BC_COUNT = 32 };
+enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_LIST_LOST, BC_RANGE_REJECT /* reservations that reach past the held columns (bholds) */, BC_CASC_CURSOR /* k_relax_cascade_flow */, BC_NFLOOD = 8, BC_NFLAG = 10, BC_NCASC = 12, BC_NRUN = 30, BC_COUNT = 32 };
 constexpr int R_MAXSTEPS = 8;                 // relaxed schedule: steps one wind particle may take per epoch (2 request entries each)
 
 struct BatchShared {
@@ -112,6 +112,7 @@ struct BatchShared {
   uint32_t* rcount;                           // [slots] entries this slot queued in this epoch
   uint32_t* rhead;                            // [cells] newest entry queued for the cell (NIL: none)
   uint32_t* cflag;                            // [cells] tag of the last epoch that asked for Particle::cascade here
+  uint32_t* cstate;                           // [cells] device only (nullptr: unused): 2 * tag = the cell waits in this epoch's colour lists, 2 * tag + 1 = its cascade is done
   uint32_t* flist[2]; uint32_t* flagl[2]; uint32_t* clist[2];   // per epoch parity: flood list (slots), flagged cells, cascade lists [9 colours][clist_cap]
   uint32_t list_cap, flag_cap, clist_cap;
 };

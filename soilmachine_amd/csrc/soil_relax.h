@@ -115,6 +115,7 @@ SMX_D void relax_filter(Sim<P>& sim, const BatchShared& bs, uint32_t c, bool val
     const bool mine = need && col == q;
     const uint32_t k = relax_append(&bs.ctrl[BC_NCASC + 9u * par + q], mine);
     if (mine) { if (k < bs.clist_cap) bs.clist[par][(size_t)q * bs.clist_cap + k] = c; else SMX_A_ADD(&bs.ctrl[BC_LIST_LOST], 1u); }
+    if (mine && k < bs.clist_cap && bs.cstate) bs.cstate[c] = 2u * bs.rtag;       // (the colour lists as ONE dataflow launch: soilmx.hip k_relax_cascade_flow)
   }
 }
 

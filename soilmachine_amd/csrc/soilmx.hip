@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(64) k_relax_apply(DevState s, BatchShared bs, 
     const uint32_t par = (epoch + 1u) & 1u;
     bs.ctrl[BC_NFLOOD + par] = 0u; bs.ctrl[BC_NFLAG + par] = 0u; bs.ctrl[BC_NRUN + par] = 0u;
     for (uint32_t k = 0; k < 9u; k++) bs.ctrl[BC_NCASC + 9u * par + k] = 0u;
+    bs.ctrl[BC_CASC_CURSOR] = 0u;                            // (this epoch's cascade dataflow starts at its first listed cell)
   }
   if (i >= nlive) return;
   BatchPolicy pol(s, bs);
@@ -361,6 +362,51 @@ __global__ void __launch_bounds__(64) k_relax_cascade(DevState s, BatchShared bs
     nc += pol.a_casc; nt += pol.a_tr;
   }
   relax_commit_cascade_counters(s, nc, nt);
+}
+// The nine colour lists of an epoch as ONE launch (round 5): a DATAFLOW over the listed cells in colour order -- a wavefront takes the
+// next cell, waits until every listed cell of an earlier colour within two cells of it (3x3 blocks that overlap its own) is done, runs
+// Particle::cascade there (lane 0) and publishes it (bs.cstate). Same order between conflicting cells as nine launches with a barrier
+// each, so the same result -- without eight kernel boundaries of ~8 us in an epoch that lasts ~230 (2 300 epochs per tick: 19.8 % of it).
+__global__ void __launch_bounds__(64) k_relax_cascade_flow(DevState s, BatchShared bs, uint32_t epoch) {
+  const uint32_t par = epoch & 1u;
+  uint32_t cnt[9], total = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < 9u; q++) { uint32_t n = bs.ctrl[BC_NCASC + 9u * par + q]; if (n > bs.clist_cap) n = bs.clist_cap; cnt[q] = n; total += n; }
+  if (total == 0u) return;
+  SMX_LOAD_SOILS(sh)
+  __shared__ uint32_t s_i;
+  unsigned long long nc = 0, nt = 0;
+  const uint32_t pending = 2u * bs.rtag;
+  while (true) {
+    if (threadIdx.x == 0) s_i = atomicAdd(&bs.ctrl[BC_CASC_CURSOR], 1u);
+    __syncthreads();
+    uint32_t i = s_i;
+    __syncthreads();
+    if (i >= total) break;
+    if (threadIdx.x == 0) {
+      uint32_t q = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 9u; k++) { if (q == k && i >= cnt[k]) { i -= cnt[k]; q = k + 1u; } }
+      const uint32_t c = bs.clist[par][(size_t)q * bs.clist_cap + i];
+      const int x = (int)(c / (uint32_t)s.dimy), y = (int)(c - (uint32_t)x * (uint32_t)s.dimy);
+      const int xa = x - 2 < s.x_lo ? s.x_lo : x - 2, xb = x + 2 >= s.x_hi ? s.x_hi - 1 : x + 2;
+      const int ya = y - 2 < 0 ? 0 : y - 2, yb = y + 2 >= s.dimy ? s.dimy - 1 : y + 2;
+      for (int xx = xa; xx <= xb; xx++)
+        for (int yy = ya; yy <= yb; yy++) {
+          if ((uint32_t)((xx % 3) * 3 + (yy % 3)) >= q) continue;            // (only cells of an earlier colour; the cell itself has colour q)
+          uint32_t* f = &bs.cstate[(size_t)xx * (size_t)s.dimy + (size_t)yy];
+          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pending) __builtin_amdgcn_s_sleep(2);
+        }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      BatchPolicy pol(s, bs);
+      Sim<BatchPolicy> sim(s, sh, pol);
+      relax_cascade(sim, c);
+      sim.flush_counters(); pol.finish(s);
+      nc += pol.a_casc; nt += pol.a_tr;
+      __hip_atomic_store(&bs.cstate[c], pending + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (threadIdx.x == 0) { if (nc) atomicAdd(&s.ctr[C_CASCADE_CALLS], nc); if (nt) atomicAdd(&s.ctr[C_CASCADE_TRANSFERS], nt); }
 }
 // the floods of the relaxed schedule: batch_water_epoch over this epoch's list of ended particles; who is not done joins the next
 // list. The launch has a fixed number of wavefronts; the floods are spread over them as thinly as the list allows (a wavefront costs
@@ -920,7 +966,7 @@ struct smx_ctx {
   std::string err;
   size_t ncells = 0, nw0 = 0, nw1 = 0, nw2 = 0;
   size_t c_lo = 0, c_hi = 0, lcells = 0;   // cells HELD by this context: [c_lo, c_hi) = columns [x_lo, x_hi) (the whole map unless smx_create_strip)
-  Sec* cells_alloc = nullptr; uint8_t* flags_alloc = nullptr; uint32_t* rhead_alloc = nullptr; uint32_t* cflag_alloc = nullptr;   // unbiased allocations
+  Sec* cells_alloc = nullptr; uint8_t* flags_alloc = nullptr; uint32_t* rhead_alloc = nullptr; uint32_t* cflag_alloc = nullptr; uint32_t* cstate_alloc = nullptr;   // unbiased allocations
   bool partial() const { return lcells != ncells; }
   SoilP* d_soils = nullptr;
   int nsoils = 0;
@@ -1105,7 +1151,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_vtx1); hipFree(ctx->d_tsort); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(ctx->cstate_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_vtx1); hipFree(ctx->d_tsort); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1728,7 +1774,8 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
   if (ctx->cfg.engine == SMX_ENGINE_RELAXED && !bs.rhead) {   // per-cell request lists and cascade flags (8 B / cell), empty between epochs
     HIPCHK(hipMalloc(&ctx->rhead_alloc, ctx->lcells * 4)); HIPCHK(hipMalloc(&ctx->cflag_alloc, ctx->lcells * 4));
     HIPCHK(hipMemsetAsync(ctx->rhead_alloc, 0xFF, ctx->lcells * 4, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->cflag_alloc, 0, ctx->lcells * 4, ctx->stream));
-    bs.rhead = ctx->rhead_alloc - ctx->c_lo; bs.cflag = ctx->cflag_alloc - ctx->c_lo;   // (global cell index, held range only)
+    HIPCHK(hipMalloc(&ctx->cstate_alloc, ctx->lcells * 4)); HIPCHK(hipMemsetAsync(ctx->cstate_alloc, 0, ctx->lcells * 4, ctx->stream));
+    bs.rhead = ctx->rhead_alloc - ctx->c_lo; bs.cflag = ctx->cflag_alloc - ctx->c_lo; bs.cstate = ctx->cstate_alloc - ctx->c_lo;   // (global cell index, held range only)
   }
   if (ctx->draws_cap < 2u * nslots) {
     hipFree(ctx->d_draws); if (ctx->h_draws) hipHostFree(ctx->h_draws); ctx->d_draws = nullptr; ctx->h_draws = nullptr; ctx->draws_cap = 0;
@@ -1832,7 +1879,7 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     const bool tail = !wind && use_tail && nlive <= tail_at;
     chunk_epochs = strips ? B_CHUNK : (tail ? 64 : (first ? CHUNK : RCHUNK_KIDS));
     ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : std::max(2, ctx->relax_water_steps); ctx->bs.rsteps = wind ? ctx->relax_wind_steps : ctx->relax_water_steps;
-    if (ctx->relax_tag > 0xFFFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(ctx->cflag_alloc, 0, ctx->lcells * 4, st)); }   // (tags never repeat)
+    if (ctx->relax_tag > 0x7FFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(ctx->cflag_alloc, 0, ctx->lcells * 4, st)); HIPCHK(hipMemsetAsync(ctx->cstate_alloc, 0, ctx->lcells * 4, st)); }   // (tags never repeat; 2 * tag + 1 fits 32 bits)
     if (strips) HIPCHK(hipMemsetAsync(bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
     if (strips && !wind) {                                   // who waits for a flood on this device right now?
       if (nslots) hipLaunchKernelGGL(k_relax_rebuild_floods, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots, epoch & 1u);
@@ -1865,8 +1912,12 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
         hipLaunchKernelGGL(k_relax_apply, dim3(nb64), dim3(64), 0, st, ctx->d, bs, nlive, epoch);
         hipLaunchKernelGGL(k_relax_filter, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch);
         static const unsigned casc_blocks = [] { const char* e = getenv("SMX_RELAX_CASC_BLOCKS"); return e ? (unsigned)atoi(e) : 64u; }();
-        const unsigned ncc = std::min(ncb, std::max(1u, casc_blocks));
-        for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncc), dim3(64), 0, st, ctx->d, bs, epoch, col);
+        static const unsigned casc_flow = [] { const char* e = getenv("SMX_RELAX_CASC_FLOW"); return e ? (unsigned)atoi(e) : 1024u; }();   // 0: nine launches (round 4)
+        if (casc_flow && bs.cstate) hipLaunchKernelGGL(k_relax_cascade_flow, dim3(std::min(ncb, casc_flow)), dim3(64), 0, st, ctx->d, bs, epoch);
+        else {
+          const unsigned ncc = std::min(ncb, std::max(1u, casc_blocks));
+          for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncc), dim3(64), 0, st, ctx->d, bs, epoch, col);
+        }
         if (!wind) hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch);
       }
     }

@@ -447,7 +447,7 @@ static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) 
   b.bs.dirty = c->dirty.data(); b.bs.own_x0 = c->own_x0; b.bs.own_x1 = c->own_x1 < 0 ? s.dimx : c->own_x1;
   b.bs.freed = b.freed.data(); b.bs.freed_cap = (uint32_t)b.freed.size(); b.bs.ctrl = b.ctrl.data(); b.bs.draws = b.draws.data();
   b.bs.relaxed = g_relaxed ? 1 : 0;
-  b.bs.req = nullptr; b.bs.rnext = nullptr; b.bs.rcount = nullptr; b.bs.rhead = nullptr; b.bs.cflag = nullptr;
+  b.bs.req = nullptr; b.bs.rnext = nullptr; b.bs.rcount = nullptr; b.bs.rhead = nullptr; b.bs.cflag = nullptr; b.bs.cstate = nullptr;
   b.bs.flist[0] = b.bs.flist[1] = b.bs.clist[0] = b.bs.clist[1] = b.bs.flagl[0] = b.bs.flagl[1] = nullptr; b.bs.rstride = 2; b.bs.rsteps = 1; b.bs.rtag = 0;
   if (b.bs.relaxed) {
     const size_t ent = (size_t)(nslots ? nslots : 1) * 2 * R_MAXSTEPS;
