@@ -208,10 +208,12 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles);
  * depend on it. Default: min_running = 0xFFFFFFFF, i.e. wind always runs the exclusive schedule (measured faster, profiles/r03_relaxed.md);
  * 4 steps per epoch. */
 int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epoch);
-/* throughput engines: smx_tick_water(n) runs its n particles as k consecutive top-level generations of n/k (default 1). The particles of one
- * generation advance together; in the reference particle i sees what particles < i of the same tick did (SoilMachine.cpp:287-298). k > 1 gives
- * some of that feedback back at the price of k epoch chains: at 2048^2 the nested-particle count moves from -3.5 to +0.1 sigma of the
- * reference's own rand()-stream spread at k = 4, for 1.5 x the device time (profiles/r04_p2_analysis.md). Identical to k calls of n/k. */
+/* throughput engines: smx_tick_water(n) (and smx_strips_tick) run the n particles as k consecutive top-level generations of n/k. DEFAULT 4
+ * since round 5 (rounds 3-4: 1). The particles of one generation advance together and do not see the lakes their own generation makes; in the
+ * reference particle i sees what particles < i of the same tick did (SoilMachine.cpp:287-298), and every wet cell stops the particles that
+ * reach it (water.h:56 with soils["Air"].friction = 0). k generations give a particle (k-1)/k of that view for k epoch chains: at the
+ * headline workload k = 1 is outside the reference's own spread by up to 11 sigma, k = 4 within 3.3 (profiles/r05_p2_analysis.md).
+ * Identical to k calls of n/k with k = 1. */
 int smx_set_water_generations(smx_ctx* ctx, int32_t k);
 /* batched engine: column strips (DESIGN.md "Multi-GPU"). The schedule alternates INTERIOR chunks (a particle acts iff its
  * reservation lies `inset` cells inside one of `nstrips` equal x-strips) and SEAM chunks (iff inside one seam zone of

@@ -663,9 +663,9 @@ struct so_ctx {
   //     holds every tile of its reservation, and may go on (<= maxsteps actions) while the next action stays
   //     inside the tiles it holds; (dilate, maxsteps) follow from the number of running particles at the start
   //     of every 32-epoch chunk (b_schedule);
-  //   * nested particles are deferred: children sorted by (parent slot << 8 | sequence) form the next generation
-  //     and take the rand() draws after the current generation's;
-  //   * grid pass: 9 colour passes over tiles (tx mod 3, ty mod 3), cells of a tile x-major, active set fixed at
+  //   * nested particles run at once inside the tiles their parent owns (b_nested); one that leaves them is suspended as it stands: the
+  //     records sorted by (parent slot << 8 | sequence) form the next generation (no rand() draws: a record carries its state);
+  //   * grid pass: 8x8-cell tiles colour by colour (tx mod 3, ty mod 3), cells of a tile x-major, active set fixed at
   //     the start of the pass.
   // Acting order inside an epoch is irrelevant by construction (winners own disjoint tiles); this
   // restatement walks slots in ascending order.

@@ -15,7 +15,8 @@
 //   filter  (relax_filter)   the flagged cells that can move anything at all (the conservative test Particle::cascade starts with,
 //           on the map after the epoch's edits) enter the cascade list of their colour (x mod 3, y mod 3) -- except the isolated ones
 //           (no other flagged cell within two cells), which cascade at once: same result, eight launches' worth of latency less;
-//   cascade (relax_cascade)  the listed cells, ONCE each, with the reference's Particle::cascade(.., 0) -- in nine colour passes
+//   cascade (relax_cascade)  the listed cells, ONCE each, with the reference's Particle::cascade(.., 0) -- in colour order (nine passes; on the
+//           device one dataflow launch that keeps that order between cells whose blocks overlap: soilmx.hip k_relax_cascade_flow)
 //           (the cascades of one pass touch disjoint 3x3 blocks, so they commute).
 //   floods  water.h:123-145 reach 4 cells and spawn nested particles: they stay behind claim tiles (batch_water_epoch, run over the
 //           epoch's list of ended particles), nested particles form the next generation as before.

@@ -869,7 +869,7 @@ void hs_d_unpack_particles(hs_ctx* c, const uint8_t* buf, uint64_t bytes) {
     memcpy(d.wind ? (void*)&d.b.wind[i] : (void*)&d.b.water[i], buf + 8 + k * (4 + rs), rs);
   }
 }
-// grid pass, strip by strip: classification, then one sweep (9 colours) over the tiles tx in [tx_lo, tx_hi) that belong to `phase`
+// grid pass, strip by strip: classification, then one sweep (9 colours) over the 8x8 tiles of the columns [x_lo, x_hi) that belong to `phase`
 void hs_d_grid_begin(hs_ctx* c) {
   const DevState& s = c->d; const size_t n = c->n;
   std::fill(c->a0.begin(), c->a0.end(), 0);
