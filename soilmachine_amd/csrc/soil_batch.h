@@ -212,6 +212,7 @@ SMX_D bool bholds(const BatchShared& bs, int plane, const BRect& r, unsigned lon
 struct BatchPolicy {
   static constexpr bool READ_ONLY = false;
   static constexpr bool DEFER_NESTED = true;
+  static constexpr bool EXCLUSIVE = true;       // this thread owns every cell it touches while it acts (soil_core.h push_frame)
   const BatchShared& bs;
   unsigned long long live0;                   // live sections when the kernel started (+ what this thread added)
   long long live_delta = 0;

@@ -141,7 +141,7 @@ struct Blk {
 
 // One suspended WaterParticle::cascade invocation (water.h:151-283): centre, remaining spill budget,
 // the sorted neighbour list and the loop index.
-struct Frame { int ix, iy, spill, num, i; uint32_t codes; };
+struct Frame { int ix, iy, spill, num, i; uint32_t codes, cand, stamp; };   // cand / stamp: see Sim::push_frame
 constexpr int MAX_FRAMES = 24;
 
 // The wind step's one level of cascade recursion (particle.h:96-97), OUT of line and BY VALUE for policies that ask
@@ -154,6 +154,9 @@ template <class P> struct RecRes { P pol; Blk b; bool ab, moved; };
 #define SMX_NOINLINE __device__ __attribute__((noinline))
 #endif
 template <class P> SMX_NOINLINE RecRes<P> wind_recurse(DevState s, const SoilP* soils, P pol, float cx, float cy, int ix, int iy);
+// policies whose thread owns every cell it touches for as long as it acts (serial walker, batched / relaxed engines): nothing changes under it
+template <class P, class = void> struct exclusive_access { static constexpr bool value = false; };
+template <class P> struct exclusive_access<P, decltype((void)P::EXCLUSIVE)> { static constexpr bool value = P::EXCLUSIVE; };
 template <class P, class = void> struct outline_recursion { static constexpr bool value = false; };
 template <class P> struct outline_recursion<P, decltype((void)P::OUTLINE_RECURSION)> { static constexpr bool value = P::OUTLINE_RECURSION; };
 
@@ -166,6 +169,7 @@ struct Sim {
   bool ab = false;         // speculative execution only: this particle has been aborted
   bool susp_ok = false;    // speculative execution only: the main loop of this particle may be suspended ...
   int susp = 0;            // ... and has been (2 = before interact()'s block load; the block is checkpointed)
+  uint32_t n_mod = 0;      // writes of (size, floor, type) this Sim has made to the map so far (push_frame's candidate mask is valid while it stands still)
   // counters live in registers and are flushed once per kernel
   unsigned long long n_steps_w_top = 0, n_steps_w_all = 0, n_steps_wind = 0, n_nested = 0, n_floods = 0,
                      n_casc = 0, n_casc_tr = 0, n_wcasc = 0, n_overflow = 0;
@@ -375,6 +379,7 @@ struct Sim {
 
   // ---------------- mutation primitives ----------------
   SMX_D void pop_top(Sec& c) {                              // dat = E->prev; pool.unget(E)
+    n_mod++;
     const uint32_t pv = c.prev;
     if (pv == NIL) {
       c.size = 0.0; c.floor = 0.0; c.sat = 0.0; c.type = EMPTY; c.prev = NIL;
@@ -387,6 +392,7 @@ struct Sim {
   // the tail of Layermap::add once the incoming section is known to be kept apart from a water top:
   // empty column -> place (:243-246); same type -> elongate (:249-253); else push (:302-305)
   SMX_D void place(int x, int y, Sec& c, double size, uint32_t type, double sat) {
+    n_mod++;
     if (c.type == EMPTY) {
       c.size = size; c.floor = 0.0; c.sat = sat; c.type = type; c.prev = NIL;
     } else if (c.type == type) {
@@ -416,6 +422,7 @@ struct Sim {
     pol.live_add(s, +1);
     if (size <= 0) { pol.live_add(s, -1); return; }         // :237-240 unget(E)
     if (c.type != EMPTY && c.type != type && c.type == AIR) {   // :258-275 water stays on top
+      n_mod++;
       const double wsize = c.size, wsat = c.sat;
       const uint32_t pv = c.prev;                           // dat = top->prev (the water section is kept aside)
       if (pv == NIL) { c.size = 0.0; c.floor = 0.0; c.sat = 0.0; c.type = EMPTY; c.prev = NIL; }
@@ -438,7 +445,7 @@ struct Sim {
     if (c.size <= 0.0) { pop_top(c); sync_air_flag(x, y, c.type); if (popped) *popped = true; return 0.0; }
     if (h <= 0.0) return 0.0;
     const double diff = h - c.size;
-    c.size -= h;
+    c.size -= h; n_mod++;
     if (diff >= 0.0) { pop_top(c); sync_air_flag(x, y, c.type); if (popped) *popped = true; return diff; }
     return 0.0;
   }
@@ -454,7 +461,7 @@ struct Sim {
       if (h <= 0.0) return 0.0;                             // layermap.h:325
       if (h < v.size) {                                     // :328-337 with diff < 0: shrink, nothing pops
         v.size -= h;
-        s.cells[c].size = v.size;
+        s.cells[c].size = v.size; n_mod++;
         return 0.0;
       }
     }
@@ -468,7 +475,7 @@ struct Sim {
     if (size <= 0) { if (!pol.can_get(s)) n_overflow++; return; }   // pool.get + unget of an empty section (layermap.h:237-240)
     if (v.type == type && v.type != EMPTY && size > 0 && pol.can_get(s)) {   // layermap.h:249-253 elongate (pool.get + unget: net 0)
       v.size += size;
-      s.cells[c].size = v.size;
+      s.cells[c].size = v.size; n_mod++;
       return;
     }
     add(x, y, size, type, true);
@@ -866,10 +873,27 @@ struct Sim {
   }
   SMX_D void push_frame(Frame* st, int& depth, int ix, int iy, int spill) {   // entry of WaterParticle::cascade
     n_wcasc++;
-    const Sorted sn = sorted_neighbours(ix, iy);
+    size_t cc[9]; bool inb[8]; View v[9];
+    block3x3(ix, iy, cc, inb, v);
+    double h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = inb[k] ? vh(v[k]) : -INFINITY;   // particle.h:43-60 == water.h:168-185
+    // Which neighbours can the loop of water.h:187-281 do anything with, on the map as it is NOW? It skips a neighbour whose water table equals
+    // the centre's (:216-218), whose higher column has no water on top (:229-230) or no water left (:240-241). While this Sim has not written
+    // the map since (n_mod stands still -- and nobody else can: exclusive policies only), water_drive skips those neighbours without loading them
+    // again: the same `continue`, two dependent memory round trips less per neighbour (a lake cell runs ~40 of them).
+    uint32_t cand = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (!inb[k]) continue;
+      const double diff = (v[8].floor + v[8].size - v[k].floor - v[k].size) * (double)s.scale / 80.0;   // the expression of water_drive, operand by operand
+      const View& T = diff > 0 ? v[8] : v[k];
+      if (diff != 0 && T.type == AIR && T.size > 0) cand |= 1u << k;
+    }
+    const Sorted sn = sort8(h);
     if (depth >= MAX_FRAMES) { n_overflow++; return; }      // unreachable: depth is bounded by the spill budget
     Frame& f = st[depth++];
-    f.ix = ix; f.iy = iy; f.spill = spill; f.num = sn.num; f.i = 0; f.codes = sn.codes;
+    f.ix = ix; f.iy = iy; f.spill = spill; f.num = sn.num; f.i = 0; f.codes = sn.codes; f.cand = cand; f.stamp = n_mod;
   }
   // WaterParticle::move (water.h:43-73) on the carried block `cur` around ipos. false = move() returned false.
   // PURE: the batched engine's look-ahead -- where would this move go? No track write, no counters.
@@ -1126,6 +1150,7 @@ struct Sim {
       if (f.i >= f.num) { depth--; continue; }
       const int k = (f.codes >> (4 * f.i)) & 15;
       f.i++;
+      if constexpr (exclusive_access<P>::value) { if (f.stamp == n_mod && !((f.cand >> k) & 1u)) continue; }   // (push_frame: nothing to do there, decided on registers)
       const int ix = f.ix, iy = f.iy;
       const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
       const Sec& A = cell(ix, iy);

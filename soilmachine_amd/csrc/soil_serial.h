@@ -7,6 +7,7 @@ namespace smx {
 struct SerialPolicy {
   static constexpr bool READ_ONLY = false;
   static constexpr bool DEFER_NESTED = false;
+  static constexpr bool EXCLUSIVE = true;       // this thread owns every cell it touches while it acts (soil_core.h push_frame)
   unsigned long long live;       // live sections, cached in a register for the kernel's lifetime
   uint32_t nfree;                // entries on the free-node stack
   SMX_D explicit SerialPolicy(const DevState& s) : live(s.ctr[C_LIVE_SECTIONS]), nfree(*s.free_count) {}
