@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- particle-steps/s and ms/tick of the SoilMachine particle-transport hot path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0 -- the LAST line of stdout, compact
+(~4 KB: compact_line below); the detailed record (per-tick entries, extra lines, parity blocks, LBM) goes to a side file
+(gpurun_out/bench_detail_n<N>.json, named on the line).
   * a "step" of the bench = one tick of SoilMachine.cpp:283-329 (water particles -> grid pass -> wind particles ->
     frequency update) over the synthetic 4096^2 layermap of BASELINE.json configs[3]
     (soil/rockgravelpebblessand.soil: 4 soils, 2 noise layers, SCALE 120, SEED 0); terrain comes from
@@ -9,16 +11,18 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
   * value = particle-steps/s, whole job: a particle-step is one WaterParticle/WindParticle move()==true followed by its
     interact(), top-level AND nested particles. The unmodified reference can only count top-level steps,
     so the CPU baseline is top-level steps/s and the GPU line carries `value_top_level` next to `value` for that ratio.
-  * headline line: the RELAXED schedule of the batched engine (SMX_ENGINE_RELAXED, csrc/soil_relax.h) with AREA-SCALED particle counts
-    (NWATER = 250*(N/256)^2 = 64 000, NWIND = 16 000 at 4096^2). Deterministic, but NOT the reference's particle order:
-    parity tier P2 (statistical) -- `parity_vs_exact` measures it on the device against the exact engine and against the exact engine's
-    own rand()-stream spread. The EXACT engine (bit-identical to the reference, the parity anchor) is reported under "lines" at the soil
+  * headline line: the RELAXED schedule of the batched engine (SMX_ENGINE_RELAXED, csrc/soil_relax.h) in its DEFAULT configuration (four
+    water generations, nested particles inside their parents, 8x8 grid tiles: the one measured against the reference) with
+    AREA-SCALED particle counts (NWATER = 250*(N/256)^2 = 64 000, NWIND = 16 000 at 4096^2). Deterministic, but NOT the
+    reference's particle order: parity tier P2 (statistical) -- `parity_vs_reference` measures it in the run against the reference itself
+    (1024^2), profiles/r05_p2_reference_4096.json at the headline's size; `parity_vs_exact` against the exact engine on the device. The EXACT engine (bit-identical to the reference, the parity anchor) is reported under "lines" at the soil
     file's own counts and under config.bit_exact_on_this_workload for the headline's counts, next to the batched schedule of round 2 and
     the 1024^2 default.soil lines of BASELINE configs[1] and [2].
   * every line carries the state digest after its timed region (section count, type hash, sum of heights, rand() draws).
   * "roofline": algorithmic bytes of the dominant kernel / its HIP-event duration (events on the library's own stream,
     bracketing nothing but launches of that kernel) vs the 8 TB/s HBM peak; "phases" gives the same for the O(cells)
-    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r04_pmc.json), labelled as such.
+    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r04_pmc.json: the wind kernel is unchanged since), labelled as such.
+    achieved = bytes of ALL launches / ALL launches / the average duration of the bracketed launches (kernel_roofline).
   * "cpu_baseline": the reference's own CPU loop (oracle/_ref/soil_ref_lean = the unmodified reference headers,
     render-only Layermap::update elided) timed on this box's host on THE SAME tick the timed window starts with: the state after the
     warm-up is checkpointed (smx_save, outside the timed region) and the reference continues it (ref_driver --load) at the same counts,
@@ -471,7 +475,7 @@ def main():
         strips4 = {"name": f"configs4_8192_rockgravelpebbles_big_{world}_strips", "engine": eng_name, "scaling": "strong",
                    "workload": f"8192x8192, soil/rockgravelpebbles_big.soil, area-scaled NWATER={nw4} / NWIND=0, ONE map in {world} column strips of {n4 // world}x{n4} (BASELINE configs[4])",
                    "value": s4 / t4, "unit": "particle-steps/s", "ms_per_tick": 1e3 * t4 / 2, "steps": 2, "warmup": 1, "n_gpus": world,
-                   "engine_stats_rank0": r4["engine_stats"], "single_gpu_reference": "lines[configs4_8192_rockgravelpebbles_big_relaxed] of the N=1 run (profiles/r03_bench.json: 356 M steps/s, 316 ms/tick)"}
+                   "engine_stats_rank0": r4["engine_stats"], "single_gpu_reference": "lines[configs4_8192_rockgravelpebbles_big_relaxed] of the N=1 run (profiles/r05_bench_detail.json: 144 M steps/s, 740 ms/tick with the round-5 schedule)"}
 
     if rank == 0:
         tm = r["tm"]
@@ -577,12 +581,12 @@ def main():
                 except Exception as e:
                     parity = {"error": str(e)}
                 # ... and against THE REFERENCE (oracle/_ref/soil_ref_lean on this box's host cores), eight control streams, z-scores: 1024^2 at the
-                # headline's particle density, ticks 1-10 (~25 s; the record at the headline's own size and counts: profiles/r04_p2_reference_4096.json)
+                # headline's particle density, ticks 1-10 (~25 s; the record at the headline's own size and counts: profiles/r05_p2_reference_4096.json)
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
                     import p2_reference
                     pref = p2_reference.run(soil, 1024, 10, 8, eng_name, device=local_rank, verbose=False)
-                    pref["headline_size_record"] = "profiles/r04_p2_reference_4096.json (tools/p2_reference.py --size 4096 --ticks 10 --nctl 16 on the MI355X box)"
+                    pref["headline_size_record"] = "profiles/r05_p2_reference_4096.json (tools/p2_reference.py --size 4096 --ticks 10 --nctl 16 on the MI355X box: 5 of 8 figures inside |z| < 2, none beyond 3.3)"
                 except Exception as e:
                     pref = {"error": str(e)}
         if args.only is not None:
