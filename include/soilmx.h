@@ -96,6 +96,12 @@ typedef struct smx_timing {
    * launches_kernel_water is then the average duration over the bracketed launches, and the algorithmic bytes per launch are the
    * steps of ALL launches over launches_step_water (bench.py). */
   uint64_t launches_step_water, launches_step_wind;
+  /* round 6 (smx_get_timing_sized only): the relaxed water phase's persistent launches, each between its own pair of HIP events --
+   * k_relax_epochs (the dense epochs of a generation: step, apply, filter, colour lists and floods behind device-wide barriers) and
+   * k_relax_tail (the same phases inside one workgroup once <= 256 particles run): milliseconds, launches, epochs the launches covered;
+   * and the generations of suspended nested particles the grid pass leaves behind (part of ms_grid) */
+  double ms_kernel_epochs, ms_kernel_tail, ms_kernel_grid_children;
+  uint64_t launches_kernel_epochs, epochs_kernel_epochs, launches_kernel_tail, epochs_kernel_tail, launches_kernel_grid_children;
 } smx_timing;
 
 /* ---- life cycle: replaces Layermap::Layermap + secpool::reserve (layermap.h:64-119,218-226) ---- */
@@ -208,13 +214,24 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles);
  * depend on it. Default: min_running = 0xFFFFFFFF, i.e. wind always runs the exclusive schedule (measured faster, profiles/r03_relaxed.md);
  * 4 steps per epoch. */
 int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epoch);
-/* throughput engines: smx_tick_water(n) (and smx_strips_tick) run the n particles as k consecutive top-level generations of n/k. DEFAULT 4
- * since round 5 (rounds 3-4: 1). The particles of one generation advance together and do not see the lakes their own generation makes; in the
- * reference particle i sees what particles < i of the same tick did (SoilMachine.cpp:287-298), and every wet cell stops the particles that
- * reach it (water.h:56 with soils["Air"].friction = 0). k generations give a particle (k-1)/k of that view for k epoch chains: at the
- * headline workload k = 1 is outside the reference's own spread by up to 11 sigma, k = 4 within 3.3 (profiles/r05_p2_analysis.md).
- * Identical to k calls of n/k with k = 1. */
+/* relaxed schedule, water phase: the LAUNCH SHAPE of its epochs -- never the result (tests/test_gpu_relaxed.py runs every shape against the
+ * same host-thread states). persistent: 0 = five launches per epoch (step, apply, filter, colour lists, floods: the default), 1 = the dense
+ * epochs of a chunk as one cooperative launch with device-wide barriers (k_relax_epochs, round 6: measured 15-45 % slower on the headline,
+ * profiles/r06_persistent_epochs.md); tail_at: from this many running particles down one workgroup runs whole epochs back to back
+ * (k_relax_tail; 0..256, default 256). -1 = leave as is / back to the default. */
+int smx_set_relax_launch(smx_ctx* ctx, int32_t persistent, int32_t tail_at);
+/* REMOVED in round 5 (nested particles run inside their parent since then; there is nothing to interleave): kept as a symbol that fails
+ * loudly (-2, smx_last_error says so) so that a round-4 caller neither crashes at load time nor silently runs another schedule. */
+int smx_set_grid_interleave(smx_ctx* ctx, int32_t k);
+/* throughput engines: smx_tick_water(n) (and smx_strips_tick) run the n particles as k consecutive top-level generations of n/k. DEFAULT 8
+ * since round 6 (round 5: 4; rounds 3-4: 1). The particles of one generation advance together and do not see the lakes their own generation
+ * makes; in the reference particle i sees what particles < i of the same tick did (SoilMachine.cpp:287-298), and every wet cell stops the
+ * particles that reach it (water.h:56 with soils["Air"].friction = 0). k generations give a particle (k-1)/k of that view for k epoch chains.
+ * At the headline workload, against 33 rand() streams of the reference itself (profiles/r06_p2_reference_4096.json): k = 1 is outside by up
+ * to 7.9 sigma, k = 4 outside on three of eight figures (2.3-3.0 sigma), k = 8 inside |z| < 2 on all eight. Callers of round 5 see a
+ * behaviour and a cost change (the water phase ~1.3 x) unless they call smx_set_water_generations(4). Identical to k calls of n/k with k = 1. */
 int smx_set_water_generations(smx_ctx* ctx, int32_t k);
+int smx_get_water_generations(smx_ctx* ctx, int32_t* k);   /* the value in force (bench.py reports it instead of a literal) */
 /* batched engine: column strips (DESIGN.md "Multi-GPU"). The schedule alternates INTERIOR chunks (a particle acts iff its
  * reservation lies `inset` cells inside one of `nstrips` equal x-strips) and SEAM chunks (iff inside one seam zone of
  * +-seam_halfwidth cells around a strip boundary). nstrips == 1 (default) = the single-strip schedule. The result is a
@@ -242,7 +259,9 @@ int smx_d_unpack_columns(smx_ctx* ctx, const void* buf, uint64_t bytes);
 int smx_d_pack_particles(smx_ctx* ctx, int32_t x0, int32_t x1, void* buf, uint64_t cap, uint64_t* bytes);
 int smx_d_unpack_particles(smx_ctx* ctx, const void* buf, uint64_t bytes);
 int smx_d_grid_begin(smx_ctx* ctx);                                            /* classification of the grid pass       */
-int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t x_lo, int32_t x_hi);   /* the grid tiles of the COLUMNS [x_lo, x_hi) that belong to `phase`, colour by colour */
+/* (rounds 2-4 exported `smx_d_grid_sweep` over 4x4-TILE indices; the arguments are CELL columns since round 5, so the
+ *  entry point carries a new name: a caller of the old one fails to link instead of sweeping the wrong range) */
+int smx_d_grid_sweep_cols(smx_ctx* ctx, int32_t phase, int32_t x_lo, int32_t x_hi);   /* the grid tiles of the COLUMNS [x_lo, x_hi) that belong to `phase`, colour by colour */
 /* ---- column strips driven INSIDE the library (csrc/soil_strips_host.h): the tick of SoilMachine.cpp:283-329 on this rank's strip of ONE
  * map; halo columns and migrating particles go from the pack kernel to the unpack kernel of the neighbour without leaving device memory.
  *   smx_strips_attach_rccl   transport = RCCL (ncclSend / ncclRecv / ncclAllReduce / ncclAllGather over xGMI) on this context's stream;

@@ -938,7 +938,7 @@ struct so_ctx {
   //            the waiting particles, every epoch is a flood epoch (the rule above counts one device's particles: not partition-invariant).
   // =====================================================================================================
   bool b_relaxed = false;
-  int b_water_generations = 4;                                // so_set_water_generations (smx_set_water_generations; the engine's default)
+  int b_water_generations = 8;                                // so_set_water_generations (smx_set_water_generations; the engine's default)
   struct RReq { int x, y; double vol, amount; uint32_t type; int kind; int cx, cy; };   // kind 1: erode, 2: deposit
   uint32_t r_surf(int x, int y) const { const uint32_t t = top[cidx(x, y)]; return t == NIL ? 0u : type[t]; }
   bool r_precheck(int x, int y) const {

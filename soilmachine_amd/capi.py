@@ -57,7 +57,10 @@ class Timing(C.Structure):
                 ("ms_kernel_classify", C.c_double), ("ms_kernel_gridtiles", C.c_double), ("ms_kernel_mapfreq", C.c_double),
                 ("launches_kernel_classify", C.c_uint64), ("launches_kernel_gridtiles", C.c_uint64),
                 ("launches_kernel_mapfreq", C.c_uint64),
-                ("launches_step_water", C.c_uint64), ("launches_step_wind", C.c_uint64)]
+                ("launches_step_water", C.c_uint64), ("launches_step_wind", C.c_uint64),
+                ("ms_kernel_epochs", C.c_double), ("ms_kernel_tail", C.c_double), ("ms_kernel_grid_children", C.c_double),
+                ("launches_kernel_epochs", C.c_uint64), ("epochs_kernel_epochs", C.c_uint64), ("launches_kernel_tail", C.c_uint64),
+                ("epochs_kernel_tail", C.c_uint64), ("launches_kernel_grid_children", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -70,9 +73,9 @@ SYMBOLS = [
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
     "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices", "smx_fill_vertices_cut", "smx_fill_vertex_cut",
-    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_get_counters_sized", "smx_get_timing_sized", "smx_timing_reset", "smx_set_engine", "smx_set_spec_limits", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind", "smx_set_water_generations", "smx_strips_rccl_unique_id", "smx_strips_attach_rccl", "smx_strips_attach", "smx_strips_detach", "smx_strips_tick", "smx_strips_stats",
+    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_get_counters_sized", "smx_get_timing_sized", "smx_timing_reset", "smx_set_engine", "smx_set_spec_limits", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind", "smx_set_relax_launch", "smx_set_grid_interleave", "smx_set_water_generations", "smx_get_water_generations", "smx_strips_rccl_unique_id", "smx_strips_attach_rccl", "smx_strips_attach", "smx_strips_detach", "smx_strips_tick", "smx_strips_stats",
     "smx_d_set_own", "smx_d_gen_begin", "smx_d_gen_spawn", "smx_d_next_phase", "smx_d_chunk", "smx_d_gen_end", "smx_d_pack_columns",
-    "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep",
+    "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep_cols",
     "smx_lbm_create", "smx_lbm_destroy", "smx_lbm_last_error", "smx_lbm_set_boundary", "smx_lbm_boundary_from_map", "smx_lbm_initialize",
     "smx_lbm_step", "smx_lbm_read", "smx_lbm_write_f", "smx_lbm_move", "smx_lbm_get_timing",
 ]
@@ -136,10 +139,12 @@ def load() -> C.CDLL:
     L.smx_timing_reset.argtypes = [vp]
     L.smx_set_engine.argtypes = [vp, i32]
     L.smx_set_water_generations.argtypes = [vp, i32]
+    L.smx_get_water_generations.argtypes = [vp, C.POINTER(i32)]
     L.smx_set_spec_limits.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.smx_set_batch_dilate.argtypes = [vp, i32]
     L.smx_set_batch_strips.argtypes = [vp, i32, i32, i32]
     L.smx_set_relax_wind.argtypes = [vp, u32, i32]
+    L.smx_set_relax_launch.argtypes = [vp, i32, i32]
     L.smx_create_strip.argtypes = [C.POINTER(Config), i32, i32, C.POINTER(vp)]
     L.smx_strips_rccl_unique_id.argtypes = [vp]
     L.smx_strips_attach_rccl.argtypes = [vp, vp, i32, i32, i32, i32]
@@ -158,7 +163,7 @@ def load() -> C.CDLL:
     L.smx_d_pack_particles.argtypes = [vp, i32, i32, vp, u64, C.POINTER(u64)]
     L.smx_d_unpack_particles.argtypes = [vp, vp, u64]
     L.smx_d_grid_begin.argtypes = [vp]
-    L.smx_d_grid_sweep.argtypes = [vp, i32, i32, i32]
+    L.smx_d_grid_sweep_cols.argtypes = [vp, i32, i32, i32]
     L.smx_get_batch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.smx_lbm_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
     L.smx_lbm_destroy.argtypes = [vp]; L.smx_lbm_destroy.restype = None

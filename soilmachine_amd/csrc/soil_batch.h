@@ -43,10 +43,12 @@ constexpr int GRID_SHIFT = 3;                 // the grid pass works on 8x8-cell
 constexpr int DIRTY_SHIFT = 2;                // column strips: the halo exchange tracks changes in 4x4-cell tiles (bs.dirty)
 constexpr uint32_t B_RUN = 0, B_ENDED = 1, B_DONE = 2, B_NEW = 3;   // B_NEW: top-level particle that has not acted yet
 constexpr uint32_t B_AWAY = 4;               // column strips on several devices: the particle currently lives on another device
-constexpr int SMX_WATER_GENERATIONS = 4;      // a tick's water particles run as this many consecutive top-level generations of n/k (smx_set_water_generations): the particles of
+constexpr int SMX_WATER_GENERATIONS = 8;      // a tick's water particles run as this many consecutive top-level generations of n/k (smx_set_water_generations): the particles of
                                               // one generation advance together and do not see the lakes their own generation makes -- in the reference particle i sees what
-                                              // every particle < i did (SoilMachine.cpp:287-298). One generation loses 20 % of the nested particles and doubles the standing
-                                              // water while lakes are seeded; four are inside the reference's own spread (profiles/r05_p2_*.json)
+                                              // every particle < i did (SoilMachine.cpp:287-298). Measured against 33 streams of the reference itself at the headline workload
+                                              // (4096^2, 64 000 + 16 000, profiles/r06_p2_reference_4096.json): one generation is outside on four of eight figures by 4.8-7.9
+                                              // sigma, four (round 5's default) on three by 2.3-3.0 (nested particles -23 %), EIGHT inside |z| < 2 on all eight, also under the
+                                              // two-strip schedule and two of three other device streams; sixteen: water volume +2.1
 constexpr int B_CHUNK = 32;                   // epochs between two looks at the number of running particles (schedule, compaction)
 constexpr int B_MAXCHILD = 250;               // nested particles one flood / one grid tile may emit per pass (the key keeps 8 bits for the sequence). Round 5: 24 -> 250:
                                               // a 4x4 tile of lake cells spawns more than 24 (every sweep position can send off its own film and those of its eight
@@ -85,7 +87,7 @@ constexpr int STRIP_INTERIOR = 0, STRIP_SEAM = 1;
 // relaxed schedule, per epoch parity p = epoch & 1: BC_NFLOOD + p = length of the flood list, BC_NFLAG + p = cells flagged for a cascade,
 // BC_NCASC + 9 * p + colour = length of a colour's cascade list
 // BC_NRUN + p = particles that stepped in the epoch
-enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_LIST_LOST, BC_RANGE_REJECT /* reservations that reach past the held columns (bholds) */, BC_CASC_CURSOR /* k_relax_cascade_flow */, BC_NFLOOD = 8, BC_NFLAG = 10, BC_NCASC = 12, BC_NRUN = 30, BC_COUNT = 32 };
+enum BCtrl { BC_NLIVE = 0, BC_NCHILD, BC_CHILD_LOST, BC_NFREED, BC_FREED_LOST, BC_LIST_LOST, BC_RANGE_REJECT /* reservations that reach past the held columns (bholds) */, BC_CASC_CURSOR /* k_relax_cascade_flow */, BC_NFLOOD = 8, BC_NFLAG = 10, BC_NCASC = 12, BC_NRUN = 30, BC_LISTS_END = 32 /* [BC_NFLOOD, BC_LISTS_END): the per-epoch list lengths */, BC_STALLED = 32 /* k_relax_epochs: a device-wide barrier or a dataflow wait ran out of its spin budget */, BC_COUNT = 40 };
 constexpr int R_MAXSTEPS = 8;                 // relaxed schedule: steps one wind particle may take per epoch (2 request entries each)
 
 struct BatchShared {

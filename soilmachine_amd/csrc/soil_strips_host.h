@@ -334,10 +334,10 @@ static int st_phase(smx_ctx* ctx, StripState& S, bool wind, uint32_t n, std::vec
 static int st_grid(smx_ctx* ctx, StripState& S) {
   const int r = S.T->rank, n = S.geo.n;
   if (smx_d_grid_begin(ctx)) return -1;
-  if (smx_d_grid_sweep(ctx, STRIP_INTERIOR, S.x0, S.x1)) return -1;
+  if (smx_d_grid_sweep_cols(ctx, STRIP_INTERIOR, S.x0, S.x1)) return -1;
   if (n > 1) {
     if (st_band_to_left(ctx, S, false)) return -1;
-    if (r < n - 1 && smx_d_grid_sweep(ctx, STRIP_SEAM, S.x1 - S.geo.b, S.x1 + S.geo.b)) return -1;
+    if (r < n - 1 && smx_d_grid_sweep_cols(ctx, STRIP_SEAM, S.x1 - S.geo.b, S.x1 + S.geo.b)) return -1;
     if (st_band_to_right(ctx, S, false)) return -1;
   }
   std::vector<BChild> kids;

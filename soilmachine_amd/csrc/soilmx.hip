@@ -525,6 +525,194 @@ __global__ void __launch_bounds__(256) k_relax_tail(DevState s, BatchShared bs, 
     __syncthreads();
   }
 }
+// The DENSE epochs of a relaxed water generation as ONE persistent launch (round 6; OFF by default -- smx_set_relax_launch(1, ..) /
+// SMX_RELAX_MEGA=1 turn it on): the same five phases in the same order -- step, apply, filter (isolated cells cascade there), the colour
+// lists as a dataflow, floods -- run by a grid of co-resident workgroups (hipLaunchCooperativeKernel) with a device-wide barrier where the
+// per-phase launches have kernel boundaries; phases whose list is empty are skipped together with their barrier (the count is read by
+// everybody after a barrier, so the decision is uniform). Which lane runs a slot / a cell has no influence on any result (soil_relax.h): the
+// state after the launch is the one the per-phase launches leave, bit for bit (tests/test_gpu_relaxed.py runs every launch shape against the
+// same host-thread states and against the restatement).
+// MEASURED, and why it is not the default (profiles/r06_persistent_epochs.md): the idea was that 5 launches per epoch x 4 352 dense epochs per
+// tick are launch-bound. They are not. The barrier itself is cheap -- 6-7 us for 256 workgroups with thread 0 fencing, 2.4 us for 64
+// (tools/barrier_bench.hip; no fence: stale reads, counted) -- but an epoch inside this kernel takes 183 us against 143 us as five launches
+// (headline workload, k = 8, ticks 4-7: water phase 904 ms against 623; 64 workgroups: 714): workgroup 0's clock puts the step phase at
+// 23 + 15 us (its own work + waiting for the slowest workgroup) where k_relax_step takes 9.7 us as a launch of its own, apply at 9 + 18
+// (13), and the flood phase at 20 + 48. One kernel holds all five phases' code (240 KB against a 64 KB instruction cache that every
+// wavefront walks through once per epoch), is register-allocated for its worst phase (256 VGPR + 96 AGPR, 1.1 KB of scratch per lane: one
+// wavefront per SIMD, where the step / apply / filter kernels run at 64-144 registers), and every barrier's acquire invalidates the L2 the
+// next phase's first loads -- instructions included -- then miss. Kernel boundaries do the same flushes in hardware, overlapped with the
+// dispatch of a kernel compiled for that phase alone. What bounds an epoch is the slowest flood and the slowest cascade, not the launches.
+struct GridBar { uint32_t count, gen, busy[2], abort, pad[3]; unsigned long long prof[16]; };   // prof: (flags & 2) ticks of the 100 MHz clock per phase, workgroup 0's view
+constexpr uint32_t GB_SPIN_LIMIT = 1u << 22;                  // ~ seconds: a barrier nobody releases sets `abort`, everybody leaves, the host reports it
+// The fences are thread 0's alone: a workgroup's stores are acknowledged by its XCD's L2 when __syncthreads() lets it through (the per-CU
+// cache writes through), thread 0's release then writes that L2 back, and its acquire after the wait invalidates the CU's cache and the
+// L2's stale lines for everybody behind the second __syncthreads(). (Every thread fencing -- 1 024 wavefronts x write-back + invalidate per
+// barrier -- cost 65 us per barrier: the first build of this kernel ran the water phase three times slower than five launches per epoch.)
+__device__ __forceinline__ bool grid_sync(GridBar* b, uint32_t nblocks, uint32_t& gen, bool every_thread_fences) {
+  if (every_thread_fences) __threadfence();
+  __syncthreads();
+  gen++;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (__hip_atomic_fetch_add(&b->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1u) {
+      __hip_atomic_store(&b->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&b->gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&b->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > GB_SPIN_LIMIT) { __hip_atomic_store(&b->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((spins & 0x3FFu) == 0u && __hip_atomic_load(&b->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (every_thread_fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return __hip_atomic_load(&b->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;   // (the host reads it through bs.ctrl[BC_STALLED], k_relax_epochs)
+}
+__global__ void __launch_bounds__(256) k_relax_epochs(DevState s, BatchShared bs, uint32_t nlive, uint32_t epoch0, uint32_t nepochs, uint32_t tag0, GridBar* bar, uint32_t dense_waves, uint32_t flags) {
+  SMX_LOAD_SOILS(sh)
+  // entry i of a list -> lane (i / W) % 64 of wavefront i % W, W wavefronts dealt round robin over the workgroups (wavefront w of the deal =
+  // wave w / nblocks of workgroup w % nblocks: the first `nblocks` wavefronts sit on different CUs). Steps, applies and the filter use
+  // `dense_waves` wavefronts (one per CU by default, as batch_lanes_per_wave: their paths are uniform, and wavefronts of one CU compete for the
+  // instruction cache); floods -- long, branchy, one lane each -- are dealt over ALL wavefronts.
+  const uint32_t NW = gridDim.x * 4u, lane = threadIdx.x & 63u, gw = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+  const bool fence_all = (flags & 1u) != 0u, prof = (flags & 2u) != 0u && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long t_prev = prof ? wall_clock64() : 0ull;
+#define SMX_PROF(slot) if (prof) { const unsigned long long t_now = wall_clock64(); bar->prof[slot] += t_now - t_prev; t_prev = t_now; }
+  uint32_t DW = dense_waves < 1u ? 1u : (dense_waves > NW ? NW : dense_waves);
+  { const uint32_t need = (nlive + 63u) / 64u; if (need > DW) DW = need > NW ? NW : need; }
+  const uint32_t first = lane * DW + gw, stride = 64u * DW;    // (gw >= DW: this wavefront sits the dense phases out)
+  uint32_t gen = __hip_atomic_load(&bar->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t k = 0; k < nepochs; k++) {
+    const uint32_t epoch = epoch0 + k, par = epoch & 1u;
+    bs.rtag = tag0 + k;
+    unsigned long long nc = 0, nt = 0;
+    {                                                                                            // ---- step
+      uint32_t mine = 0u;
+      for (uint32_t i = first; gw < DW && i < nlive; i += stride) {
+        BatchPolicy pol(s, bs);
+        Sim<BatchPolicy> sim(s, sh, pol);
+        const uint32_t slot = bs.live[i];
+        relax_water_step(sim, bs, slot, epoch);
+        mine |= (bs.water[slot].state != B_DONE || bs.rcount[slot] != 0u) ? 1u : 0u;            // (a particle's last step still has edits to apply)
+      }
+      if (mine) __hip_atomic_store(&bar->busy[k & 1u], bs.rtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (tags are unique and never 0: nothing to reset)
+      if (blockIdx.x == 0 && threadIdx.x == 0) {                                                 // the lists of the next epoch start empty
+        bs.ctrl[BC_NFLOOD + (par ^ 1u)] = 0u; bs.ctrl[BC_NFLAG + (par ^ 1u)] = 0u; bs.ctrl[BC_NRUN + (par ^ 1u)] = 0u;
+        for (uint32_t q = 0; q < 9u; q++) bs.ctrl[BC_NCASC + 9u * (par ^ 1u) + q] = 0u;
+        bs.ctrl[BC_CASC_CURSOR] = 0u;
+      }
+    }
+    SMX_PROF(0)
+    if (!grid_sync(bar, gridDim.x, gen, fence_all)) { bs.ctrl[BC_STALLED] = 1u; return; }
+    SMX_PROF(1)
+    if (__hip_atomic_load(&bar->busy[k & 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != bs.rtag) break;   // every particle of the generation is done
+    for (uint32_t i = first; gw < DW && i < nlive; i += stride) {                                // ---- apply
+      BatchPolicy pol(s, bs);
+      Sim<BatchPolicy> sim(s, sh, pol);
+      relax_apply_slot(sim, bs, bs.live[i]);
+      sim.flush_counters(); pol.finish(s);
+    }
+    SMX_PROF(2)
+    if (!grid_sync(bar, gridDim.x, gen, fence_all)) { bs.ctrl[BC_STALLED] = 1u; return; }
+    SMX_PROF(3)
+    {                                                                                            // ---- filter (isolated cells cascade in here)
+      uint32_t n = __hip_atomic_load(&bs.ctrl[BC_NFLAG + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n > bs.flag_cap) n = bs.flag_cap;
+      if (n) {
+        uint32_t FW = DW; { const uint32_t need = (n + 63u) / 64u; if (need > FW) FW = need > NW ? NW : need; }
+        for (uint32_t i0 = gw; gw < FW && i0 < n; i0 += 64u * FW) {                              // (wavefront-uniform trip count: relax_filter appends with ballots)
+          const uint32_t i = i0 + lane * FW;
+          BatchPolicy pol(s, bs);
+          Sim<BatchPolicy> sim(s, sh, pol);
+          relax_filter(sim, bs, i < n ? bs.flagl[par][i] : 0u, i < n, epoch);
+          sim.flush_counters(); pol.finish(s);
+          nc += pol.a_casc; nt += pol.a_tr;
+        }
+        SMX_PROF(4)
+        if (!grid_sync(bar, gridDim.x, gen, fence_all)) { bs.ctrl[BC_STALLED] = 1u; return; }
+        SMX_PROF(5)
+      }
+    }
+    {                                                                                            // ---- the colour lists: the dataflow of k_relax_cascade_flow, a cell per wavefront
+      uint32_t cnt[9], total = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < 9u; q++) {
+        uint32_t n = __hip_atomic_load(&bs.ctrl[BC_NCASC + 9u * par + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n > bs.clist_cap) n = bs.clist_cap;
+        cnt[q] = n; total += n;
+      }
+      if (total) {
+        const uint32_t pending = 2u * bs.rtag;
+        while (true) {
+          uint32_t i = 0u;
+          if (lane == 0u) i = atomicAdd(&bs.ctrl[BC_CASC_CURSOR], 1u);
+          i = (uint32_t)__shfl((int)i, 0);
+          if (i >= total) break;
+          if (lane == 0u) {
+            uint32_t q = 0;
+#pragma unroll
+            for (uint32_t c9 = 0; c9 < 9u; c9++) { if (q == c9 && i >= cnt[c9]) { i -= cnt[c9]; q = c9 + 1u; } }
+            const uint32_t c = bs.clist[par][(size_t)q * bs.clist_cap + i];
+            const int x = (int)(c / (uint32_t)s.dimy), y = (int)(c - (uint32_t)x * (uint32_t)s.dimy);
+            const int xa = x - 2 < s.x_lo ? s.x_lo : x - 2, xb = x + 2 >= s.x_hi ? s.x_hi - 1 : x + 2;
+            const int ya = y - 2 < 0 ? 0 : y - 2, yb = y + 2 >= s.dimy ? s.dimy - 1 : y + 2;
+            uint32_t spins = 0;
+            for (int xx = xa; xx <= xb; xx++)
+              for (int yy = ya; yy <= yb; yy++) {
+                if ((uint32_t)((xx % 3) * 3 + (yy % 3)) >= q) continue;                          // (only cells of an earlier colour; the cell itself has colour q)
+                uint32_t* f = &bs.cstate[(size_t)xx * (size_t)s.dimy + (size_t)yy];
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pending) {
+                  __builtin_amdgcn_s_sleep(2);
+                  if (++spins > GB_SPIN_LIMIT) { __hip_atomic_store(&bar->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+              }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            BatchPolicy pol(s, bs);
+            Sim<BatchPolicy> sim(s, sh, pol);
+            relax_cascade(sim, c);
+            sim.flush_counters(); pol.finish(s);
+            nc += pol.a_casc; nt += pol.a_tr;
+            __hip_atomic_store(&bs.cstate[c], pending + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        SMX_PROF(6)
+        if (!grid_sync(bar, gridDim.x, gen, fence_all)) { bs.ctrl[BC_STALLED] = 1u; return; }
+        SMX_PROF(7)
+      }
+    }
+    relax_commit_cascade_counters(s, nc, nt);
+    {                                                                                            // ---- floods (and their nested particles), one per wavefront while the list allows
+      uint32_t n = __hip_atomic_load(&bs.ctrl[BC_NFLOOD + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n > bs.list_cap) n = bs.list_cap;
+      if (n) {
+        const bool due = relax_floods_due(bs, epoch, n, __hip_atomic_load(&bs.ctrl[BC_NRUN + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        for (uint32_t i0 = gw; i0 < n; i0 += 64u * NW) {
+          const uint32_t i = i0 + lane * NW;
+          bool again = false; uint32_t slot = 0u;
+          if (i < n && !due) { slot = bs.flist[par][i]; again = true; }                          // not this epoch: the list moves on
+          else if (i < n) {
+            slot = bs.flist[par][i];
+            BatchPolicy pol(s, bs);
+            Sim<BatchPolicy> sim(s, sh, pol);
+            Frame st[MAX_FRAMES];
+            batch_water_epoch(sim, bs, slot, epoch, st);
+            sim.flush_counters(); pol.finish(s);
+            again = bs.water[slot].state == B_ENDED;
+          }
+          relax_flood_later(bs, slot, par ^ 1u, again);
+        }
+        SMX_PROF(8)
+        if (!grid_sync(bar, gridDim.x, gen, fence_all)) { bs.ctrl[BC_STALLED] = 1u; return; }
+        SMX_PROF(9)
+      }
+    }
+    if (prof) bar->prof[10] += 1ull;
+  }
+#undef SMX_PROF
+}
 // how many particles share a wavefront: as few as fill `SMX_BATCH_WAVES` wavefronts (default 256 = one per CU; 0 = always 64;
 // measured in profiles/r02_batched_schedules.md, sweep 5). Which lane runs a slot has no influence on results.
 static uint32_t batch_lanes_per_wave(uint32_t nlive) {
@@ -978,7 +1166,7 @@ struct smx_ctx {
   std::vector<hipEvent_t> evpool;
   smx_timing timing{};
   uint32_t spec_sub = 0, spec_maxnest = 0; bool spec_realloc = false;   // smx_set_spec_limits (0 = defaults)
-  int water_generations = SMX_WATER_GENERATIONS;             // smx_set_water_generations (throughput engines: 4)
+  int water_generations = SMX_WATER_GENERATIONS;             // smx_set_water_generations (throughput engines: 8)
   uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0, spec_subphases_cut = 0, spec_serial_particles = 0;
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
@@ -997,6 +1185,10 @@ struct smx_ctx {
   int relax_wind_steps = 4;           // ... taking up to this many steps per epoch (<= R_MAXSTEPS)
   int relax_water_steps = 1;          // relaxed water: steps per epoch (1 = an edit is visible to everybody's next step)
   uint32_t relax_tag = 0;             // epoch tags of the cascade flags (unique over the context's life)
+  struct GridBar* d_gbar = nullptr;   // k_relax_epochs: the device-wide barrier of the persistent launch
+  int mega_blocks = 0;                // ... its grid (0: not sized yet): co-resident workgroups, hipLaunchCooperativeKernel
+  bool mega_off = false;              // ... the device refused a cooperative launch: the per-phase launches run instead (said once on stderr)
+  int relax_persistent = -1, relax_tail_at = -1;   // smx_set_relax_launch (-1: the defaults / the environment's)
   uint32_t relax_cap = 0;             // slots the relaxed schedule's buffers are sized for
   int strips_n = 1, strips_a = 16, strips_b = 48;
   int own_x0 = 0, own_x1 = -1;        // strips on several devices: the columns this context owns (-1: to the map's edge)
@@ -1037,7 +1229,9 @@ static void drain_events(smx_ctx* ctx) {
       case 6: ctx->timing.ms_kernel_classify += ms; ctx->timing.launches_kernel_classify += p.launches; break;
       case 7: ctx->timing.ms_kernel_gridtiles += ms; ctx->timing.launches_kernel_gridtiles += p.launches; break;
       case 8: ctx->timing.ms_kernel_mapfreq += ms; ctx->timing.launches_kernel_mapfreq += p.launches; break;
-      case 9: break;                                            // (k_relax_tail: part of its phase's time, no line of its own)
+      case 9: ctx->timing.ms_kernel_tail += ms; ctx->timing.launches_kernel_tail++; ctx->timing.epochs_kernel_tail += p.launches; break;          // k_relax_tail (p.launches = its epochs)
+      case 10: ctx->timing.ms_kernel_epochs += ms; ctx->timing.launches_kernel_epochs++; ctx->timing.epochs_kernel_epochs += p.launches; break;   // k_relax_epochs
+      case 11: ctx->timing.ms_kernel_grid_children += ms; ctx->timing.launches_kernel_grid_children += p.launches; break;
       default: ctx->timing.ms_freq += ms; ctx->timing.launches_freq++; break;
     }
     ctx->evpool.push_back(p.a); ctx->evpool.push_back(p.b);
@@ -1134,6 +1328,14 @@ void smx_destroy(smx_ctx* ctx) {
   if (!ctx) return;
   strips_free(ctx);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->d_gbar && getenv("SMX_RELAX_MEGA_FLAGS") && (atoi(getenv("SMX_RELAX_MEGA_FLAGS")) & 2)) {   // (experiments: where an epoch of k_relax_epochs goes, workgroup 0's clock)
+    GridBar hb; if (hipMemcpy(&hb, ctx->d_gbar, sizeof(hb), hipMemcpyDeviceToHost) == hipSuccess && hb.prof[10]) {
+      static const char* nm[10] = {"step", "sync", "apply", "sync", "filter", "sync", "colours", "sync", "floods", "sync"};
+      fprintf(stderr, "[soilmx] k_relax_epochs, %llu epochs, microseconds per epoch (100 MHz clock):", hb.prof[10]);
+      for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.1f", nm[k], 0.01 * (double)hb.prof[k] / (double)hb.prof[10]);
+      fprintf(stderr, "\n");
+    }
+  }
   drain_events(ctx);
   for (hipEvent_t e : ctx->evpool) hipEventDestroy(e);
   DevState& d = ctx->d;
@@ -1151,7 +1353,7 @@ void smx_destroy(smx_ctx* ctx) {
   {
     BatchShared& bs = ctx->bs;
     hipFree(bs.claim[0]); hipFree(bs.claim[1]); hipFree(bs.water); hipFree(bs.wind); hipFree(bs.live); hipFree(bs.children);
-    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(ctx->cstate_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_vtx1); hipFree(ctx->d_tsort); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
+    hipFree(bs.freed); hipFree(bs.ctrl); hipFree(bs.dirty); hipFree(bs.req); hipFree(bs.rnext); hipFree(bs.rcount); hipFree(ctx->rhead_alloc); hipFree(ctx->cflag_alloc); hipFree(ctx->cstate_alloc); hipFree(bs.flist[0]); hipFree(bs.flist[1]); hipFree(bs.clist[0]); hipFree(bs.clist[1]); hipFree(bs.flagl[0]); hipFree(bs.flagl[1]); hipFree(ctx->d_rdata); hipFree(ctx->d_roffs); hipFree(ctx->d_xpart); hipFree(ctx->d_rpart); hipFree(ctx->d_contains); hipFree(ctx->d_xdata); hipFree(ctx->d_xoffs); hipFree(ctx->d_xcur); hipFree(ctx->d_draws); hipFree(ctx->d_kids); hipFree(ctx->d_skeys[0]); hipFree(ctx->d_skeys[1]); hipFree(ctx->d_sidx[0]); hipFree(ctx->d_sidx[1]); hipFree(ctx->d_stemp); hipFree(ctx->d_vtx1); hipFree(ctx->d_tsort); hipFree(ctx->d_tdone); hipFree(ctx->d_tpend[0]); hipFree(ctx->d_tpend[1]); hipFree(ctx->d_tcount); hipFree(ctx->d_gbar); if (ctx->h_tcount) hipHostFree(ctx->h_tcount);
     if (ctx->h_draws) hipHostFree(ctx->h_draws);
     if (ctx->h_bctrl) hipHostFree(ctx->h_bctrl);
   }
@@ -1195,9 +1397,19 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) {
   ctx->batch_dilate = tiles;
   return 0;
 }
+int smx_get_water_generations(smx_ctx* ctx, int32_t* k) { if (!k) return -2; *k = ctx->water_generations; return 0; }
 int smx_set_water_generations(smx_ctx* ctx, int32_t k) {
   if (k < 1 || k > 64) { ctx->err = "smx_set_water_generations: 1..64"; return -2; }
   ctx->water_generations = k;
+  return 0;
+}
+int smx_set_grid_interleave(smx_ctx* ctx, int32_t) {
+  ctx->err = "smx_set_grid_interleave: removed in round 5 (nested particles run inside their parent's region; the grid pass has no interleave any more)";
+  return -2;
+}
+int smx_set_relax_launch(smx_ctx* ctx, int32_t persistent, int32_t tail_at) {
+  if (tail_at > 256) { ctx->err = "smx_set_relax_launch: the tail kernel holds at most 256 particles (one per thread of its workgroup)"; return -2; }
+  ctx->relax_persistent = persistent < 0 ? -1 : (persistent ? 1 : 0); ctx->relax_tail_at = tail_at < 0 ? -1 : tail_at;
   return 0;
 }
 int smx_set_relax_wind(smx_ctx* ctx, uint32_t min_running, int32_t steps_per_epoch) {
@@ -1827,6 +2039,44 @@ static int sort_children(smx_ctx* ctx, uint32_t nc) {       // bs.children[0, nc
   hipLaunchKernelGGL(k_child_gather, dim3(nb), dim3(256), 0, st, ctx->bs.children, ctx->d_sidx[1], nc, ctx->d_kids);
   return 0;
 }
+// `nepochs` dense epochs of the running relaxed water generation as one persistent cooperative launch (k_relax_epochs). 0 = launched.
+static int relax_epochs_launch(smx_ctx* ctx, uint32_t nlive, uint32_t epoch, uint32_t nepochs) {
+  hipStream_t st = ctx->stream;
+  if (!ctx->d_gbar) {
+    if (hipMalloc(&ctx->d_gbar, sizeof(GridBar)) != hipSuccess) { ctx->mega_off = true; return 1; }
+    hipMemsetAsync(ctx->d_gbar, 0, sizeof(GridBar), st);
+  }
+  if (!ctx->mega_blocks) {
+    int dev = 0, ncu = 0, coop = 0, per_cu = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_relax_epochs, 256, 0) != hipSuccess) per_cu = 0;
+    static const int want = [] { const char* e = getenv("SMX_RELAX_MEGA_BLOCKS"); return e ? atoi(e) : 0; }();   // (0: one workgroup per CU)
+    int nb = want > 0 ? want : ncu;
+    if (nb > ncu * per_cu) nb = ncu * per_cu;
+    if (!coop || nb < 1) {
+      fprintf(stderr, "[soilmx] cooperative launch unavailable (attribute %d, %d CUs x %d workgroups): the relaxed epochs run as per-phase launches\n", coop, ncu, per_cu);
+      ctx->mega_off = true; return 1;
+    }
+    ctx->mega_blocks = nb;
+  }
+  BatchShared bs = ctx->bs;
+  uint32_t tag0 = ctx->relax_tag + 1u;
+  GridBar* bar = ctx->d_gbar;
+  static const uint32_t dense_waves_env = [] { const char* e = getenv("SMX_RELAX_MEGA_WAVES"); return e ? (uint32_t)atoi(e) : 0u; }();   // (0: one wavefront per workgroup)
+  static const uint32_t flags_env = [] { const char* e = getenv("SMX_RELAX_MEGA_FLAGS"); return e ? (uint32_t)atoi(e) : 0u; }();          // (1: every thread fences at a barrier)
+  uint32_t dense_waves = dense_waves_env ? dense_waves_env : (uint32_t)ctx->mega_blocks, flags = flags_env;
+  void* args[] = {(void*)&ctx->d, (void*)&bs, (void*)&nlive, (void*)&epoch, (void*)&nepochs, (void*)&tag0, (void*)&bar, (void*)&dense_waves, (void*)&flags};
+  PhaseTimer tk(ctx, 10, nepochs);
+  const hipError_t e = hipLaunchCooperativeKernel((const void*)k_relax_epochs, dim3((unsigned)ctx->mega_blocks), dim3(256), args, 0, st);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    fprintf(stderr, "[soilmx] hipLaunchCooperativeKernel(k_relax_epochs, %d workgroups): %s -- the relaxed epochs run as per-phase launches\n", ctx->mega_blocks, hipGetErrorString(e));
+    ctx->mega_off = true; return 1;
+  }
+  return 0;
+}
 // One CHUNK of a particle phase on the context's current generation: the schedule for `nlive_sched` running particles (all strips
 // together), fresh reservations where the schedule asks for them, then the chunk's epochs over the `nlive` slots of bs.live.
 // Shared by the single-context driver (batch_generations) and the step-wise one of the column strips (smx_d_chunk).
@@ -1875,12 +2125,17 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     // result does not depend on where a generation is cut into chunks; with strips the chunk is the unit of the exchange).
     static const int RCHUNK_KIDS = [] { const char* e = getenv("SMX_RELAX_CHUNK_KIDS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
     static const bool use_tail = [] { const char* e = getenv("SMX_RELAX_TAIL"); return e ? atoi(e) != 0 : true; }();
-    static const uint32_t tail_at = [] { const char* e = getenv("SMX_RELAX_TAIL_AT"); return e ? (uint32_t)atoi(e) : RELAX_TAIL; }();
+    static const uint32_t tail_at_env = [] { const char* e = getenv("SMX_RELAX_TAIL_AT"); return e ? (uint32_t)atoi(e) : RELAX_TAIL; }();
+    const uint32_t tail_at = ctx->relax_tail_at >= 0 ? (uint32_t)ctx->relax_tail_at : tail_at_env;
     const bool tail = !wind && use_tail && nlive <= tail_at;
-    chunk_epochs = strips ? B_CHUNK : (tail ? 64 : (first ? CHUNK : RCHUNK_KIDS));
+    static const bool use_mega_env = [] { const char* e = getenv("SMX_RELAX_MEGA"); return e ? atoi(e) != 0 : false; }();   // (off by default: measured slower, see k_relax_epochs)
+    const bool use_mega = ctx->relax_persistent >= 0 ? ctx->relax_persistent != 0 : use_mega_env;
+    static const int mega_chunk = [] { const char* e = getenv("SMX_RELAX_MEGA_CHUNK"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();   // (0: the chunk lengths of the per-phase launches)
+    const bool mega = !wind && !tail && use_mega && !ctx->mega_off && bs.cstate != nullptr;
+    chunk_epochs = strips ? B_CHUNK : (tail ? 64 : (mega && mega_chunk ? mega_chunk : (first ? CHUNK : RCHUNK_KIDS)));
     ctx->bs.rstride = wind ? 2 * ctx->relax_wind_steps : std::max(2, ctx->relax_water_steps); ctx->bs.rsteps = wind ? ctx->relax_wind_steps : ctx->relax_water_steps;
     if (ctx->relax_tag > 0x7FFF0000u) { ctx->relax_tag = 0; HIPCHK(hipMemsetAsync(ctx->cflag_alloc, 0, ctx->lcells * 4, st)); HIPCHK(hipMemsetAsync(ctx->cstate_alloc, 0, ctx->lcells * 4, st)); }   // (tags never repeat; 2 * tag + 1 fits 32 bits)
-    if (strips) HIPCHK(hipMemsetAsync(bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
+    if (strips) HIPCHK(hipMemsetAsync(bs.ctrl + BC_NFLOOD, 0, (BC_LISTS_END - BC_NFLOOD) * 4, st));   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
     if (strips && !wind) {                                   // who waits for a flood on this device right now?
       if (nslots) hipLaunchKernelGGL(k_relax_rebuild_floods, dim3((nslots + 255u) / 256u), dim3(256), 0, st, bs, nslots, epoch & 1u);
     }
@@ -1888,6 +2143,8 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
     else if (tail) {                                         // few particles left: whole epochs inside one workgroup (k_relax_tail)
       PhaseTimer tk(ctx, 9, (uint32_t)chunk_epochs);
       hipLaunchKernelGGL(k_relax_tail, dim3(1), dim3(256), 0, st, ctx->d, bs, nlive, epoch, (uint32_t)chunk_epochs, ctx->relax_tag + 1u);
+      ctx->relax_tag += (uint32_t)chunk_epochs; epoch += (uint32_t)chunk_epochs;
+    } else if (mega && relax_epochs_launch(ctx, nlive, epoch, (uint32_t)chunk_epochs) == 0) {   // the chunk's dense epochs as ONE persistent launch (k_relax_epochs)
       ctx->relax_tag += (uint32_t)chunk_epochs; epoch += (uint32_t)chunk_epochs;
     } else {
       const uint32_t lpw = batch_lanes_per_wave(nlive);
@@ -1968,7 +2225,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, uint32_t nkids
     ctx->bs.tshift = -1;                                      // (the first chunk clears the planes and issues the first reservations)
     const bool relax_gen = ctx->cfg.engine == SMX_ENGINE_RELAXED;
     ctx->bs.relaxed = relax_gen ? 1 : 0;
-    if (relax_gen) HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // flood, flag and cascade lists start empty
+    if (relax_gen) HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NFLOOD, 0, (BC_LISTS_END - BC_NFLOOD) * 4, st));   // flood, flag and cascade lists start empty
     const BChild* dk = first ? nullptr : ctx->d_kids;        // (sorted there by sort_children)
     const unsigned nb = (nslots + 63u) / 64u;
     if (wind) hipLaunchKernelGGL(k_batch_spawn<true>, dim3(nb), dim3(64), 0, st, ctx->d, bs, nslots, dk, (const uint32_t*)nullptr);
@@ -1999,6 +2256,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, uint32_t nkids
     if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
     if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
     if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
+    if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "relaxed schedule: the persistent epoch kernel ran out of its spin budget (a barrier or a dataflow wait was never released)"; return -9; }
     if (nc > bs.child_cap) nc = bs.child_cap;
     if (wind) nc = 0;
     if (nc && sort_children(ctx, nc)) return -1;             // -> ctx->d_kids, on the device
@@ -2082,10 +2340,11 @@ static int batch_grid(smx_ctx* ctx) {
   if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
   if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
   if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
+  if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "relaxed schedule: the persistent epoch kernel ran out of its spin budget (a barrier or a dataflow wait was never released)"; return -9; }
   if (nc > bs.child_cap) nc = bs.child_cap;
   if (nc && sort_children(ctx, nc)) return -1;
   HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
-  if (nc) return batch_generations(ctx, false, 0, nc);       // the nested particles that left their tile's region
+  if (nc) { PhaseTimer tk(ctx, 11); return batch_generations(ctx, false, 0, nc); }   // the nested particles that left their tile's region
   return 0;
 }
 
@@ -2127,7 +2386,7 @@ int smx_d_gen_begin(smx_ctx* ctx, int32_t wind, uint32_t nslots, const void* kid
   ctx->bs.tshift = -1;
   HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NCHILD, 0, 8, st));
   ctx->bs.relaxed = ctx->cfg.engine == SMX_ENGINE_RELAXED ? 1 : 0;
-  if (ctx->bs.relaxed) HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NFLOOD, 0, (BC_COUNT - BC_NFLOOD) * 4, st));   // flood, flag and cascade lists start empty
+  if (ctx->bs.relaxed) HIPCHK(hipMemsetAsync(ctx->bs.ctrl + BC_NFLOOD, 0, (BC_LISTS_END - BC_NFLOOD) * 4, st));   // flood, flag and cascade lists start empty
   if (kids_host) {
     if (ctx->kids_cap < nslots) { hipFree(ctx->d_kids); ctx->d_kids = nullptr; ctx->kids_cap = 0; HIPCHK(hipMalloc(&ctx->d_kids, (size_t)nslots * sizeof(BChild))); ctx->kids_cap = nslots; }
     if (ctx->contains_cap < nslots) { hipFree(ctx->d_contains); ctx->d_contains = nullptr; ctx->contains_cap = 0; HIPCHK(hipMalloc(&ctx->d_contains, (size_t)nslots * 4)); ctx->contains_cap = nslots; }
@@ -2184,6 +2443,7 @@ static int d_gen_end_impl(smx_ctx* ctx, void* children_out, uint32_t cap, uint32
   if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
   if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
   if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
+  if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "relaxed schedule: the persistent epoch kernel ran out of its spin budget (a barrier or a dataflow wait was never released)"; return -9; }
   if (nc > bs.child_cap) nc = bs.child_cap;
   if (vec) { vec->resize(nc); children_out = vec->data(); cap = nc; }
   if (nc > cap) { ctx->err = "smx_d_gen_end: children buffer too small (call again with room for *n records)"; *n = nc; return -2; }
@@ -2287,7 +2547,7 @@ int smx_d_grid_begin(smx_ctx* ctx) {
   launch_classify(ctx);
   return 0;
 }
-int smx_d_grid_sweep(smx_ctx* ctx, int32_t phase, int32_t x_lo, int32_t x_hi) {   // the tiles of the COLUMNS [x_lo, x_hi) (multiples of the tile size)
+int smx_d_grid_sweep_cols(smx_ctx* ctx, int32_t phase, int32_t x_lo, int32_t x_hi) {   // the tiles of the COLUMNS [x_lo, x_hi) (multiples of the tile size)
   const int rc = grid_sweep(ctx, phase, x_lo >> GRID_SHIFT, (x_hi + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));

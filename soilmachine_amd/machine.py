@@ -180,9 +180,19 @@ class Layermap:
         """relaxed schedule: wind steps relaxed (up to `steps_per_epoch` steps per epoch) while more than `min_running` particles run"""
         self._chk(self.L.smx_set_relax_wind(self.h, int(min_running), int(steps_per_epoch)))
 
+    def set_relax_launch(self, persistent: int = -1, tail_at: int = -1):
+        """relaxed water epochs: launch shape only, never the result (smx_set_relax_launch): persistent 1 = one cooperative launch per chunk,
+        0 = five launches per epoch; tail_at = running particles from which one workgroup runs whole epochs (0..256); -1 = default"""
+        self._chk(self.L.smx_set_relax_launch(self.h, int(persistent), int(tail_at)))
+
     def set_water_generations(self, k: int):
         """throughput engines: the water phase's particles as k consecutive generations of n/k (smx_set_water_generations)"""
         self._chk(self.L.smx_set_water_generations(self.h, int(k)))
+
+    def water_generations(self) -> int:
+        k = C.c_int32()
+        self._chk(self.L.smx_get_water_generations(self.h, C.byref(k)))
+        return int(k.value)
 
     def set_batch_strips(self, nstrips: int, inset: int = 16, seam_halfwidth: int = 48):
         self._chk(self.L.smx_set_batch_strips(self.h, int(nstrips), int(inset), int(seam_halfwidth)))

@@ -519,7 +519,7 @@ static void batch_generations(hs_ctx* c, BatchBuffers& b, bool wind, uint32_t n,
       if (relaxed_now) {                                     // mirrors soilmx.hip: step, apply, nine cascade colours, floods
         chunk_epochs = strips ? B_CHUNK : (first ? B_CHUNK : 8);   // (with strips the chunk is the unit of the exchange: soilmx.hip run_chunk)
         b.bs.rstride = wind ? 2 * g_relax_wind_steps : (g_relax_water_steps > 2 ? g_relax_water_steps : 2); b.bs.rsteps = wind ? g_relax_wind_steps : g_relax_water_steps;
-        if (strips) for (uint32_t q = BC_NFLOOD; q < (uint32_t)BC_COUNT; q++) b.ctrl[q] = 0u;   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
+        if (strips) for (uint32_t q = BC_NFLOOD; q < (uint32_t)BC_LISTS_END; q++) b.ctrl[q] = 0u;   // (the epoch skipped between two chunks breaks the lists' parity hand-over)
         if (strips && !wind) {                                // k_relax_rebuild_floods
           for (uint32_t i = 0; i < nslots; i++) relax_flood_later(bs, i, epoch & 1u, b.water[i].state == B_ENDED);
         }
@@ -887,7 +887,7 @@ void hs_d_grid_begin(hs_ctx* c) {
   batch_setup(c, d.b, 0, false);
   d.b.ctrl[BC_NCHILD] = 0;
 }
-void hs_d_grid_sweep(hs_ctx* c, int phase, int x_lo, int x_hi) {   // (cell columns, as smx_d_grid_sweep)
+void hs_d_grid_sweep(hs_ctx* c, int phase, int x_lo, int x_hi) {   // (cell columns, as smx_d_grid_sweep_cols)
   DPhase& d = dp_of(c);
   c->ctr[C_GRID_ACTIVE] += grid_sweep(c, d.b, phase, x_lo >> GRID_SHIFT, (x_hi + (1 << GRID_SHIFT) - 1) >> GRID_SHIFT, 1, 0);
 }

@@ -71,7 +71,7 @@ class DeviceStripBackend:
         a = np.frombuffer(b, np.uint8); self._chk(self.L.smx_d_unpack_particles(self.h, self.capi.ptr(a), len(b)))
 
     def grid_begin(self): self._chk(self.L.smx_d_grid_begin(self.h))
-    def grid_sweep(self, phase, lo, hi): self._chk(self.L.smx_d_grid_sweep(self.h, phase, lo, hi))
+    def grid_sweep(self, phase, lo, hi): self._chk(self.L.smx_d_grid_sweep_cols(self.h, phase, lo, hi))
     def map_frequency(self): self._chk(self.L.smx_map_frequency(self.h))
     def reset_frequency(self): self._chk(self.L.smx_reset_frequency(self.h))
 
@@ -87,7 +87,7 @@ class StripRank:
         backend.set_strips(geom.n, geom.a, geom.b)
         backend.set_own(self.x0, self.x1)
         self.stats = {"chunks": 0, "seam_chunks": 0, "generations": 0}
-        self.water_generations = 4                                # smx_set_water_generations' default (csrc/soil_batch.h SMX_WATER_GENERATIONS)
+        self.water_generations = 8                                # smx_set_water_generations' default (csrc/soil_batch.h SMX_WATER_GENERATIONS)
 
     # -- halo traffic (nearest neighbours only). A rank holds, besides its strip, the b columns right of its right boundary.
     # one message per direction: [u64 length of the column part][columns][particles]

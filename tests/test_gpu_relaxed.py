@@ -17,22 +17,30 @@ KEYS = ["steps_water_top", "steps_water_all", "steps_wind", "nested_particles", 
         "wcascade_calls", "rand_calls", "pool_free"]
 
 
-def machine(cfg, dimx, dimy, nw, nd, wind, engine, snap=None, wmin=0xFFFFFFFF, wsteps=4, size_seed=0):
+# launch shapes of the relaxed water epochs (smx_set_relax_launch): results must not depend on them
+SHAPES = {"default": (-1, -1),          # five launches per epoch above 256 running particles, the one-workgroup tail below
+          "persistent": (1, 0),         # every epoch with a running particle through k_relax_epochs (cooperative launch, device-wide barriers)
+          "per-phase": (0, 0)}          # five launches per epoch down to the last particle
+
+
+def machine(cfg, dimx, dimy, nw, nd, wind, engine, snap=None, wmin=0xFFFFFFFF, wsteps=4, size_seed=0, shape="default"):
     m = Layermap(cfg, dimx, dimy, seed=size_seed, initialize=snap is None, engine=engine)
     if snap is not None:
         m.load(snap, rand_seed=0)
     if engine == capi.ENGINE_RELAXED:
         m.set_relax_wind(wmin, wsteps)
+        m.set_relax_launch(*SHAPES[shape])
     sm = SoilMachine.__new__(SoilMachine)
     sm.cfg, sm.map, sm.nwater, sm.nwind, sm.dowater, sm.dowind = cfg, m, nw, nd, True, wind
     return sm
 
 
+@pytest.mark.parametrize("shape", list(SHAPES))
 @pytest.mark.parametrize("soil,case,t0,nw,nd,wind,ticks,wmin,wsteps", CASES)
-def test_device_equals_host_threads(soil, case, t0, nw, nd, wind, ticks, wmin, wsteps):
+def test_device_equals_host_threads(soil, case, t0, nw, nd, wind, ticks, wmin, wsteps, shape):
     cfg = load_cfg(soil)
     g = golden_snapshot(case, t0)
-    sm = machine(cfg, g.dimx, g.dimy, nw, nd, wind, capi.ENGINE_RELAXED, snap=g, wmin=wmin, wsteps=wsteps)
+    sm = machine(cfg, g.dimx, g.dimy, nw, nd, wind, capi.ENGINE_RELAXED, snap=g, wmin=wmin, wsteps=wsteps, shape=shape)
     h = HostSim(cfg, g.dimx, g.dimy, seed=0)
     h.load(g, advance_rand=True)
     for t in range(ticks):
@@ -45,13 +53,14 @@ def test_device_equals_host_threads(soil, case, t0, nw, nd, wind, ticks, wmin, w
     assert sm.map.batch_stats()["children_lost"] == 0
 
 
+@pytest.mark.parametrize("shape", ["default", "persistent"])
 @pytest.mark.parametrize("soil,case,t0,nw,nd,wind,ticks", RESTATED)
-def test_device_equals_the_independent_restatement(soil, case, t0, nw, nd, wind, ticks):
+def test_device_equals_the_independent_restatement(soil, case, t0, nw, nd, wind, ticks, shape):
     """the relaxed engine through the C-ABI against oracle/soil_oracle.cpp r_water_generation (the schedule restated from its
     definition with the oracle's own step functions): full state every tick, counters at the end"""
     cfg = load_cfg(soil)
     g = golden_snapshot(case, t0)
-    sm = machine(cfg, g.dimx, g.dimy, nw, nd, wind, capi.ENGINE_RELAXED, snap=g)
+    sm = machine(cfg, g.dimx, g.dimy, nw, nd, wind, capi.ENGINE_RELAXED, snap=g, shape=shape)
     o = Oracle(cfg, g.dimx, g.dimy, seed=0); o.load(g)
     for t in range(ticks):
         sm.tick(1, sync=True)
@@ -158,3 +167,23 @@ def test_fidelity_knobs_on_the_device_equal_host_threads():
             bad = compare(sm.map.snapshot(), h.snapshot())
             assert not bad, (t, bad)
     assert sm.map.counters()["nested_particles"] == h.counters()["nested_particles"] > 300
+
+
+def test_launch_shapes_agree_at_size():
+    """The persistent launch in its own regime -- thousands of running particles over every wavefront of the grid, lakes, floods with nested
+    particles, colour lists with dependencies -- against five launches per epoch: full state and counters after every tick (512^2, the
+    headline's soil at the headline's particle density, 8 ticks)."""
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n, nw, nd = 512, 1000, 250
+    a = machine(cfg, n, n, nw, nd, True, capi.ENGINE_RELAXED, shape="default")
+    a.map.set_relax_launch(1, -1)                                            # the persistent launch above 256 running particles, the tail kernel below
+    b = machine(cfg, n, n, nw, nd, True, capi.ENGINE_RELAXED, shape="per-phase")
+    a.map.set_water_generations(1); b.map.set_water_generations(1)          # (1 000 particles in one generation: the dense epochs are dense)
+    for t in range(8):
+        a.tick(1, sync=True); b.tick(1, sync=True)
+        bad = compare(a.map.snapshot(), b.map.snapshot())
+        assert not bad, (t, bad)
+    ca, cb = a.map.counters(), b.map.counters()
+    assert {x: ca[x] for x in KEYS} == {x: cb[x] for x in KEYS}
+    t = a.map.timing()
+    assert t["launches_kernel_epochs"] > 0 and t["epochs_kernel_epochs"] > 0, "the persistent kernel did not run (cooperative launch refused?)"

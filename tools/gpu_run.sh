@@ -51,6 +51,11 @@ for s in "$@"; do
     headwsteps) for w in ${WSTEPS_LIST:-1 2}; do run headwsteps_$w 30 300 env SMX_RELAX_WATER_STEPS=$w python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
     windtail)  i=0; IFS='|'; for w in ${WT_LIST}; do i=$((i+1)); IFS=' '; run windtail_$i 30 300 env SMX_BATCH_SCHED_TAIL_WIND="$w" python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 4 --warmup 3; IFS='|'; done; IFS=' ' ;;
     chunksweep) for kv in ${CS_LIST}; do run cs_$kv 30 300 env ${kv} python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 4 --warmup 3; done ;;
+    shapes)    run shapes 30 240 python -m pytest tests/test_gpu_relaxed.py -x -q -m gpu -k "launch_shapes or (host_threads and rgps)" --durations=5 ;;
+    megasweep) i=0; IFS='|'; for kv in ${MS_LIST}; do i=$((i+1)); IFS=' '; run megasweep_$i 30 200 env ${kv} python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 4 --warmup 3; echo "   [$kv]" | tee -a $out/status.txt; IFS='|'; done; IFS=' ' ;;
+    headmega0) run headmega0 30 300 env SMX_RELAX_MEGA=0 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
+    headmegab) for b in ${MB_LIST:-512}; do run headmegab_$b 30 300 env SMX_RELAX_MEGA_BLOCKS=$b python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
+    headmegac) for b in ${MC_LIST:-64}; do run headmegac_$b 30 300 env SMX_RELAX_MEGA_CHUNK=$b python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
     headbatch) run headbatch 30 300 python bench.py --engine batched --no-lines --no-cpu-baseline --steps 3 --warmup 2 ;;
     tracerelax) run tracerelax 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 5 ;;
     stripstest) run stripstest 60 900 python -m pytest tests/test_gpu_strips.py -x -q -m gpu --durations=8 ;;
@@ -79,6 +84,9 @@ for s in "$@"; do
                python tools/kernel_stats.py $out/exactk | tee $out/exactk.kernels; python tools/trace_gaps.py $out/exactk | tee $out/exactk.summary; rm -rf $out/exactk ;;
     exactmode2) run exactmode2 60 600 env SMX_SPEC_MODE=2 python bench.py --only exact_area_scaled ;;
     p2ref)     run p2ref 60 ${PTO:-900} python tools/p2_reference.py --size ${PSIZE:-4096} --ticks ${PTICKS:-10} --nctl ${PNCTL:-8} --engine ${PENGINE:-relaxed} --water-batches ${PWB:-0} --out $out/p2ref_${PSIZE:-4096}.json; tail -12 $out/p2ref.err ;;
+    p2multi)   run p2multi 60 ${PTO:-1200} python tools/p2_reference.py --size ${PSIZE:-4096} --ticks ${PTICKS:-10} --nctl ${PNCTL:-32} --engine ${PENGINE:-relaxed} --variants ${PVARS:-k4,k8} --out $out/p2multi_${PSIZE:-4096}.json; grep -v '^ *"' $out/p2multi.err | tail -120 ;;
+    tracedrv)  run tracedrv 60 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/tracedrv -o t -- python bench.py --gpus 1 --steps ${TSTEPS:-20} --warmup ${TWARM:-5} --no-cpu-baseline --no-lines ${BENCH_EXTRA:-}
+               python tools/kernel_stats.py $out/tracedrv | tee $out/tracedrv.kernels; python tools/trace_gaps.py $out/tracedrv --last-ticks ${TSTEPS:-20} | tee $out/tracedrv.summary; rm -rf $out/tracedrv ;;
     p2var)     i=0; for kv in ${PV_LIST}; do i=$((i+1)); run p2var_$i 60 ${PTO:-600} env ${kv} python tools/p2_reference.py --size ${PSIZE:-2048} --ticks ${PTICKS:-10} --nctl ${PNCTL:-16} --engine relaxed --out $out/p2var_$i.json; tail -9 $out/p2var_$i.err; done ;;
     exact4096) run exact4096 60 600 python bench.py --only exact_area_scaled ;;
     envelope)  run envelope 60 900 python tools/p2_envelope.py --size ${ESIZE:-1024} --ticks ${ETICKS:-20} --streams ${ESTREAMS:-4} --counts ${ECOUNTS:-area} ;;
