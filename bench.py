@@ -11,23 +11,24 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
   * value = particle-steps/s, whole job: a particle-step is one WaterParticle/WindParticle move()==true followed by its
     interact(), top-level AND nested particles. The unmodified reference can only count top-level steps,
     so the CPU baseline is top-level steps/s and the GPU line carries `value_top_level` next to `value` for that ratio.
-  * headline line: the RELAXED schedule of the batched engine (SMX_ENGINE_RELAXED, csrc/soil_relax.h) in its DEFAULT configuration (four
-    water generations, nested particles inside their parents, 8x8 grid tiles: the one measured against the reference) with
+  * headline line: the RELAXED schedule of the batched engine (SMX_ENGINE_RELAXED, csrc/soil_relax.h) in its DEFAULT configuration (eight
+    water generations since round 6, nested particles inside their parents, 8x8 grid tiles: the one measured against the reference) with
     AREA-SCALED particle counts (NWATER = 250*(N/256)^2 = 64 000, NWIND = 16 000 at 4096^2). Deterministic, but NOT the
     reference's particle order: parity tier P2 (statistical) -- `parity_vs_reference` measures it in the run against the reference itself
-    (1024^2), profiles/r05_p2_reference_4096.json at the headline's size; `parity_vs_exact` against the exact engine on the device. The EXACT engine (bit-identical to the reference, the parity anchor) is reported under "lines" at the soil
+    (1024^2, 16 control streams) and `parity_gate` applies the tests' rule to it and to the committed record at the headline's size
+    (profiles/r06_p2_reference_4096.json, 33 reference streams); `parity_vs_exact` against the exact engine on the device. The EXACT engine (bit-identical to the reference, the parity anchor) is reported under "lines" at the soil
     file's own counts and under config.bit_exact_on_this_workload for the headline's counts, next to the batched schedule of round 2 and
     the 1024^2 default.soil lines of BASELINE configs[1] and [2].
   * every line carries the state digest after its timed region (section count, type hash, sum of heights, rand() draws).
   * "roofline": algorithmic bytes of the dominant kernel / its HIP-event duration (events on the library's own stream,
     bracketing nothing but launches of that kernel) vs the 8 TB/s HBM peak; "phases" gives the same for the O(cells)
-    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass (profiles/r04_pmc.json: the wind kernel is unchanged since), labelled as such.
+    streaming kernels. `traffic` comes from a separate rocprofv3 --pmc pass of the same command (the newest profiles/r*_pmc.json whose workload matches), labelled as such.
     achieved = bytes of ALL launches / ALL launches / the average duration of the bracketed launches (kernel_roofline).
   * "cpu_baseline": the reference's own CPU loop (oracle/_ref/soil_ref_lean = the unmodified reference headers,
     render-only Layermap::update elided) timed on this box's host on THE SAME tick the timed window starts with: the state after the
     warm-up is checkpointed (smx_save, outside the timed region) and the reference continues it (ref_driver --load) at the same counts,
     1 core pinned; an all-cores line (independent processes from that state -- the reference has no threads) and the "as-is" line.
-  * "parity_vs_reference": z-scores of the timed engine against the reference itself (tools/p2_reference.py: 1024^2, 8 control streams).
+  * "parity_vs_reference": z-scores of the timed engine against the reference itself (tools/p2_reference.py: 1024^2, 16 control streams).
   * N > 1: one process per GPU. The throughput engines run ONE map in N column strips, driven inside the library (smx_strips_*: halo
     columns + migrating particles point to point with ncclSend/ncclRecv on device buffers, live count by ncclAllReduce). Default "scaling": "weak" -- the map is
     (N*size) x size, every GPU owns a size x size strip and its share of N x the particles, so per-GPU work is the N=1 line's;
@@ -49,6 +50,8 @@ sys.path.insert(0, ROOT)
 SOIL = "rockgravelpebblessand.soil"
 B_WATER_STEP = 192      # algorithmic bytes per water step   
 B_WIND_STEP = 256       # algorithmic bytes per wind step
+B_FLOOD = 800           # algorithmic bytes per flood (water.h:123-145 + the water-table cascade it starts): the 5x5 cells of 32-byte records its reach covers
+B_ACTIVE_CELL = 32      # grid pass: one top record per active cell
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 
 
@@ -157,7 +160,7 @@ def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool
 
 
 def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None, rand_seed=None, keep_heights=False, save_after_warmup=None,
-            water_generations=None):
+            water_generations=None, save_after_window=None):
     """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers).
     rand_seed: re-seed the libc stream after the terrain is built (same map, another rand() stream: the parity control)."""
     from soilmachine_amd.machine import SoilMachine
@@ -167,6 +170,7 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
         m._chk(m.L.smx_srand(m.h, int(rand_seed)))
     if water_generations is not None:
         m.set_water_generations(water_generations)
+    k_gen = m.water_generations()                               # the value in force (smx_get_water_generations), reported as measured
     sm.tick(warmup, sync=True)
     if save_after_warmup:                                       # the state the timed window starts from: what cpu_baseline continues (outside the timed region)
         try:
@@ -202,12 +206,27 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
         "dt": dt, "steps_w": steps_w, "steps_d": steps_d, "tm": tm, "digest": m.digest(),
         "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"],
         "nested": c1["nested_particles"] - c0["nested_particles"], "floods": c1["floods"] - c0["floods"],
-        "pool_overflow": c1["pool_overflow"], "per_tick": per_tick,
+        "pool_overflow": c1["pool_overflow"], "per_tick": per_tick, "water_generations": k_gen,
+        "flood_nested_steps": c1.get("flood_nested_steps", 0) - c0.get("flood_nested_steps", 0),
+        "grid_nested_steps": c1.get("grid_nested_steps", 0) - c0.get("grid_nested_steps", 0),
+        "grid_active_cells": c1["grid_active_cells"] - c0["grid_active_cells"],
         "engine_stats": dict({k: c1[k] - c0[k] for k in ("spec_rounds", "spec_aborts", "spec_fallbacks", "spec_executed")},
                              **{k: b1[k] - b0[k] for k in b1}),
     }
     if keep_heights:
         r["heights"] = m.heights()
+    if save_after_window:
+        # OUTSIDE the timed region: the state the window ends with is checkpointed and ONE more tick runs on the device -- the tick the CPU
+        # baseline's second sample continues from that checkpoint (the tick grows inside the window: lakes accumulate)
+        try:
+            m.save(save_after_window)
+            ca = m.counters(); ta = time.perf_counter()
+            sm.tick(1); m.sync()
+            cb = m.counters()
+            r["post_tick"] = {"tick": warmup + steps + 1, "ms": 1e3 * (time.perf_counter() - ta), "steps_water": cb["steps_water_all"] - ca["steps_water_all"],
+                              "steps_water_top": cb["steps_water_top"] - ca["steps_water_top"], "steps_wind": cb["steps_wind"] - ca["steps_wind"]}
+        except Exception as e:
+            r["post_tick"] = {"error": str(e)}
     sm.map.close()
     return r
 
@@ -270,7 +289,10 @@ def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dis
     c1, tm, b1 = m.counters(), m.timing(), m.batch_stats()
     r = {"dt": dt, "steps_w": c1["steps_water_all"] - c0["steps_water_all"], "steps_d": c1["steps_wind"] - c0["steps_wind"], "tm": tm,
          "digest": {"note": "strips: each rank holds its own strip; no global digest in the timed run"},
-         "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"],
+         "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"], "water_generations": m.water_generations(),
+         "flood_nested_steps": c1.get("flood_nested_steps", 0) - c0.get("flood_nested_steps", 0),
+         "grid_nested_steps": c1.get("grid_nested_steps", 0) - c0.get("grid_nested_steps", 0),
+         "grid_active_cells": c1["grid_active_cells"] - c0["grid_active_cells"],
          "nested": c1["nested_particles"] - c0["nested_particles"], "floods": c1["floods"] - c0["floods"], "pool_overflow": c1["pool_overflow"],
          "engine_stats": dict({k: b1[k] - b0[k] for k in b1}, strip_stats=rk.stats, held_columns=list(held) if held else [0, dimx], pool_sections=pool, transport="rccl (ncclSend/ncclRecv, device buffers)" if nccl else "host callbacks (gloo)")}
     rk.detach()
@@ -297,6 +319,27 @@ def measure_lbm(device, dims=(512, 320, 512), steps=40):
             "steps": int(tm["steps"]), "us_per_step": us, "cell_updates_per_s": nx * ny * nz / (us * 1e-6),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_cell_step": 176}}
+
+
+def headline_parity_record(k_gen, strips=1):
+    """The committed record of tools/p2_reference.py at the headline's own size and counts (4096^2, 64 000 + 16 000, 32 control streams) for the
+    configuration this run times: read from the newest profiles/r*_p2_reference_4096.json that holds it -- never a literal."""
+    pdir = os.path.join(ROOT, "profiles")
+    name = f"k{k_gen}" + (f"s{strips}" if strips > 1 else "")
+    for pf in sorted((f for f in os.listdir(pdir) if f.endswith("_p2_reference_4096.json")), reverse=True):
+        try:
+            rec = json.load(open(os.path.join(pdir, pf)))
+            b = (rec.get("variants") or {}).get(name)
+            if b is None and not rec.get("variants") and rec.get("water_generations") == k_gen and strips == 1:
+                b = rec
+            if b is None:
+                continue
+            return {"file": f"profiles/{pf}", "variant": name, "workload": rec.get("workload"), "controls": rec.get("controls"), "outliers": b.get("outliers"),
+                    "gate": b.get("gate"), "z": {k: round(v["z"], 2) for k, v in b["figures"].items()},
+                    "reference_streams_passing_the_gate": (rec.get("calibration") or {}).get("_streams_passing_the_gate")}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def kernel_roofline(nbytes, ms_timed, launches_timed, launches_all):
@@ -336,6 +379,28 @@ def line_of(r, name, workload, engine_name, steps):
     }
 
 
+def wet_regime_line(dcfg, device, engine, eng_name, warm=100, ticks=20, cpu_ticks=3):
+    """The established wet regime at the reference's own map size: 256^2 default.soil, NWATER = 250, lakes from tick ~60 -- `ticks`
+    timed ticks after `warm`, and the reference's CPU loop (1 core) on the first `cpu_ticks` of them from the very same state (checkpoint)."""
+    n, nw = 256, 250
+    ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"soilmx_bench_wet_{os.getpid()}.smx")
+    r = measure(dcfg, "default.soil", n, 0, nw, 0, False, engine, 10_000_000, device, ticks, warm, save_after_warmup=ckpt)
+    ln = line_of(r, "wet_regime_256_default", f"256x256, soil/default.soil, NWATER=250, NWIND=0, ticks {warm + 1}-{warm + ticks} (the established wet regime: lakes from "
+                 f"tick ~60; the map of BASELINE configs[0])", eng_name, ticks)
+    ln["steps"], ln["warmup"] = ticks, warm
+    cpu = None
+    if os.path.exists(ckpt):
+        try:
+            cpu = cpu_baseline("default.soil", n, nw, 0, cpu_ticks, 10_000_000, all_cores=False, load=ckpt, tick0=warm)
+        finally:
+            try:
+                os.remove(ckpt)
+            except OSError:
+                pass
+    ln["cpu_baseline"] = ({"value": cpu["value"], "unit": cpu["unit"], "cores": 1, "kind": "reference", "ms_per_tick": cpu["ms_per_tick"], "sample": cpu["sample"][:200]} if cpu else None)
+    return ln
+
+
 def _r(x, nd=4):
     """round floats for the compact line (NaN / inf -> None: strict JSON)"""
     if isinstance(x, float):
@@ -363,27 +428,37 @@ def compact_line(d: dict, detail_path) -> dict:
     for k, v in (rf.get("phases") or {}).items():
         if v:
             ph[k] = {"kernel": v["kernel"].split(" ")[0], "achieved": v["achieved"], "frac": v["frac"], "avg_launch_us": v.get("avg_launch_us"), "launches": v.get("launches")}
+            if v.get("ms_per_tick") is not None:
+                ph[k]["ms_per_tick"] = v["ms_per_tick"]
     out["roofline"] = {"bound": rf["bound"], "kernel": rf["kernel"].split(" ")[0], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
                        "traffic": rf["traffic"], "traffic_source": (rf["traffic_source"] or "")[:120], "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
                        "launches_timed": rf.get("launches_timed"), "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
-                       "whole_tick": {k: rf["whole_tick"][k] for k in ("achieved", "frac", "algorithmic_bytes_per_tick")}, "phases": ph}
+                       "whole_tick": {k: rf["whole_tick"][k] for k in ("achieved", "frac", "algorithmic_bytes_per_tick")}, "phases": ph,
+                       "time_share_of_tick": rf.get("time_share_of_tick")}
+    pt = d.get("per_tick") or []
+    if pt:
+        out["ms_first_tick"], out["ms_last_tick"] = pt[0]["ms"], pt[-1]["ms"]      # the trend inside the timed window (lakes keep growing: VERDICT r5 weak 5)
     if cpu:
         out["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "ms_per_tick": cpu["ms_per_tick"],
                                "host_cpu": cpu.get("host_cpu"), "host_cores_total": cpu.get("host_cores_total"),
                                "sample": cpu["sample"][:300], "steps_counted": "top-level (compare with value_top_level)",
-                               "all_cores": ({"value": cpu["all_cores"]["value"], "cores": cpu["all_cores"]["cores"]} if cpu.get("all_cores") else None)}
+                               "all_cores": ({"value": cpu["all_cores"]["value"], "cores": cpu["all_cores"]["cores"]} if cpu.get("all_cores") else None),
+                               "after_window": ({"value": cpu["after_window"]["value"], "ms_per_tick": cpu["after_window"]["ms_per_tick"],
+                                                 "gpu_ms_same_tick": (cpu["after_window"].get("gpu_same_tick") or {}).get("ms")} if cpu.get("after_window") else None)}
     else:
         out["cpu_baseline"] = None
     if pref and "error" not in pref:
         zs = {k: v.get("z") for k, v in (pref.get("figures") or {}).items()}
         out["parity_vs_reference"] = {"workload": pref.get("workload", "")[:160], "controls": pref.get("controls"), "outliers": pref.get("outliers"),
-                                      "z": zs, "skipped": pref.get("skipped"),
+                                      "z": zs, "gate": pref.get("gate"), "skipped": pref.get("skipped"),
                                       "headline_size_record": pref.get("headline_size_record")}
     elif pref:
         out["parity_vs_reference"] = {"error": str(pref.get("error"))[:200]}
+    out["parity_gate"] = d.get("parity_gate")
     out["work_dropped"] = d["work_dropped"]
     if d.get("lines"):
-        out["lines"] = [{"name": l_["name"], "value": l_["value"], "ms_per_tick": l_["ms_per_tick"]} for l_ in d["lines"] if l_]
+        out["lines"] = [dict({"name": l_["name"], "value": l_.get("value"), "ms_per_tick": l_.get("ms_per_tick")},
+                             **({"cpu_1core_ms_per_tick": l_["cpu_baseline"]["ms_per_tick"]} if l_.get("cpu_baseline") else {})) for l_ in d["lines"] if l_]
     out["detail_file"] = detail_path
     return _r(out)
 
@@ -405,8 +480,8 @@ def main():
     ap.add_argument("--cpu-ticks", type=int, default=1)
     ap.add_argument("--strong", action="store_true", help="N > 1: keep the map at --size^2 and split it (default: the map grows with N)")
     ap.add_argument("--water-generations", type=int, default=None, help="throughput engines: the tick's water particles as k consecutive generations (smx_set_water_generations; "
-                                                                        "default: the engine's own, 4 -- the configuration whose water-cycle figures are inside the reference's spread; "
-                                                                        "1 = round 4's schedule, faster and outside it, profiles/r05_p2_*.json)")
+                                                                        "default: the engine's own (8 since round 6: inside the reference's spread on all eight figures at the headline workload, "
+                                                                        "profiles/r06_p2_reference_4096.json); 4 = round 5's default, 1 = round 4's schedule: faster, outside it)")
     args = ap.parse_args()
 
     import torch
@@ -457,10 +532,13 @@ def main():
     else:
         want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soil_ref_lean"))
         ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"soilmx_bench_{os.getpid()}.smx") if want_cpu else None
+        ckpt2 = (ckpt + ".end") if (ckpt and args.steps > 1) else None
         r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier, save_after_warmup=ckpt,
-                    water_generations=args.water_generations if throughput else None)
+                    water_generations=args.water_generations if throughput else None, save_after_window=ckpt2)
         if ckpt and not os.path.exists(ckpt):
             ckpt = None
+        if ckpt2 and not os.path.exists(ckpt2):
+            ckpt2 = None
     steps = r["steps_w"] + r["steps_d"]
     dev = torch.device("cuda", local_rank) if (torch.cuda.is_available() and (dist is None or dist.get_backend() == "nccl")) else torch.device("cpu")
     tmax, total_steps = distrib.aggregate(dist, r["dt"], steps, dev)
@@ -475,7 +553,7 @@ def main():
         strips4 = {"name": f"configs4_8192_rockgravelpebbles_big_{world}_strips", "engine": eng_name, "scaling": "strong",
                    "workload": f"8192x8192, soil/rockgravelpebbles_big.soil, area-scaled NWATER={nw4} / NWIND=0, ONE map in {world} column strips of {n4 // world}x{n4} (BASELINE configs[4])",
                    "value": s4 / t4, "unit": "particle-steps/s", "ms_per_tick": 1e3 * t4 / 2, "steps": 2, "warmup": 1, "n_gpus": world,
-                   "engine_stats_rank0": r4["engine_stats"], "single_gpu_reference": "lines[configs4_8192_rockgravelpebbles_big_relaxed] of the N=1 run (profiles/r05_bench_detail.json: 144 M steps/s, 740 ms/tick with the round-5 schedule)"}
+                   "engine_stats_rank0": r4["engine_stats"], "single_gpu_reference": "lines[configs4_8192_rockgravelpebbles_big_relaxed] of the N=1 run's detail file"}
 
     if rank == 0:
         tm = r["tm"]
@@ -485,14 +563,26 @@ def main():
                              else "k_batch_epoch<wind> (the relaxed engine runs wind on the exclusive schedule by default: profiles/r03_relaxed.md)")}[eng_name]
         kr = {"water": kernel_roofline(r["steps_w"] * B_WATER_STEP, tm["ms_kernel_water"], tm["launches_kernel_water"], tm.get("launches_step_water", 0)),
               "wind": kernel_roofline(r["steps_d"] * B_WIND_STEP, tm["ms_kernel_wind"], tm["launches_kernel_wind"], tm.get("launches_step_wind", 0))}
-        # the dominant kernel = the particle kernel with the most device time: average duration x ALL its launches
+        knames = {"water": kname[0], "wind": kname[1]}
+        if eng_name == "relaxed":
+            # the launches that carry the relaxed water phase and the grid pass besides the step kernel (round 6: each priced with ITS algorithmic
+            # bytes -- floods: the steps of the nested particles that ran inside them x 192 B + 800 B per flood; grid tiles: 32 B per active cell + their
+            # nested steps x 192 B -- over ITS launches; k_relax_floods is bracketed every 7th launch, the others at every launch)
+            kr["floods"] = kernel_roofline(r.get("flood_nested_steps", 0) * B_WATER_STEP + r["floods"] * B_FLOOD, tm.get("ms_kernel_floods", 0.0),
+                                           tm.get("launches_kernel_floods", 0), tm.get("launches_floods_all", 0))
+            kr["grid_tiles"] = kernel_roofline(r.get("grid_active_cells", 0) * B_ACTIVE_CELL + r.get("grid_nested_steps", 0) * B_WATER_STEP, tm["ms_kernel_gridtiles"],
+                                               tm["launches_kernel_gridtiles"], tm["launches_kernel_gridtiles"])
+            kr["tail"] = kernel_roofline(0.0, tm.get("ms_kernel_tail", 0.0), tm.get("launches_kernel_tail", 0), tm.get("launches_kernel_tail", 0))   # (time only: its steps are not counted apart)
+            kr["epochs"] = kernel_roofline(0.0, tm.get("ms_kernel_epochs", 0.0), tm.get("launches_kernel_epochs", 0), tm.get("launches_kernel_epochs", 0))
+            knames.update(floods="k_relax_floods", grid_tiles="k_grid_tiles_flow", tail="k_relax_tail", epochs="k_relax_epochs")
+        # the dominant kernel = the one with the most device time: average duration x ALL its launches
         ktime = {k: (v["avg_launch_us"] * v["launches"] if v else 0.0) for k, v in kr.items()}
         dom = max(ktime, key=lambda k: ktime[k])
-        kn = kname[0 if dom == "water" else 1]
+        kn = knames[dom]
         kd = kr[dom] or {"achieved": 0.0, "frac": 0.0, "launches": 0, "launches_timed": 0, "avg_launch_us": 0.0, "algorithmic_bytes_per_launch": 0.0}
         ach = kd["achieved"]
         traffic, traffic_src = None, "not collected in this process (rocprofv3 --pmc runs as its own job, tools/gpu_run.sh pmc); no committed pass matches this workload"
-        for pf in ("r05_pmc.json", "r04_pmc.json"):
+        for pf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")), reverse=True):   # the newest round's pass first
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 k = pmc.get("kernels", {}).get(kn.split(" ")[0])
@@ -515,6 +605,11 @@ def main():
                                          "k_map_frequency (freq r/w + track r, 12 B/cell; %d MB working set%s)" % (ncells * 12 // 2**20, ", below the 256 MiB Infinity Cache: see lines[*8192*] for one past it" if ncells * 12 < 256 * 2**20 else ""))
         for key, kk, kname_ in (("particles_water", "water", kname[0]), ("particles_wind", "wind", kname[1])):
             phases[key] = dict(kr[kk], kernel=kname_, algorithmic_bytes_per_step=B_WATER_STEP if kk == "water" else B_WIND_STEP) if kr[kk] else None
+        for kk in ("floods", "grid_tiles", "tail", "epochs"):
+            if kr.get(kk):
+                phases[kk] = dict(kr[kk], kernel=knames[kk], ms_per_tick=ktime[kk] * 1e-3 / args.steps)
+        tick_us = 1e6 * tmax / args.steps
+        time_share = {knames[k].split(" ")[0]: ktime[k] / args.steps / tick_us for k in ktime if ktime[k] > 0}
         # whole-tick figure of SURVEY 8d: B_tick = cells * (32 + 24 * sections/cell) + 192 * water steps + 256 * wind steps, over the tick
         spc = r["digest"]["nsec"] / ncells if isinstance(r["digest"].get("nsec"), int) else 1.5
         b_tick = ncells * (32 + 24 * spc) + (B_WATER_STEP * r["steps_w"] + B_WIND_STEP * r["steps_d"]) / args.steps
@@ -522,10 +617,12 @@ def main():
         roofline = {"bound": "hbm", "kernel": kn, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": kd["avg_launch_us"] * 1e-3, "launches": kd["launches"],
                     "launches_timed": kd["launches_timed"], "algorithmic_bytes_per_launch": kd["algorithmic_bytes_per_launch"], "phases": phases,
+                    "time_share_of_tick": time_share,
                     "whole_tick": {"algorithmic_bytes_per_tick": b_tick, "achieved": tick_gbs, "unit": "GB/s", "frac": tick_gbs / HBM_PEAK_GBS},
-                    "note": "achieved = algorithmic bytes per launch (SURVEY 8d: 192 B per water step, 256 B per wind step, x the steps of ALL launches / ALL launches) "
-                            "/ the average launch duration (HIP events on the library's stream around the bracketed launches: every launch of the wind kernels, every 8th "
-                            "of k_relax_step<water>). A particle step is a ~1000-instruction f64 chain around scattered 32-byte records: latency- and issue-bound, "
+                    "note": "kernel = the launch family with the most device time in the timed window (time_share_of_tick). achieved = algorithmic bytes per launch (SURVEY 8d: 192 B per "
+                            "water step, 256 B per wind step; a flood launch: its nested particles' steps x 192 B + 800 B per flood; the grid tiles: 32 B per active cell + nested steps x 192 B; "
+                            "x the units of ALL launches / ALL launches) / the average launch duration (HIP events on the library's stream around the bracketed launches: every launch of the "
+                            "wind, tile and tail kernels, every 8th of k_relax_step<water>, every 7th of k_relax_floods). A particle step is a ~1000-instruction f64 chain around scattered 32-byte records: latency- and issue-bound, "
                             "not a stream (DESIGN.md 3); the O(cells) kernels are the HBM streams (phases)."}
 
         workload = (f"{dimx}x{n} layermap{f' (one map, {world} column strips of {dimx // world}x{n})' if strips else ''}, soil/{soil}, SEED 0, nwater={nwater}, nwind={nwind} per tick"
@@ -545,7 +642,7 @@ def main():
                 # (37 s per tick at 4096^2 / 64 000 + 16 000: measured once, profiles/r04_exact_area_scaled_4096.json; --full or --only re-measures it)
                 extra.append(("exact_area_scaled", cfg, soil, n, nwater, nwind, "spec", pool, 1, 1, workload, False))
                 other = "batched" if eng_name == "relaxed" else "relaxed"
-                extra.append((f"{other}_area_scaled", cfg, soil, n, nwater, nwind, other, pool, k3, w3, workload, True))
+                extra.append((f"{other}_area_scaled", cfg, soil, n, nwater, nwind, other, pool, k3, w3, workload, False))   # (--full: the exclusive schedule is an internal of the relaxed one -- wind, floods --, not a shipped configuration: DESIGN.md 4.2)
                 extra.append(("exact_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, "spec", pool, k3, w3, fc + " (round-1 headline workload)", True))
                 extra.append((f"{eng_name}_file_counts", cfg, soil, n, cfg.NWATER, cfg.NWIND, eng_name, pool, k3, w3, fc, True))
             for nm, wind in (("configs1_1024_default_hydraulic", 0), ("configs2_1024_default_coupled", 250)):
@@ -571,6 +668,11 @@ def main():
                 ln["map_frequency_GBs"] = (n_ * n_ * 12.0 * rr["tm"]["launches_kernel_mapfreq"] / (rr["tm"]["ms_kernel_mapfreq"] * 1e-3) / 1e9) if rr["tm"]["ms_kernel_mapfreq"] > 0 else None
                 lines.append(ln)
             if throughput and args.only is None:
+                try:
+                    lines.append(wet_regime_line(dcfg, local_rank, ENG[eng_name], eng_name))
+                except Exception as e:                              # (an extra line must not take the headline down with it)
+                    lines.append({"name": "wet_regime_256_default", "error": str(e)})
+            if throughput and args.only is None:
                 # parity of the throughput schedules against the exact engine, ON THE DEVICE, next to the exact engine's own stream-to-stream
                 # spread: 512^2 of the headline's soil at the headline's particle density, measured in this run (the exact engine needs ~4 s per
                 # tick at 1024^2 and 82 s at 4096^2 with these counts: the 1024^2 table, 10 ticks, is profiles/r03_p2_envelope_1024.json)
@@ -585,8 +687,8 @@ def main():
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
                     import p2_reference
-                    pref = p2_reference.run(soil, 1024, 10, 8, eng_name, device=local_rank, verbose=False)
-                    pref["headline_size_record"] = "profiles/r05_p2_reference_4096.json (tools/p2_reference.py --size 4096 --ticks 10 --nctl 16 on the MI355X box: 5 of 8 figures inside |z| < 2, none beyond 3.3)"
+                    pref = p2_reference.run(soil, 1024, 10, 16, eng_name, device=local_rank, verbose=False, water_batches=r.get("water_generations"))
+                    pref["headline_size_record"] = headline_parity_record(r.get("water_generations"))
                 except Exception as e:
                     pref = {"error": str(e)}
         if args.only is not None:
@@ -606,11 +708,17 @@ def main():
             # counts: ~25 s of one core at 4096^2 / 64 000 + 16 000. Fallback (no checkpoint): a bounded sample from the initial terrain.
             if ckpt:
                 pt0 = (r.get("per_tick") or [None])[0]
-                cpu = cpu_baseline(soil, n, nwater, nwind, args.cpu_ticks, pool, all_cores=True, load=ckpt, tick0=args.warmup, gpu_same_tick=pt0)
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=2) as ex:   # (two samples side by side: the first tick of the window and the tick right after it -- the tick grows with the lakes)
+                    f_end = ex.submit(cpu_baseline, soil, n, nwater, nwind, 1, pool, False, ckpt2, args.warmup + args.steps, r.get("post_tick")) if ckpt2 else None
+                    cpu = cpu_baseline(soil, n, nwater, nwind, args.cpu_ticks, pool, all_cores=True, load=ckpt, tick0=args.warmup, gpu_same_tick=pt0)
+                    ce = f_end.result() if f_end else None
+                if cpu and ce:
+                    cpu["after_window"] = {"value": ce["value"], "ms_per_tick": ce["ms_per_tick"], "sample": ce["sample"][:160], "gpu_same_tick": ce.get("gpu_same_tick")}
             else:
                 cw, cd = (max(nwater // 8, 1000), max(nwind // 8, 250 if nwind else 0)) if nwater > 8000 else (nwater, nwind)
                 cpu = cpu_baseline(soil, n, cw, cd, args.cpu_ticks, pool, all_cores=True)
-        p2 = "P2: deterministic (== CPU restatement bit for bit), statistical vs the reference (parity_vs_reference); never claimed bit-exact"
+        p2 = "P2: deterministic (== CPU restatement bit for bit), statistical vs the reference (parity_gate, parity_vs_reference); never claimed bit-exact"
         exact_rec = None                                        # the bit-exact engine on this workload: a RECORD of an earlier run, read from its file (never a literal)
         if throughput and n == 4096 and nwater == 64000 and soil == SOIL:
             for pf in ("r05_exact_area_scaled_4096.json", "r04_exact_area_scaled_4096.json"):
@@ -621,7 +729,18 @@ def main():
                     break
                 except (OSError, ValueError, KeyError):
                     pass
-        config = {"workload": workload, "engine": eng_name, "water_generations": (args.water_generations or 4) if throughput else None,
+        hrec = headline_parity_record(r.get("water_generations"), world if strips else 1) if (throughput and n == 4096 and nwater // max(world if (strips and not args.strong) else 1, 1) == 64000 and soil == SOIL) else None
+        # parity_gate: the rule of tests/test_gpu_relaxed.py (nothing at |z| >= 3, at most one figure in [2, 3)) applied to THIS run's own check against the
+        # reference (1024^2, 16 control streams) and to the committed record at the headline's size; "fail" if either breaks it
+        g_run = (pref or {}).get("gate") if isinstance(pref, dict) else None
+        g_rec = (hrec or {}).get("gate")
+        if not throughput:
+            parity_gate = {"verdict": "exact", "note": "bit-identical to the reference (tests/golden, tests/test_gpu_parity.py)"}
+        else:
+            verdict = "unmeasured" if (g_run is None and g_rec is None) else ("fail" if ((g_run and not g_run["pass"]) or (g_rec and not g_rec["pass"])) else "pass")
+            parity_gate = {"verdict": verdict, "rule": "no figure at |z| >= 3, at most one in [2, 3) (eight figures, z against the reference's own rand()-stream spread)",
+                           "this_run_1024": g_run, "headline_size_record": ({"file": hrec["file"], "variant": hrec["variant"], "gate": g_rec, "outliers": hrec["outliers"]} if hrec else None)}
+        config = {"workload": workload, "engine": eng_name, "water_generations": r.get("water_generations") if throughput else None,
                   "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
                   "parity": p2 if throughput else head["parity"]}
         detail = {
@@ -638,7 +757,7 @@ def main():
             "ms_per_tick": 1e3 * tmax / args.steps, "phase_ms_per_tick": head["phase_ms_per_tick"],
             "per_tick": r.get("per_tick"),
             "steps_per_tick": head["steps_per_tick"], "engine_stats": head["engine_stats"], "digest": head["digest"],
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_exact": parity, "parity_vs_reference": pref, "lines": lines, "lbm_wind": lbm,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_exact": parity, "parity_vs_reference": pref, "parity_gate": parity_gate, "lines": lines, "lbm_wind": lbm,
             # nothing was dropped inside the timed region (nested particles that did not fit the children buffer, sediment
             # that found no pool node): a line with work skipped would not be a measurement
             "work_dropped": {"children_lost": int(head["engine_stats"].get("children_lost", 0)), "pool_overflow": int(head.get("pool_overflow") or 0)},
@@ -658,11 +777,12 @@ def main():
             except OSError:
                 detail_path = None
         print(json.dumps(compact_line(detail, detail_path), default=float, separators=(",", ":"), allow_nan=False), flush=True)
-    try:
-        if not strips and ckpt:
-            os.remove(ckpt)
-    except (OSError, NameError):
-        pass
+    for f_ in ("ckpt", "ckpt2"):
+        try:
+            if not strips and locals().get(f_):
+                os.remove(locals()[f_])
+        except (OSError, NameError):
+            pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

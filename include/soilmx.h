@@ -76,6 +76,8 @@ typedef struct smx_counters {
   uint64_t spec_subphases_cut;     /* speculative engine: sub-phases that ended early (nested-slot budget used up) and were re-armed  */
   uint64_t spec_serial_particles;  /* ... single particles run by the serial walker between two sub-phases (more nested particles    */
                                    /*     than a sub-phase has slots)                                                                */
+  uint64_t flood_nested_steps;     /* round 6 (sized getter only): steps of the nested particles that ran INSIDE floods of the relaxed  */
+  uint64_t grid_nested_steps;      /* schedule / INSIDE grid tiles -- both are part of steps_water_all; bench.py prices those launches */
 } smx_counters;
 
 /* Elapsed device time of the phases of the last smx_tick* calls, measured with HIP events on the
@@ -102,6 +104,9 @@ typedef struct smx_timing {
    * and the generations of suspended nested particles the grid pass leaves behind (part of ms_grid) */
   double ms_kernel_epochs, ms_kernel_tail, ms_kernel_grid_children;
   uint64_t launches_kernel_epochs, epochs_kernel_epochs, launches_kernel_tail, epochs_kernel_tail, launches_kernel_grid_children;
+  /* k_relax_floods: every 7th launch of a context is bracketed (ms / launches_kernel_floods); launches_floods_all counts every launch */
+  double ms_kernel_floods;
+  uint64_t launches_kernel_floods, launches_floods_all;
 } smx_timing;
 
 /* ---- life cycle: replaces Layermap::Layermap + secpool::reserve (layermap.h:64-119,218-226) ---- */
@@ -285,6 +290,9 @@ int smx_strips_attach_rccl(smx_ctx* ctx, const void* unique_id128, int32_t rank,
 int smx_strips_attach(smx_ctx* ctx, const smx_transport* t, int32_t rank, int32_t world, int32_t inset, int32_t seam_halfwidth);
 int smx_strips_detach(smx_ctx* ctx);
 int smx_strips_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater, int32_t dowind);
+/* what the transport itself cost since it was attached: stream synchronisations it asked for and ncclGroupStart/End pairs (RCCL: 2 groups and at most
+ * 2 synchronisations per seam exchange since round 6 -- pack counts, incoming header --, plus one per all-reduce) */
+int smx_strips_sync_stats(smx_ctx* ctx, uint64_t* host_syncs, uint64_t* groups);
 int smx_strips_stats(smx_ctx* ctx, uint64_t* chunks, uint64_t* seam_chunks, uint64_t* generations, uint64_t* bytes_sent, uint64_t* messages);
 /* batched engine: epochs (kernel rounds), generations and dropped child particles since the context was created */
 int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost);

@@ -28,7 +28,8 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
         "cascade_transfers", "wcascade_calls", "grid_active_cells", "rand_calls", "pool_free", "pool_overflow",
-        "spec_rounds", "spec_aborts")] + [("reserved", C.c_uint64 * 2), ("spec_subphases_cut", C.c_uint64), ("spec_serial_particles", C.c_uint64)]
+        "spec_rounds", "spec_aborts")] + [("reserved", C.c_uint64 * 2), ("spec_subphases_cut", C.c_uint64), ("spec_serial_particles", C.c_uint64),
+                                           ("flood_nested_steps", C.c_uint64), ("grid_nested_steps", C.c_uint64)]
 
     def as_dict(self) -> dict:
         d = {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
@@ -60,7 +61,8 @@ class Timing(C.Structure):
                 ("launches_step_water", C.c_uint64), ("launches_step_wind", C.c_uint64),
                 ("ms_kernel_epochs", C.c_double), ("ms_kernel_tail", C.c_double), ("ms_kernel_grid_children", C.c_double),
                 ("launches_kernel_epochs", C.c_uint64), ("epochs_kernel_epochs", C.c_uint64), ("launches_kernel_tail", C.c_uint64),
-                ("epochs_kernel_tail", C.c_uint64), ("launches_kernel_grid_children", C.c_uint64)]
+                ("epochs_kernel_tail", C.c_uint64), ("launches_kernel_grid_children", C.c_uint64),
+                ("ms_kernel_floods", C.c_double), ("launches_kernel_floods", C.c_uint64), ("launches_floods_all", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -73,7 +75,7 @@ SYMBOLS = [
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
     "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices", "smx_fill_vertices_cut", "smx_fill_vertex_cut",
-    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_get_counters_sized", "smx_get_timing_sized", "smx_timing_reset", "smx_set_engine", "smx_set_spec_limits", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind", "smx_set_relax_launch", "smx_set_grid_interleave", "smx_set_water_generations", "smx_get_water_generations", "smx_strips_rccl_unique_id", "smx_strips_attach_rccl", "smx_strips_attach", "smx_strips_detach", "smx_strips_tick", "smx_strips_stats",
+    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_get_counters_sized", "smx_get_timing_sized", "smx_timing_reset", "smx_set_engine", "smx_set_spec_limits", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind", "smx_set_relax_launch", "smx_set_grid_interleave", "smx_set_water_generations", "smx_get_water_generations", "smx_strips_rccl_unique_id", "smx_strips_attach_rccl", "smx_strips_attach", "smx_strips_detach", "smx_strips_tick", "smx_strips_stats", "smx_strips_sync_stats",
     "smx_d_set_own", "smx_d_gen_begin", "smx_d_gen_spawn", "smx_d_next_phase", "smx_d_chunk", "smx_d_gen_end", "smx_d_pack_columns",
     "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep_cols",
     "smx_lbm_create", "smx_lbm_destroy", "smx_lbm_last_error", "smx_lbm_set_boundary", "smx_lbm_boundary_from_map", "smx_lbm_initialize",
@@ -152,6 +154,7 @@ def load() -> C.CDLL:
     L.smx_strips_detach.argtypes = [vp]
     L.smx_strips_tick.argtypes = [vp, i32, i32, i32, i32]
     L.smx_strips_stats.argtypes = [vp] + [C.POINTER(u64)] * 5
+    L.smx_strips_sync_stats.argtypes = [vp] + [C.POINTER(u64)] * 2
     L.smx_d_set_own.argtypes = [vp, i32, i32]
     L.smx_d_gen_begin.argtypes = [vp, i32, u32, vp, vp]
     L.smx_d_gen_spawn.argtypes = [vp, vp, C.POINTER(u32)]

@@ -69,7 +69,8 @@ struct RandState {   // glibc TYPE_3 additive feedback generator: r[i] = r[i-31]
 };
 
 enum Ctr { C_STEPS_WATER_TOP = 0, C_STEPS_WATER_ALL, C_STEPS_WIND, C_NESTED, C_FLOODS, C_CASCADE_CALLS,
-           C_CASCADE_TRANSFERS, C_WCASCADE_CALLS, C_GRID_ACTIVE, C_POOL_OVERFLOW, C_LIVE_SECTIONS, C_COUNT };
+           C_CASCADE_TRANSFERS, C_WCASCADE_CALLS, C_GRID_ACTIVE, C_POOL_OVERFLOW, C_LIVE_SECTIONS,
+           C_FLOOD_NESTED_STEPS, C_GRID_NESTED_STEPS /* steps of nested particles run INSIDE floods / grid tiles (device kernels only: the bench's algorithmic bytes) */, C_COUNT };
 
 struct DevState {
   int dimx, dimy, scale;
@@ -1115,6 +1116,12 @@ struct Sim {
   SMX_D void water_drive(Water& p, bool toplevel, bool start_with_particle, Frame* st, int& depth, bool resume = false,
                          bool loop_done = false) {
     bool have = start_with_particle;
+    // The TOP frame lives in registers (`f`); the stack array -- dynamically indexed, hence scratch memory on the device -- is written when a frame is
+    // pushed over it and read when a frame is popped back to, not on every field access of every neighbour iteration (round 6: ~4 dependent scratch
+    // loads per iteration before). `top` = st[depth - 1] is cached in f; every push_frame below is preceded by a write-back.
+    Frame f; bool top = false;
+    f.ix = f.iy = f.spill = f.num = f.i = 0; f.codes = f.cand = f.stamp = 0u;
+#define SMX_FRAME_WRITE_BACK() do { if (top) { st[depth - 1] = f; top = false; } } while (0)
     while (true) {
       if constexpr (P::DEFER_NESTED) {
         // throughput engines: a nested particle (spawned below) runs here, at once, inside the cells this thread owns; what does not
@@ -1122,7 +1129,7 @@ struct Sim {
         if (have) {
           have = false;
           if (pol.run_nested(*this, p) == 0 && !(p.volume < 0.01 || p.spill <= 0) && pol.flood_fits(*this, p)) {   // water.h:125 gate, then :123-145
-            if (water_flood_prelude(p)) push_frame(st, depth, p.ix, p.iy, p.spill);
+            if (water_flood_prelude(p)) { SMX_FRAME_WRITE_BACK(); push_frame(st, depth, p.ix, p.iy, p.spill); }
           }
         }
       } else
@@ -1141,13 +1148,13 @@ struct Sim {
             }
           return;
         }
-        if (water_flood_prelude(p)) push_frame(st, depth, p.ix, p.iy, p.spill);   // :140
+        if (water_flood_prelude(p)) { SMX_FRAME_WRITE_BACK(); push_frame(st, depth, p.ix, p.iy, p.spill); }   // :140
         if (ab) return;
         have = false;
       }
       if (depth == 0) return;
-      Frame& f = st[depth - 1];
-      if (f.i >= f.num) { depth--; continue; }
+      if (!top) { f = st[depth - 1]; top = true; }
+      if (f.i >= f.num) { depth--; top = false; continue; }
       const int k = (f.codes >> (4 * f.i)) & 15;
       f.i++;
       if constexpr (exclusive_access<P>::value) { if (f.stamp == n_mod && !((f.cand >> k) & 1u)) continue; }   // (push_frame: nothing to do there, decided on registers)
@@ -1206,11 +1213,13 @@ struct Sim {
         if (R.type != EMPTY) { R.sat = 1.0f; on_sat(bx, by); }
         if (recascade && f.spill > 0) {                     // :278-279 cascade(npos, --spill)
           const int sp = --f.spill;
+          SMX_FRAME_WRITE_BACK();
           push_frame(st, depth, nx, ny, sp);
         }
         if (ab) return;
       }
     }
+#undef SMX_FRAME_WRITE_BACK
   }
 
   // ---------------- WindParticle wind.h:11-138 ----------------

@@ -21,7 +21,16 @@ static_assert(sizeof(XBundle) == 32, "seam message header");
 struct StripTransport {
   int rank = 0, world = 1;
   uint64_t bytes_sent = 0, messages = 0;
+  uint64_t host_syncs = 0, groups = 0;                        // stream synchronisations the transport itself asked for; ncclGroupStart/End pairs (smx_strips_sync_stats)
   virtual ~StripTransport() {}
+  // ONE seam exchange of this rank: `out` goes to send_peer, `in` comes from recv_peer (-1: this rank has no such neighbour). Default -- blocking host
+  // callbacks --: send, then receive; ranks are visited left to right, so the dependent operations resolve from rank 0 upward and cannot deadlock.
+  // The RCCL transport posts both directions together (round 6): no rank's receive waits behind its own send any more.
+  virtual int exchange(smx_ctx* ctx, int send_peer, const XBundle* out, int recv_peer, XBundle* in) {
+    if (send_peer >= 0 && send_bundle(ctx, send_peer, *out)) return -1;
+    if (recv_peer >= 0 && recv_bundle(ctx, recv_peer, *in)) return -1;
+    return 0;
+  }
   // payload of a send: ctx->d_xoffs (4*nrec bytes), ctx->d_xdata (nbytes), ctx->d_xpart (npart*rs); of a receive: d_roffs, d_rdata, d_rpart
   virtual int send_bundle(smx_ctx* ctx, int peer, const XBundle& b) = 0;
   virtual int recv_bundle(smx_ctx* ctx, int peer, XBundle& b) = 0;
@@ -85,12 +94,55 @@ struct RcclTransport : StripTransport {
     hipStream_t st = ctx->stream;
     NCCLCHK(g_rccl.Recv(&d_hdr[1], sizeof(XBundle), ncclUint8, peer, comm, st));
     HIPCHK(hipMemcpyAsync(&b, &d_hdr[1], sizeof(b), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));                         // the payload sizes decide the receives that follow
+    HIPCHK(hipStreamSynchronize(st)); host_syncs++;           // the payload sizes decide the receives that follow
     if (b.nrec > ctx->xoffs_cap || b.nbytes > ctx->xdata_cap || (uint64_t)b.npart * b.rs > ctx->xpart_cap) { ctx->err = "strips: incoming seam message exceeds the exchange buffers"; return -2; }
     NCCLCHK(g_rccl.GroupStart());
     if (b.nrec) { NCCLCHK(g_rccl.Recv(ctx->d_roffs, 4ull * b.nrec, ncclUint8, peer, comm, st)); NCCLCHK(g_rccl.Recv(ctx->d_rdata, b.nbytes, ncclUint8, peer, comm, st)); }
     if (b.npart) NCCLCHK(g_rccl.Recv(ctx->d_rpart, (size_t)b.npart * b.rs, ncclUint8, peer, comm, st));
     NCCLCHK(g_rccl.GroupEnd());
+    return 0;
+  }
+  // Both directions of a seam exchange in TWO grouped operations (round 6): {header out, header in}, one stream synchronisation
+  // for the incoming sizes, {payloads out, payloads in}. Rounds 3-5 issued send (header, payloads) and then receive (header, sync, payloads) one after
+  // the other on the stream: rank r's receive from r + 1 sat behind its own send to r - 1, whose completion needs r - 1's receive, which sat behind
+  // r - 1's send ... -- an (N - 1)-hop chain of dependent point-to-point kernels per exchange. Inside one ncclGroup the operations progress together.
+  int exchange(smx_ctx* ctx, int send_peer, const XBundle* out, int recv_peer, XBundle* in) override {
+    hipStream_t st = ctx->stream;
+    if (send_peer < 0 && recv_peer < 0) return 0;
+    if (!h_hdr) HIPCHK(hipHostMalloc(&h_hdr, HDR_RING * sizeof(XBundle)));
+    XBundle* hin = &h_hdr[hdr_slot++ % HDR_RING];
+    if (send_peer >= 0) {
+      XBundle* slot = &h_hdr[hdr_slot++ % HDR_RING];
+      *slot = *out;
+      HIPCHK(hipMemcpyAsync(&d_hdr[0], slot, sizeof(XBundle), hipMemcpyHostToDevice, st));
+    }
+    NCCLCHK(g_rccl.GroupStart());
+    if (send_peer >= 0) NCCLCHK(g_rccl.Send(&d_hdr[0], sizeof(XBundle), ncclUint8, send_peer, comm, st));
+    if (recv_peer >= 0) NCCLCHK(g_rccl.Recv(&d_hdr[1], sizeof(XBundle), ncclUint8, recv_peer, comm, st));
+    NCCLCHK(g_rccl.GroupEnd());
+    groups++;
+    XBundle bi;
+    if (recv_peer >= 0) {
+      HIPCHK(hipMemcpyAsync(hin, &d_hdr[1], sizeof(XBundle), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st)); host_syncs++;        // the payload sizes decide the receives that follow
+      bi = *hin; *in = bi;
+      if (bi.nrec > ctx->xoffs_cap || bi.nbytes > ctx->xdata_cap || (uint64_t)bi.npart * bi.rs > ctx->xpart_cap) { ctx->err = "strips: incoming seam message exceeds the exchange buffers"; return -2; }
+    }
+    const bool so = send_peer >= 0 && (out->nrec || out->npart), si = recv_peer >= 0 && (bi.nrec || bi.npart);
+    if (so || si) {
+      NCCLCHK(g_rccl.GroupStart());
+      if (so) {
+        if (out->nrec) { NCCLCHK(g_rccl.Send(ctx->d_xoffs, 4ull * out->nrec, ncclUint8, send_peer, comm, st)); NCCLCHK(g_rccl.Send(ctx->d_xdata, out->nbytes, ncclUint8, send_peer, comm, st)); }
+        if (out->npart) NCCLCHK(g_rccl.Send(ctx->d_xpart, (size_t)out->npart * out->rs, ncclUint8, send_peer, comm, st));
+      }
+      if (si) {
+        if (bi.nrec) { NCCLCHK(g_rccl.Recv(ctx->d_roffs, 4ull * bi.nrec, ncclUint8, recv_peer, comm, st)); NCCLCHK(g_rccl.Recv(ctx->d_rdata, bi.nbytes, ncclUint8, recv_peer, comm, st)); }
+        if (bi.npart) NCCLCHK(g_rccl.Recv(ctx->d_rpart, (size_t)bi.npart * bi.rs, ncclUint8, recv_peer, comm, st));
+      }
+      NCCLCHK(g_rccl.GroupEnd());
+      groups++;
+    }
+    if (send_peer >= 0) { bytes_sent += sizeof(XBundle) + 4ull * out->nrec + out->nbytes + (uint64_t)out->npart * out->rs; messages++; }
     return 0;
   }
   int allreduce_sum(smx_ctx* ctx, uint64_t& v) override {
@@ -99,7 +151,7 @@ struct RcclTransport : StripTransport {
     HIPCHK(hipMemcpyAsync(d_coll, &h, 8, hipMemcpyHostToDevice, st));
     NCCLCHK(g_rccl.AllReduce(d_coll, d_coll + 1, 1, ncclUint64, ncclSum, comm, st));
     HIPCHK(hipMemcpyAsync(&h, d_coll + 1, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(st)); host_syncs++;
     v = h;
     return 0;
   }
@@ -229,39 +281,36 @@ static int xbuf_alloc_strips(smx_ctx* ctx) {                  // exchange buffer
   }
   return 0;
 }
-// dirty halo columns of [cx0, cx1) and (optionally) the running particles of [px0, px1): packed on the device, handed to the transport
-static int st_send_band(smx_ctx* ctx, StripState& S, int peer, int cx0, int cx1, int px0, int px1, bool particles) {
+// dirty halo columns of [cx0, cx1) and (optionally) the running particles of [px0, px1): packed on the device; the header says how much
+// (both pack kernels run back to back, their two cursors come home with ONE stream synchronisation -- rounds 3-5: one per kernel)
+static int st_pack_band(smx_ctx* ctx, StripState& S, int cx0, int cx1, int px0, int px1, bool particles, XBundle& b) {
   hipStream_t st = ctx->stream;
   if (batch_alloc(ctx, 1, false) || xbuf_alloc_strips(ctx)) return -1;
-  XBundle b;
+  b = XBundle();
   if (cx0 < 0) cx0 = 0; if (cx1 > ctx->cfg.dimx) cx1 = ctx->cfg.dimx;
   const int gx0 = cx0 >> 2, gx1 = (cx1 + 3) >> 2, gty = (ctx->cfg.dimy + 3) >> 2;
   const long long nt = (long long)(gx1 - gx0) * gty;
-  XCursor c{};
-  HIPCHK(hipMemsetAsync(ctx->d_xcur, 0, sizeof(XCursor), st));
+  XCursor c[2] = {};
+  HIPCHK(hipMemsetAsync(ctx->d_xcur, 0, 2 * sizeof(XCursor), st));
   if (nt > 0) hipLaunchKernelGGL(k_strip_pack_columns, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, st, ctx->d, ctx->bs, gx0, gx1, ctx->d_xdata, ctx->xdata_cap, ctx->d_xoffs, ctx->xoffs_cap, ctx->d_xcur);
-  HIPCHK(hipMemcpyAsync(&c, ctx->d_xcur, sizeof(c), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (c.lost) { ctx->err = "strips: exchange buffer too small for the halo columns"; return -2; }
-  b.nrec = c.nrec; b.nbytes = (uint32_t)c.bytes;
-  b.rs = (uint32_t)(4 + (ctx->d_wind ? sizeof(BWind) : sizeof(BWater)));
-  if (particles && ctx->d_nslots) {
+  const bool parts = particles && ctx->d_nslots;
+  if (parts) {
     const uint32_t nslots = ctx->d_nslots;
-    HIPCHK(hipMemsetAsync(ctx->d_xcur, 0, sizeof(XCursor), st));
-    if (ctx->d_wind) hipLaunchKernelGGL(k_strip_pack_particles<true>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, ctx->bs, nslots, px0, px1, ctx->d_xpart, ctx->xpart_cap, ctx->d_xcur);
-    else hipLaunchKernelGGL(k_strip_pack_particles<false>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, ctx->bs, nslots, px0, px1, ctx->d_xpart, ctx->xpart_cap, ctx->d_xcur);
-    HIPCHK(hipMemcpyAsync(&c, ctx->d_xcur, sizeof(c), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (c.lost) { ctx->err = "strips: exchange buffer too small for the migrating particles"; return -2; }
-    b.npart = c.nrec;
+    if (ctx->d_wind) hipLaunchKernelGGL(k_strip_pack_particles<true>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, ctx->bs, nslots, px0, px1, ctx->d_xpart, ctx->xpart_cap, ctx->d_xcur + 1);
+    else hipLaunchKernelGGL(k_strip_pack_particles<false>, dim3((nslots + 255u) / 256u), dim3(256), 0, st, ctx->bs, nslots, px0, px1, ctx->d_xpart, ctx->xpart_cap, ctx->d_xcur + 1);
   }
-  return S.T->send_bundle(ctx, peer, b);
+  HIPCHK(hipMemcpyAsync(c, ctx->d_xcur, 2 * sizeof(XCursor), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st)); S.T->host_syncs++;
+  if (c[0].lost) { ctx->err = "strips: exchange buffer too small for the halo columns"; return -2; }
+  if (c[1].lost) { ctx->err = "strips: exchange buffer too small for the migrating particles"; return -2; }
+  b.nrec = c[0].nrec; b.nbytes = (uint32_t)c[0].bytes;
+  b.rs = (uint32_t)(4 + (ctx->d_wind ? sizeof(BWind) : sizeof(BWater)));
+  if (parts) b.npart = c[1].nrec;
+  (void)S;
+  return 0;
 }
-static int st_recv_band(smx_ctx* ctx, StripState& S, int peer) {
+static int st_unpack_band(smx_ctx* ctx, const XBundle& b) {
   hipStream_t st = ctx->stream;
-  if (batch_alloc(ctx, 1, false) || xbuf_alloc_strips(ctx)) return -1;
-  XBundle b;
-  if (S.T->recv_bundle(ctx, peer, b)) return -1;
   if (b.nrec) {
     hipLaunchKernelGGL(k_strip_unpack_columns, dim3((b.nrec + 63u) / 64u), dim3(64), 0, st, ctx->d, ctx->bs, ctx->d_rdata, ctx->d_roffs, b.nrec, b.nbytes);
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, ctx->bs);
@@ -274,18 +323,23 @@ static int st_recv_band(smx_ctx* ctx, StripState& S, int peer) {
   HIPCHK(hipGetLastError());
   return 0;
 }
+// one seam exchange: what this rank packs goes to `send_peer`, what `recv_peer` packed comes in and is unpacked (StripTransport::exchange)
+static int st_exchange(smx_ctx* ctx, StripState& S, int send_peer, int cx0, int cx1, int px0, int px1, bool particles, int recv_peer) {
+  if (batch_alloc(ctx, 1, false) || xbuf_alloc_strips(ctx)) return -1;
+  XBundle out, in;
+  if (send_peer >= 0 && st_pack_band(ctx, S, cx0, cx1, px0, px1, particles, out)) return -1;
+  if (S.T->exchange(ctx, send_peer, &out, recv_peer, &in)) return -1;
+  if (recv_peer >= 0 && st_unpack_band(ctx, in)) return -1;
+  return 0;
+}
 // A rank holds, besides its strip, the b columns right of its right boundary (the seam zone it runs).
 static int st_band_to_left(smx_ctx* ctx, StripState& S, bool particles) {     // band [x0, x0+b) of this strip -> the rank on the left (which runs that seam)
   const int r = S.T->rank, n = S.T->world;
-  if (r > 0 && st_send_band(ctx, S, r - 1, S.x0, S.x0 + S.geo.b, S.x0, S.x0 + S.geo.b, particles)) return -1;
-  if (r < n - 1 && st_recv_band(ctx, S, r + 1)) return -1;
-  return 0;
+  return st_exchange(ctx, S, r > 0 ? r - 1 : -1, S.x0, S.x0 + S.geo.b, S.x0, S.x0 + S.geo.b, particles, r < n - 1 ? r + 1 : -1);
 }
 static int st_band_to_right(smx_ctx* ctx, StripState& S, bool particles) {    // the halo [x1, x1+b) goes home, with every particle that sits beyond x1
   const int r = S.T->rank, n = S.T->world;
-  if (r < n - 1 && st_send_band(ctx, S, r + 1, S.x1, S.x1 + S.geo.b, S.x1, ctx->cfg.dimx, particles)) return -1;
-  if (r > 0 && st_recv_band(ctx, S, r - 1)) return -1;
-  return 0;
+  return st_exchange(ctx, S, r < n - 1 ? r + 1 : -1, S.x1, S.x1 + S.geo.b, S.x1, ctx->cfg.dimx, particles, r > 0 ? r - 1 : -1);
 }
 static int st_gather_sorted(smx_ctx* ctx, StripState& S, std::vector<BChild>& kids) {   // this rank's new children -> everybody's, in key order
   uint32_t nc = 0;
@@ -413,6 +467,11 @@ int smx_strips_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater
   }
   if (dowind) { roctx_range rd("soilmx:strips:wind"); if (st_phase(ctx, S, true, nwind > 0 ? (uint32_t)nwind : 0u, {}, false)) return -1; }
   if (dowater) { if (smx_map_frequency(ctx)) return -1; if (smx_reset_frequency(ctx)) return -1; }
+  return 0;
+}
+int smx_strips_sync_stats(smx_ctx* ctx, uint64_t* host_syncs, uint64_t* groups) {   // what the transport itself cost: stream synchronisations, grouped operations
+  if (!ctx->strip) return -2;
+  if (host_syncs) *host_syncs = ctx->strip->T->host_syncs; if (groups) *groups = ctx->strip->T->groups;
   return 0;
 }
 int smx_strips_stats(smx_ctx* ctx, uint64_t* chunks, uint64_t* seam_chunks, uint64_t* generations, uint64_t* bytes_sent, uint64_t* messages) {

@@ -332,6 +332,11 @@ __device__ __forceinline__ void relax_commit_cascade_counters(const DevState& s,
   for (int off = 32; off > 0; off >>= 1) { nc += (unsigned long long)__shfl_down((long long)nc, off); nt += (unsigned long long)__shfl_down((long long)nt, off); }
   if ((threadIdx.x & 63u) == 0) { if (nc) atomicAdd(&s.ctr[C_CASCADE_CALLS], nc); if (nt) atomicAdd(&s.ctr[C_CASCADE_TRANSFERS], nt); }
 }
+// steps of the nested particles that ran inside this launch's floods (C_FLOOD_NESTED_STEPS: what bench.py prices a flood launch with)
+__device__ __forceinline__ void relax_commit_flood_steps(const DevState& s, unsigned long long n) {
+  for (int off = 32; off > 0; off >>= 1) n += (unsigned long long)__shfl_down((long long)n, off);
+  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&s.ctr[C_FLOOD_NESTED_STEPS], n);
+}
 __global__ void __launch_bounds__(64) k_relax_filter(DevState s, BatchShared bs, uint32_t epoch) {
   const uint32_t par = epoch & 1u;
   uint32_t n = bs.ctrl[BC_NFLAG + par];
@@ -408,10 +413,41 @@ __global__ void __launch_bounds__(64) k_relax_cascade_flow(DevState s, BatchShar
   }
   if (threadIdx.x == 0) { if (nc) atomicAdd(&s.ctr[C_CASCADE_CALLS], nc); if (nt) atomicAdd(&s.ctr[C_CASCADE_TRANSFERS], nt); }
 }
+// ---------------- cache warm-up by the idle lanes (round 6) ----------------
+// A flood and a grid tile are ONE lane's dependent chain through a small rectangle of the map: the 32-byte records of its cells, their flag
+// bytes, the water frequency / track words its nested particles read. Every launch starts cold -- the cells were last written by other CUs,
+// on other XCDs, whose L2s are not coherent with this one: the first touch of a line comes from the fabric at 1-2 us -- and the chain
+// touches them one after the other (rocprofv3 --pmc, profiles/r06_pmc.json: k_relax_floods spends 80 % of its wave cycles waiting, 2 000
+// VALU instructions per flood; k_grid_tiles_flow 91 %). The 63 lanes that have nothing to do fetch the whole rectangle at once, one 4-byte
+// load per 128-byte line: one round trip in parallel instead of ~50 in sequence; the chain then runs out of this CU's L1 / this XCD's L2.
+// Loads only: no result can depend on it. `sink` keeps the loads alive (it is compared with a value it never takes).
+__device__ __forceinline__ void warm_region(const DevState& s, int x0, int x1, int y0, int y1, uint32_t lane, uint32_t nlanes, uint32_t& sink) {
+  if (x0 < s.x_lo) x0 = s.x_lo; if (x1 > s.x_hi - 1) x1 = s.x_hi - 1;
+  if (y0 < 0) y0 = 0; if (y1 > s.dimy - 1) y1 = s.dimy - 1;
+  if (x1 < x0 || y1 < y0) return;
+  const uint32_t nx = (uint32_t)(x1 - x0 + 1), ny = (uint32_t)(y1 - y0 + 1);
+  const uint32_t nch = (ny + 3u) / 4u + 1u;                   // a row of cells: one touch per 4 records (128 bytes) + the row's last record
+  for (uint32_t t = lane; t < nx * nch; t += nlanes) {
+    const int x = x0 + (int)(t / nch); int y = y0 + 4 * (int)(t % nch); if (y > y1) y = y1;
+    sink ^= s.cells[(size_t)x * s.dimy + y].type;
+  }
+  for (uint32_t t = lane; t < 2u * nx; t += nlanes) {         // flag bytes: a row's first and last (12-24 bytes apart: one or two lines)
+    const int x = x0 + (int)(t >> 1);
+    sink ^= (uint32_t)s.flags[(size_t)x * s.dimy + ((t & 1u) ? y1 : y0)];
+  }
+  for (uint32_t t = lane; t < 4u * ny; t += nlanes) {         // frequency / track words (index y * dimx + x: rows run along x)
+    const int y = y0 + (int)(t >> 2);
+    const size_t fi = (size_t)y * s.dimx + ((t & 1u) ? x1 : x0);
+    sink ^= __float_as_uint((t & 2u) ? s.wtrack[fi] : s.wfreq[fi]);
+  }
+}
+__device__ __forceinline__ void warm_sink(const BatchShared& bs, uint32_t sink) {   // (never true: the loads above must not be optimised away)
+  if (sink == 0x7F4A7C15u && blockIdx.x == 0x7FFFFFFFu) bs.ctrl[BC_COUNT - 1] = sink;
+}
 // the floods of the relaxed schedule: batch_water_epoch over this epoch's list of ended particles; who is not done joins the next
 // list. The launch has a fixed number of wavefronts; the floods are spread over them as thinly as the list allows (a wavefront costs
 // the union of its lanes' paths, and a flood is a long, branchy path).
-__global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs, uint32_t epoch) {
+__global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs, uint32_t epoch, uint32_t warm) {
   const uint32_t par = epoch & 1u;
   uint32_t n = bs.ctrl[BC_NFLOOD + par];
   if (n > bs.list_cap) n = bs.list_cap;
@@ -428,16 +464,37 @@ __global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs,
     relax_flood_later(bs, slot, par ^ 1u, act);
     return;
   }
+  unsigned long long nst = 0;
+  if (act) slot = bs.flist[par][i];
+  if (warm) {                                                 // the floods of this wavefront that hold their tiles: their rectangles, fetched by all 64 lanes
+    int rx0 = 0, rx1 = -1, ry0 = 0, ry1 = -1;
+    if (act) {
+      const BWater& q = bs.water[slot];
+      const BRect r = q.rect;
+      const unsigned long long tag = btag(epoch, slot);
+      bool holds = q.state == B_ENDED && !brect_empty(r) && r.tx0 >= bs.txb && r.tx1 < bs.txe;
+      if (holds)
+        for (int tx = r.tx0; tx <= r.tx1; tx++)
+          for (int ty = r.ty0; ty <= r.ty1; ty++) holds &= (bs.claim[epoch & 1u][(size_t)(tx - bs.txb) * bs.nty + ty] == tag);
+      if (holds) { rx0 = r.tx0 << bs.tshift; rx1 = ((r.tx1 + 1) << bs.tshift) - 1; ry0 = r.ty0 << bs.tshift; ry1 = ((r.ty1 + 1) << bs.tshift) - 1; }
+    }
+    uint32_t sink = 0u;
+    for (uint32_t j = 0; j < lpw; j++) {
+      const int ax0 = __shfl(rx0, (int)j), ax1 = __shfl(rx1, (int)j), ay0 = __shfl(ry0, (int)j), ay1 = __shfl(ry1, (int)j);
+      if (ax1 >= ax0) warm_region(s, ax0, ax1, ay0, ay1, threadIdx.x, 64u, sink);
+    }
+    warm_sink(bs, sink);
+  }
   if (act) {
-    slot = bs.flist[par][i];
     BatchPolicy pol(s, bs);
     Sim<BatchPolicy> sim(s, sh, pol);
     Frame st[MAX_FRAMES];
     batch_water_epoch(sim, bs, slot, epoch, st);
-    sim.flush_counters(); pol.finish(s);
+    sim.flush_counters(); nst = pol.a_nsteps; pol.finish(s);
     again = bs.water[slot].state == B_ENDED;
   }
   relax_flood_later(bs, slot, par ^ 1u, again);
+  relax_commit_flood_steps(s, nst);
 }
 // The tail of a relaxed water generation (a few hundred particles left, for hundreds of epochs; and every nested generation after
 // its first steps): ONE workgroup runs whole epochs back to back -- step, apply, filter, nine cascade colours, floods -- with
@@ -506,6 +563,7 @@ __global__ void __launch_bounds__(256) k_relax_tail(DevState s, BatchShared bs, 
       uint32_t n = SMX_A_LOAD(&bs.ctrl[BC_NFLOOD + par]);
       if (n > bs.list_cap) n = bs.list_cap;
       const bool due = relax_floods_due(bs, epoch, n, SMX_A_LOAD(&bs.ctrl[BC_NRUN + par]));
+      unsigned long long nst = 0;
       for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
         const uint32_t i = i0 + threadIdx.x;
         bool again = false; uint32_t slot = 0u;
@@ -516,11 +574,12 @@ __global__ void __launch_bounds__(256) k_relax_tail(DevState s, BatchShared bs, 
           Sim<BatchPolicy> sim(s, sh, pol);
           Frame st[MAX_FRAMES];
           batch_water_epoch(sim, bs, slot, epoch, st);
-          sim.flush_counters(); pol.finish(s);
+          sim.flush_counters(); nst += pol.a_nsteps; pol.finish(s);
           again = bs.water[slot].state == B_ENDED;
         }
         relax_flood_later(bs, slot, par ^ 1u, again);
       }
+      relax_commit_flood_steps(s, nst);
     }
     __syncthreads();
   }
@@ -689,6 +748,7 @@ __global__ void __launch_bounds__(256) k_relax_epochs(DevState s, BatchShared bs
       if (n > bs.list_cap) n = bs.list_cap;
       if (n) {
         const bool due = relax_floods_due(bs, epoch, n, __hip_atomic_load(&bs.ctrl[BC_NRUN + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        unsigned long long nst = 0;
         for (uint32_t i0 = gw; i0 < n; i0 += 64u * NW) {
           const uint32_t i = i0 + lane * NW;
           bool again = false; uint32_t slot = 0u;
@@ -699,11 +759,12 @@ __global__ void __launch_bounds__(256) k_relax_epochs(DevState s, BatchShared bs
             Sim<BatchPolicy> sim(s, sh, pol);
             Frame st[MAX_FRAMES];
             batch_water_epoch(sim, bs, slot, epoch, st);
-            sim.flush_counters(); pol.finish(s);
+            sim.flush_counters(); nst += pol.a_nsteps; pol.finish(s);
             again = bs.water[slot].state == B_ENDED;
           }
           relax_flood_later(bs, slot, par ^ 1u, again);
         }
+        relax_commit_flood_steps(s, nst);
         SMX_PROF(8)
         if (!grid_sync(bar, gridDim.x, gen, fence_all)) { bs.ctrl[BC_STALLED] = 1u; return; }
         SMX_PROF(9)
@@ -794,10 +855,10 @@ __global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared
   const uint32_t k = relax_append(&g.count[0], act);
   if (act) g.pend[0][k] = entry;
 }
-__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n) {
+__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n, uint32_t warm) {
   SMX_LOAD_SOILS(sh)
   __shared__ uint32_t s_i;
-  unsigned long long vis = 0;
+  unsigned long long vis = 0, gns = 0;
   const uint32_t nt = (uint32_t)g.gtx * (uint32_t)g.gty;
   while (true) {
     if (threadIdx.x == 0) s_i = atomicAdd(&g.count[1], 1u);
@@ -805,9 +866,9 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
     const uint32_t i = s_i;
     __syncthreads();
     if (i >= n) break;
+    const uint32_t entry = order[i], col = entry / nt, tile = entry - col * nt;
+    const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
     if (threadIdx.x == 0) {
-      const uint32_t entry = order[i], col = entry / nt, tile = entry - col * nt;
-      const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
       for (int dx = -2; dx <= 2; dx++)                         // the tiles whose region overlaps this one's and whose colour comes first
         for (int dy = -2; dy <= 2; dy++) {
           const int ax = tx + dx, ay = ty + dy;
@@ -817,15 +878,25 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
           while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GT_PENDING) __builtin_amdgcn_s_sleep(8);
         }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // what the tiles before wrote to the map is visible from here on
+    }
+    __syncthreads();
+    if (warm) {                                                // the tile's region (tile + ring, 24 x 24 cells), fetched by all 64 lanes: warm_region above
+      uint32_t sink = 0u;
+      const int T = 1 << GRID_SHIFT;
+      warm_region(s, (tx - 1) * T, (tx + 2) * T - 1, (ty - 1) * T, (ty + 2) * T - 1, threadIdx.x, 64u, sink);
+      warm_sink(bs, sink);
+    }
+    if (threadIdx.x == 0) {
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
       Frame st[MAX_FRAMES];
       vis += batch_grid_tile(sim, tx, ty, g.keybase + (unsigned long long)entry, st);
-      sim.flush_counters(); pol.finish(s);
+      sim.flush_counters(); gns += pol.a_nsteps; pol.finish(s);
       __hip_atomic_store(&g.tdone[(size_t)(tx - g.txb) * g.gty + ty], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (threadIdx.x == 0 && vis) atomicAdd(&s.ctr[C_GRID_ACTIVE], vis);
+  if (threadIdx.x == 0 && gns) atomicAdd(&s.ctr[C_GRID_NESTED_STEPS], gns);
 }
 __global__ void k_batch_grid_finish(DevState s, unsigned long long visited0) {   // counter parity: every other cell "calls" cascade once
   const unsigned long long n = (unsigned long long)s.dimx * s.dimy, v = s.ctr[C_GRID_ACTIVE] - visited0;
@@ -1189,6 +1260,7 @@ struct smx_ctx {
   int mega_blocks = 0;                // ... its grid (0: not sized yet): co-resident workgroups, hipLaunchCooperativeKernel
   bool mega_off = false;              // ... the device refused a cooperative launch: the per-phase launches run instead (said once on stderr)
   int relax_persistent = -1, relax_tail_at = -1;   // smx_set_relax_launch (-1: the defaults / the environment's)
+  uint32_t flood_launch_no = 0;       // k_relax_floods launches so far (every 7th is bracketed by HIP events)
   uint32_t relax_cap = 0;             // slots the relaxed schedule's buffers are sized for
   int strips_n = 1, strips_a = 16, strips_b = 48;
   int own_x0 = 0, own_x1 = -1;        // strips on several devices: the columns this context owns (-1: to the map's edge)
@@ -1232,6 +1304,7 @@ static void drain_events(smx_ctx* ctx) {
       case 9: ctx->timing.ms_kernel_tail += ms; ctx->timing.launches_kernel_tail++; ctx->timing.epochs_kernel_tail += p.launches; break;          // k_relax_tail (p.launches = its epochs)
       case 10: ctx->timing.ms_kernel_epochs += ms; ctx->timing.launches_kernel_epochs++; ctx->timing.epochs_kernel_epochs += p.launches; break;   // k_relax_epochs
       case 11: ctx->timing.ms_kernel_grid_children += ms; ctx->timing.launches_kernel_grid_children += p.launches; break;
+      case 12: ctx->timing.ms_kernel_floods += ms; ctx->timing.launches_kernel_floods += p.launches; break;       // k_relax_floods, the bracketed launches
       default: ctx->timing.ms_freq += ms; ctx->timing.launches_freq++; break;
     }
     ctx->evpool.push_back(p.a); ctx->evpool.push_back(p.b);
@@ -2175,7 +2248,12 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
           const unsigned ncc = std::min(ncb, std::max(1u, casc_blocks));
           for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncc), dim3(64), 0, st, ctx->d, bs, epoch, col);
         }
-        if (!wind) hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch);
+        if (!wind) {                                         // (bracketed every 7th launch of the context: a stride coprime to the every-4th-epoch rule of relax_floods_due)
+          ctx->timing.launches_floods_all++;
+          static const uint32_t warm = [] { const char* e = getenv("SMX_WARM"); return e ? (uint32_t)atoi(e) : 1u; }();   // (0: no cache warm-up by the idle lanes -- A/B)
+          if (ctx->flood_launch_no++ % 7u == 0u) { PhaseTimer tk(ctx, 12, 1u); hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch, warm); }
+          else hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch, warm);
+        }
       }
     }
   } else if (nlive) {
@@ -2312,7 +2390,8 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
     HIPCHK(rocprim::radix_sort_keys(ctx->d_tsort, tb, ctx->d_tpend[0], ctx->d_tpend[1], (size_t)n, 0u, 32u, st));
     HIPCHK(hipMemsetAsync(ctx->d_tcount + 1, 0, 4, st));     // the cursor of the dataflow kernel
     static const unsigned flow_waves = [] { const char* e = getenv("SMX_GRID_FLOW_WAVES"); const int v = e ? atoi(e) : 2048; return (unsigned)(v < 1 ? 1 : v); }();
-    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n); }
+    static const uint32_t warm = [] { const char* e = getenv("SMX_WARM"); return e ? (uint32_t)atoi(e) : 1u; }();
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n, warm); }
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
     HIPCHK(hipStreamSynchronize(st));
     ctx->grid_passes++;
@@ -2363,7 +2442,7 @@ static void launch_classify(smx_ctx* ctx) {                  // which cells can 
 static int xbuf_alloc(smx_ctx* ctx) {
   if (ctx->d_xdata) return 0;
   ctx->xdata_cap = 256ull << 20; ctx->xoffs_cap = 8u << 20;
-  HIPCHK(hipMalloc(&ctx->d_xdata, ctx->xdata_cap)); HIPCHK(hipMalloc(&ctx->d_xoffs, (size_t)ctx->xoffs_cap * 4)); HIPCHK(hipMalloc(&ctx->d_xcur, sizeof(XCursor)));
+  HIPCHK(hipMalloc(&ctx->d_xdata, ctx->xdata_cap)); HIPCHK(hipMalloc(&ctx->d_xoffs, (size_t)ctx->xoffs_cap * 4)); HIPCHK(hipMalloc(&ctx->d_xcur, 2 * sizeof(XCursor)));   // [0] columns, [1] particles (st_pack_band)
   return 0;
 }
 extern "C" {
@@ -2729,6 +2808,7 @@ int smx_get_counters_sized(smx_ctx* ctx, smx_counters* out, uint64_t struct_size
   t.spec_rounds = ctx->spec_rounds; t.spec_aborts = ctx->spec_aborts;
   t.reserved[0] = ctx->spec_fallbacks; t.reserved[1] = ctx->spec_executed;
   t.spec_subphases_cut = ctx->spec_subphases_cut; t.spec_serial_particles = ctx->spec_serial_particles;
+  t.flood_nested_steps = c[C_FLOOD_NESTED_STEPS]; t.grid_nested_steps = c[C_GRID_NESTED_STEPS];
   memcpy(out, &t, struct_size < sizeof(t) ? (size_t)struct_size : sizeof(t));
   return 0;
 }

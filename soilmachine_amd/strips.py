@@ -220,7 +220,13 @@ class LibStripRank:
         C = self.C
         v = [C.c_uint64() for _ in range(5)]
         self.lm._chk(self.L.smx_strips_stats(self.h, *[C.byref(x) for x in v]))
-        return dict(zip(("chunks", "seam_chunks", "generations", "bytes_sent", "messages"), (int(x.value) for x in v)))
+        d = dict(zip(("chunks", "seam_chunks", "generations", "bytes_sent", "messages"), (int(x.value) for x in v)))
+        w = [C.c_uint64(), C.c_uint64()]                            # what the transport itself cost (round 6): stream synchronisations, grouped operations
+        self.lm._chk(self.L.smx_strips_sync_stats(self.h, C.byref(w[0]), C.byref(w[1])))
+        d["transport_host_syncs"], d["transport_groups"] = int(w[0].value), int(w[1].value)
+        if d["seam_chunks"]:
+            d["transport_host_syncs_per_seam_chunk"] = d["transport_host_syncs"] / d["seam_chunks"]
+        return d
 
     def detach(self):
         self.lm._chk(self.L.smx_strips_detach(self.h))

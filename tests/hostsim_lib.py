@@ -79,7 +79,8 @@ def _p(a):
 
 
 CTR = ["steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls",
-       "cascade_transfers", "wcascade_calls", "grid_active_cells", "pool_overflow", "live_sections"]
+       "cascade_transfers", "wcascade_calls", "grid_active_cells", "pool_overflow", "live_sections",
+       "flood_nested_steps", "grid_nested_steps"]      # (the last two: device kernels only -- soil_core.h Ctr; 0 on host threads)
 
 
 class HostSim:

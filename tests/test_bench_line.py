@@ -21,11 +21,15 @@ def _detail():
     roof = {"bound": "hbm", "kernel": "k_batch_epoch<wind> (the relaxed engine runs wind on the exclusive schedule by default)", "achieved": kr_d["achieved"], "peak": 8000.0,
             "unit": "GB/s", "frac": kr_d["frac"], "traffic": 9.7e6, "traffic_source": "profiles/r04_pmc.json " + "x" * 400, "avg_launch_ms": 0.26, "launches": 10880,
             "launches_timed": 10880, "algorithmic_bytes_per_launch": 2.1e7, "phases": phases,
-            "whole_tick": {"algorithmic_bytes_per_tick": 1.6e10, "achieved": 17.6, "unit": "GB/s", "frac": 0.0022}, "note": "n" * 2000}
+            "whole_tick": {"algorithmic_bytes_per_tick": 1.6e10, "achieved": 17.6, "unit": "GB/s", "frac": 0.0022}, "note": "n" * 2000,
+            "time_share_of_tick": {"k_relax_floods": 0.31, "k_batch_epoch<wind>": 0.15, "k_grid_tiles_flow": 0.18, "k_relax_tail": 0.06, "k_relax_step<water>": 0.03}}
+    phases["floods"] = dict(bench.kernel_roofline(3.0e6 * 20 * 192 + 2.1e5 * 20 * bench.B_FLOOD, 900.0, 6900, 48000), kernel="k_relax_floods", ms_per_tick=310.0)
+    gate = {"pass": False, "beyond_3": [], "between_2_and_3": ["sumh", "nested"]}
     cpu = {"value": 2.5e6, "unit": "particle-steps/s", "cores": 1, "kind": "reference", "sample": "s" * 900, "ms_per_tick": 25570.9, "host_cpu": "EPYC", "host_cores_total": 256,
            "all_cores": {"value": 3.4e7, "unit": "…", "cores": 32, "note": "n" * 300}, "as_is": {"value": 1.0e6}}
     pref = {"workload": "1024x1024 ...", "controls": 8, "outliers": ["sumh"], "figures": {k: {"z": 0.5 * i - 1.0, "engine": 1.0} for i, k in enumerate(
-        ("steps_water_top", "steps_wind", "nested", "sections", "standing", "water_volume", "sumh", "height_rmse"))}, "headline_size_record": "profiles/r05_p2_reference_4096.json"}
+        ("steps_water_top", "steps_wind", "nested", "sections", "standing", "water_volume", "sumh", "height_rmse"))}, "gate": gate,
+            "headline_size_record": {"file": "profiles/r06_p2_reference_4096.json", "variant": "k8", "outliers": [], "gate": {"pass": True, "beyond_3": [], "between_2_and_3": []}}}
     return {"metric": "particle-steps/s", "value": 6.77e7, "unit": "particle-steps/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 917.08, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "4096x4096 layermap, ...", "engine": "relaxed", "water_generations": 4, "parallelism": "single", "parity": "P2 ...", "scaling_note": None,
@@ -34,13 +38,15 @@ def _detail():
             "per_tick": [{"tick": t, "ms": 900.0 + t} for t in range(6, 26)], "steps_per_tick": {"water": 1.6e7, "wind": 4.5e7, "nested_particles": 1.3e6, "floods": 2.1e5},
             "engine_stats": {"epochs": 48000}, "digest": {"sumh": 9004586.4, "nsec": 33972926, "typehash": "41c8c5802c77fd2f", "rand_calls": 4000000},
             "roofline": roof, "cpu_baseline": cpu, "parity_vs_exact": {"big": "b" * 5000}, "parity_vs_reference": pref,
+            "parity_gate": {"verdict": "fail", "rule": "no figure at |z| >= 3, at most one in [2, 3)", "this_run_1024": gate,
+                            "headline_size_record": {"file": "profiles/r06_p2_reference_4096.json", "variant": "k8", "gate": {"pass": True, "beyond_3": [], "between_2_and_3": []}, "outliers": []}},
             "lines": [{"name": f"line{i}", "value": 1.0e6 * i, "ms_per_tick": 10.0 * i, "digest": {"x": "y" * 300}} for i in range(1, 9)], "lbm_wind": {"roofline": {}},
             "work_dropped": {"children_lost": 0, "pool_overflow": 0}}
 
 
 def test_the_driver_line_is_compact_strict_json_with_roofline_and_cpu_baseline():
     line = json.dumps(bench.compact_line(_detail(), "/tmp/bench_detail_n1.json"), default=float, separators=(",", ":"), allow_nan=False)
-    assert len(line) < 6000 and "\n" not in line
+    assert len(line) < 8000 and "\n" not in line
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
@@ -55,6 +61,24 @@ def test_the_driver_line_is_compact_strict_json_with_roofline_and_cpu_baseline()
     assert c["kind"] == "reference" and len(c["sample"]) <= 300
     assert d["parity_vs_reference"]["outliers"] == ["sumh"] and len(d["parity_vs_reference"]["z"]) == 8
     assert "per_tick" not in d and "parity_vs_exact" not in d and d["detail_file"].endswith(".json")
+    # round 6: the gate's verdict is a top-level key (a run whose own check breaks the rule says so), the trend of the window is on the line,
+    # and the launch families' shares of the tick travel with the roofline
+    assert d["parity_gate"]["verdict"] == "fail" and d["parity_gate"]["this_run_1024"]["between_2_and_3"] == ["sumh", "nested"]
+    assert d["ms_first_tick"] == 906.0 and d["ms_last_tick"] == 925.0
+    assert abs(r["time_share_of_tick"]["k_relax_floods"] - 0.31) < 1e-9 and r["phases"]["floods"]["kernel"] == "k_relax_floods"
+
+
+def test_the_headline_size_parity_record_is_read_from_its_file():
+    """bench.py quotes the 4096^2 record of tools/p2_reference.py for the configuration it times by READING the committed file (VERDICT r5 weak 8:
+    no literals): the default configuration (eight water generations) and the two-strip schedule are in it, inside on all eight figures."""
+    rec = bench.headline_parity_record(8)
+    assert rec is not None and rec["file"].startswith("profiles/r") and rec["variant"] == "k8"
+    assert rec["outliers"] == [] and rec["gate"]["pass"] and len(rec["z"]) == 8 and rec["controls"] >= 32
+    two = bench.headline_parity_record(8, strips=2)
+    assert two is not None and two["variant"] == "k8s2" and two["gate"]["pass"]
+    four = bench.headline_parity_record(4)                        # round 5's default: in the record too, and outside
+    assert four is not None and not four["gate"]["pass"] and "nested" in four["outliers"]
+    assert bench.headline_parity_record(3) is None
 
 
 def test_roofline_is_bytes_per_launch_over_the_average_bracketed_launch():

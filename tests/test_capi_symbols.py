@@ -27,8 +27,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes():
     assert C.sizeof(capi.Config) == 32
-    assert C.sizeof(capi.Counters) == 18 * 8
-    assert C.sizeof(capi.Timing) == 96 + 48 + 16 + 64   # + the three streaming-kernel timers of round 2, + the step-launch totals of round 5, + the persistent launches of round 6
+    assert C.sizeof(capi.Counters) == 20 * 8
+    assert C.sizeof(capi.Timing) == 96 + 48 + 16 + 64 + 24   # + the three streaming-kernel timers of round 2, + the step-launch totals of round 5, + the persistent launches of round 6
 
 
 def test_create_fails_loudly_without_gpu():

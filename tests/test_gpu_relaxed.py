@@ -94,31 +94,62 @@ def test_1024_coupled_structure_and_envelope_against_the_exact_engine():
     assert ctrs["relaxed"]["pool_overflow"] == 0
 
 
-@pytest.mark.parametrize("soil,size,ticks,nwater,nwind", [
-    ("rockgravelpebblessand.soil", 512, 12, None, None),        # the headline's soil at the headline's particle density (area-scaled counts)
-    ("default.soil", 256, 150, 250, 0),                         # the established wet regime (lakes from tick ~60; round 3's outlier: +11 % water steps)
-])
-def test_relaxed_z_scores_against_the_reference_streams(soil, size, ticks, nwater, nwind):
+@pytest.mark.parametrize("soil,size,ticks,nwater,nwind,variants", [
+    ("rockgravelpebblessand.soil", 512, 12, None, None, None),          # the headline's soil at the headline's particle density (area-scaled counts)
+    ("default.soil", 256, 150, 250, 0, None),                           # the established wet regime (lakes from tick ~60; round 3's outlier: +11 % water steps)
+    ("rockgravelpebblessand.soil", 2048, 10, None, None, "k8,k8s2"),    # round 6: a quarter of the headline map at the headline's density -- the default
+])                                                                      # configuration AND the two-strip schedule `bench.py --gpus 2` runs (floods due in every epoch), ~2 minutes
+def test_relaxed_z_scores_against_the_reference_streams(soil, size, ticks, nwater, nwind, variants):
     """The parity gate of the benchmarked engine: the relaxed schedule on the device against THE REFERENCE
     (oracle/_ref/soil_ref_lean, SEED 0) next to SIXTEEN reference runs (as many as the box's cores and memory hold) of the same terrain under other rand() streams, every figure as a
-    z-score against that control distribution (tools/p2_reference.py; the 4096^2 record of the same protocol at the headline's counts:
-    profiles/r05_p2_reference_4096.json). No hand-set floors: z-scores (bound below) on top-level water steps, wind steps, nested particles, section
+    z-score against that control distribution (tools/p2_reference.py; the 4096^2 record of the same protocol at the headline's counts, 33 reference streams:
+    profiles/r06_p2_reference_4096.json). No hand-set floors: z-scores (bound below) on top-level water steps, wind steps, nested particles, section
     count, cells under water, water volume and sum of heights; height RMSE one-sided."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import p2_reference
-    rep = p2_reference.run(soil, size, ticks, 16, "relaxed", verbose=False, nwater=nwater, nwind=nwind)
+    vs = [p2_reference.parse_variant(v) for v in variants.split(",")] if variants else None
+    rep = p2_reference.run(soil, size, ticks, 16, "relaxed", verbose=False, nwater=nwater, nwind=nwind, variants=vs)
     if "skipped" in rep:
         pytest.skip(rep["skipped"])
     assert rep["controls"] >= 8
-    zs = " ".join(f"{k}={f['z']:+.2f}" for k, f in rep["figures"].items())
-    print("[z-scores]", soil, size, zs)
     # Eight figures, each a t-distributed score of ONE engine run against <= 16 control runs: a schedule that IS the reference shows a
-    # |z| > 2 on one of them in about every third run (7 % per figure). The gate: nothing at |z| >= 3, at most one figure between 2 and 3.
-    az = {k: (f["z"] if f["one_sided"] else abs(f["z"])) for k, f in rep["figures"].items()}
-    strong = [k for k, v in az.items() if v >= 3.0]
-    weak = [k for k, v in az.items() if 2.0 <= v < 3.0]
-    assert not strong and len(weak) <= 1, zs
+    # |z| > 2 on one of them in about every third run (7 % per figure; the instrument's own record: 29 of 33 reference streams pass this rule at
+    # 4096^2, `calibration` in the profile). The gate (p2_reference.gate): nothing at |z| >= 3, at most one figure between 2 and 3.
+    blocks = rep["variants"] if vs else {"default": rep}
+    for name, b in blocks.items():
+        zs = " ".join(f"{k}={f['z']:+.2f}" for k, f in b["figures"].items())
+        print("[z-scores]", soil, size, name, zs)
+        g = p2_reference.gate({k: f["z"] for k, f in b["figures"].items()})
+        assert g["pass"], (name, g, zs)
+
+
+def test_relaxed_strip_schedule_device_equals_host_threads():
+    """the relaxed schedule under column strips (ONE context, two strips: what every rank of `bench.py --gpus 2` runs, floods due in every epoch),
+    device against the same headers on host threads -- full state, through lakes (restored in round 6: ADVICE r5)"""
+    from hostsim_lib import lib
+    cfg = load_cfg("default.soil")
+    o = Oracle(cfg, 256, 128, seed=0); o.initialize()
+    for _ in range(45):
+        o.tick(250, 0, True, False)
+    s0 = o.snapshot()
+    m = Layermap(cfg, 256, 128, seed=0, initialize=False, engine=capi.ENGINE_RELAXED)
+    m.load(s0, rand_seed=0)
+    m.set_batch_strips(2)
+    sm = SoilMachine.__new__(SoilMachine)
+    sm.cfg, sm.map, sm.nwater, sm.nwind, sm.dowater, sm.dowind = cfg, m, 150, 0, True, False
+    h = HostSim(cfg, 256, 128, seed=0); h.load(s0, advance_rand=True)
+    L = lib()
+    try:
+        L.hs_set_batch_strips(2, 16, 48)
+        for t in range(3):
+            sm.tick(1, sync=True)
+            h.relaxed_tick(150, 0, True, False, nthreads=4, shuffle=t + 2)
+            bad = compare(m.snapshot(), h.snapshot())
+            assert not bad, (t, bad)
+    finally:
+        L.hs_set_batch_strips(1, 16, 48)
+    assert m.counters()["floods"] == h.counters()["floods"] > 300
 
 
 def test_water_generations_equal_k_phase_calls():
