@@ -413,41 +413,19 @@ __global__ void __launch_bounds__(64) k_relax_cascade_flow(DevState s, BatchShar
   }
   if (threadIdx.x == 0) { if (nc) atomicAdd(&s.ctr[C_CASCADE_CALLS], nc); if (nt) atomicAdd(&s.ctr[C_CASCADE_TRANSFERS], nt); }
 }
-// ---------------- cache warm-up by the idle lanes (round 6) ----------------
-// A flood and a grid tile are ONE lane's dependent chain through a small rectangle of the map: the 32-byte records of its cells, their flag
-// bytes, the water frequency / track words its nested particles read. Every launch starts cold -- the cells were last written by other CUs,
-// on other XCDs, whose L2s are not coherent with this one: the first touch of a line comes from the fabric at 1-2 us -- and the chain
-// touches them one after the other (rocprofv3 --pmc, profiles/r06_pmc.json: k_relax_floods spends 80 % of its wave cycles waiting, 2 000
-// VALU instructions per flood; k_grid_tiles_flow 91 %). The 63 lanes that have nothing to do fetch the whole rectangle at once, one 4-byte
-// load per 128-byte line: one round trip in parallel instead of ~50 in sequence; the chain then runs out of this CU's L1 / this XCD's L2.
-// Loads only: no result can depend on it. `sink` keeps the loads alive (it is compared with a value it never takes).
-__device__ __forceinline__ void warm_region(const DevState& s, int x0, int x1, int y0, int y1, uint32_t lane, uint32_t nlanes, uint32_t& sink) {
-  if (x0 < s.x_lo) x0 = s.x_lo; if (x1 > s.x_hi - 1) x1 = s.x_hi - 1;
-  if (y0 < 0) y0 = 0; if (y1 > s.dimy - 1) y1 = s.dimy - 1;
-  if (x1 < x0 || y1 < y0) return;
-  const uint32_t nx = (uint32_t)(x1 - x0 + 1), ny = (uint32_t)(y1 - y0 + 1);
-  const uint32_t nch = (ny + 3u) / 4u + 1u;                   // a row of cells: one touch per 4 records (128 bytes) + the row's last record
-  for (uint32_t t = lane; t < nx * nch; t += nlanes) {
-    const int x = x0 + (int)(t / nch); int y = y0 + 4 * (int)(t % nch); if (y > y1) y = y1;
-    sink ^= s.cells[(size_t)x * s.dimy + y].type;
-  }
-  for (uint32_t t = lane; t < 2u * nx; t += nlanes) {         // flag bytes: a row's first and last (12-24 bytes apart: one or two lines)
-    const int x = x0 + (int)(t >> 1);
-    sink ^= (uint32_t)s.flags[(size_t)x * s.dimy + ((t & 1u) ? y1 : y0)];
-  }
-  for (uint32_t t = lane; t < 4u * ny; t += nlanes) {         // frequency / track words (index y * dimx + x: rows run along x)
-    const int y = y0 + (int)(t >> 2);
-    const size_t fi = (size_t)y * s.dimx + ((t & 1u) ? x1 : x0);
-    sink ^= __float_as_uint((t & 2u) ? s.wtrack[fi] : s.wfreq[fi]);
-  }
-}
-__device__ __forceinline__ void warm_sink(const BatchShared& bs, uint32_t sink) {   // (never true: the loads above must not be optimised away)
-  if (sink == 0x7F4A7C15u && blockIdx.x == 0x7FFFFFFFu) bs.ctrl[BC_COUNT - 1] = sink;
-}
 // the floods of the relaxed schedule: batch_water_epoch over this epoch's list of ended particles; who is not done joins the next
 // list. The launch has a fixed number of wavefronts; the floods are spread over them as thinly as the list allows (a wavefront costs
 // the union of its lanes' paths, and a flood is a long, branchy path).
-__global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs, uint32_t epoch, uint32_t warm) {
+// (Round 6, measured and dropped -- profiles/r06_floods.md: the 63 idle lanes fetching a flood's whole rectangle -- cells, flag bytes,
+//  frequency / track words, one load per 128-byte line -- before lane 0 starts, and the same for a grid tile's 24 x 24-cell region: no
+//  change within 0.5 % although the kernel spends 80 % of its wave cycles waiting (rocprofv3 --pmc): the chain's ~100 dependent accesses
+//  are L2 / Infinity-Cache hits already, 0.3-0.5 us each; what a flood costs is their NUMBER. 256 ... 16 384 wavefronts for the list: no
+//  change either -- a launch lasts as long as its longest flood.)
+// (experiments, SMX_FLOOD_PROF=1: how long does ONE flood take, and how many steps of nested particles run inside it? [0..31] floods by log2 of
+//  their duration in 100 MHz ticks, [32..63] the nested steps of those floods, [64] floods that acted, [65] their ticks, [66] listed floods that
+//  did not hold their tiles; printed by smx_destroy)
+__device__ unsigned long long g_flood_prof[72];
+__global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs, uint32_t epoch, uint32_t prof) {
   const uint32_t par = epoch & 1u;
   uint32_t n = bs.ctrl[BC_NFLOOD + par];
   if (n > bs.list_cap) n = bs.list_cap;
@@ -466,32 +444,19 @@ __global__ void __launch_bounds__(64) k_relax_floods(DevState s, BatchShared bs,
   }
   unsigned long long nst = 0;
   if (act) slot = bs.flist[par][i];
-  if (warm) {                                                 // the floods of this wavefront that hold their tiles: their rectangles, fetched by all 64 lanes
-    int rx0 = 0, rx1 = -1, ry0 = 0, ry1 = -1;
-    if (act) {
-      const BWater& q = bs.water[slot];
-      const BRect r = q.rect;
-      const unsigned long long tag = btag(epoch, slot);
-      bool holds = q.state == B_ENDED && !brect_empty(r) && r.tx0 >= bs.txb && r.tx1 < bs.txe;
-      if (holds)
-        for (int tx = r.tx0; tx <= r.tx1; tx++)
-          for (int ty = r.ty0; ty <= r.ty1; ty++) holds &= (bs.claim[epoch & 1u][(size_t)(tx - bs.txb) * bs.nty + ty] == tag);
-      if (holds) { rx0 = r.tx0 << bs.tshift; rx1 = ((r.tx1 + 1) << bs.tshift) - 1; ry0 = r.ty0 << bs.tshift; ry1 = ((r.ty1 + 1) << bs.tshift) - 1; }
-    }
-    uint32_t sink = 0u;
-    for (uint32_t j = 0; j < lpw; j++) {
-      const int ax0 = __shfl(rx0, (int)j), ax1 = __shfl(rx1, (int)j), ay0 = __shfl(ry0, (int)j), ay1 = __shfl(ry1, (int)j);
-      if (ax1 >= ax0) warm_region(s, ax0, ax1, ay0, ay1, threadIdx.x, 64u, sink);
-    }
-    warm_sink(bs, sink);
-  }
   if (act) {
     BatchPolicy pol(s, bs);
     Sim<BatchPolicy> sim(s, sh, pol);
     Frame st[MAX_FRAMES];
+    const unsigned long long t0 = prof ? wall_clock64() : 0ull;
     batch_water_epoch(sim, bs, slot, epoch, st);
     sim.flush_counters(); nst = pol.a_nsteps; pol.finish(s);
     again = bs.water[slot].state == B_ENDED;
+    if (prof) {
+      const unsigned long long dt = wall_clock64() - t0;
+      if (again) atomicAdd(&g_flood_prof[66], 1ull);
+      else { const int b = 63 - __clzll((long long)(dt | 1ull)); atomicAdd(&g_flood_prof[b > 31 ? 31 : b], 1ull); atomicAdd(&g_flood_prof[32 + (b > 31 ? 31 : b)], nst); atomicAdd(&g_flood_prof[64], 1ull); atomicAdd(&g_flood_prof[65], dt); }
+    }
   }
   relax_flood_later(bs, slot, par ^ 1u, again);
   relax_commit_flood_steps(s, nst);
@@ -855,7 +820,7 @@ __global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared
   const uint32_t k = relax_append(&g.count[0], act);
   if (act) g.pend[0][k] = entry;
 }
-__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n, uint32_t warm) {
+__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n) {
   SMX_LOAD_SOILS(sh)
   __shared__ uint32_t s_i;
   unsigned long long vis = 0, gns = 0;
@@ -866,9 +831,9 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
     const uint32_t i = s_i;
     __syncthreads();
     if (i >= n) break;
-    const uint32_t entry = order[i], col = entry / nt, tile = entry - col * nt;
-    const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
     if (threadIdx.x == 0) {
+      const uint32_t entry = order[i], col = entry / nt, tile = entry - col * nt;
+      const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
       for (int dx = -2; dx <= 2; dx++)                         // the tiles whose region overlaps this one's and whose colour comes first
         for (int dy = -2; dy <= 2; dy++) {
           const int ax = tx + dx, ay = ty + dy;
@@ -878,15 +843,6 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
           while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GT_PENDING) __builtin_amdgcn_s_sleep(8);
         }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // what the tiles before wrote to the map is visible from here on
-    }
-    __syncthreads();
-    if (warm) {                                                // the tile's region (tile + ring, 24 x 24 cells), fetched by all 64 lanes: warm_region above
-      uint32_t sink = 0u;
-      const int T = 1 << GRID_SHIFT;
-      warm_region(s, (tx - 1) * T, (tx + 2) * T - 1, (ty - 1) * T, (ty + 2) * T - 1, threadIdx.x, 64u, sink);
-      warm_sink(bs, sink);
-    }
-    if (threadIdx.x == 0) {
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
       Frame st[MAX_FRAMES];
@@ -1401,6 +1357,13 @@ void smx_destroy(smx_ctx* ctx) {
   if (!ctx) return;
   strips_free(ctx);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (getenv("SMX_FLOOD_PROF") && atoi(getenv("SMX_FLOOD_PROF"))) {
+    unsigned long long h[72];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_flood_prof), sizeof(h)) == hipSuccess && h[64]) {
+      fprintf(stderr, "[soilmx] k_relax_floods: %llu floods acted, mean %.1f us; %llu listed floods waited (did not hold their tiles). duration bucket (us): floods, nested steps per flood\n", h[64], 0.01 * (double)h[65] / (double)h[64], h[66]);
+      for (int b = 0; b < 32; b++) if (h[b]) fprintf(stderr, "   [%8.1f, %8.1f) %9llu  %7.1f\n", 0.01 * (double)(1ull << b), 0.01 * (double)(2ull << b), h[b], (double)h[32 + b] / (double)h[b]);
+    }
+  }
   if (ctx->d_gbar && getenv("SMX_RELAX_MEGA_FLAGS") && (atoi(getenv("SMX_RELAX_MEGA_FLAGS")) & 2)) {   // (experiments: where an epoch of k_relax_epochs goes, workgroup 0's clock)
     GridBar hb; if (hipMemcpy(&hb, ctx->d_gbar, sizeof(hb), hipMemcpyDeviceToHost) == hipSuccess && hb.prof[10]) {
       static const char* nm[10] = {"step", "sync", "apply", "sync", "filter", "sync", "colours", "sync", "floods", "sync"};
@@ -2250,9 +2213,9 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
         }
         if (!wind) {                                         // (bracketed every 7th launch of the context: a stride coprime to the every-4th-epoch rule of relax_floods_due)
           ctx->timing.launches_floods_all++;
-          static const uint32_t warm = [] { const char* e = getenv("SMX_WARM"); return e ? (uint32_t)atoi(e) : 1u; }();   // (0: no cache warm-up by the idle lanes -- A/B)
-          if (ctx->flood_launch_no++ % 7u == 0u) { PhaseTimer tk(ctx, 12, 1u); hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch, warm); }
-          else hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch, warm);
+          static const uint32_t fprof = [] { const char* e = getenv("SMX_FLOOD_PROF"); return e ? (uint32_t)atoi(e) : 0u; }();
+          if (ctx->flood_launch_no++ % 7u == 0u) { PhaseTimer tk(ctx, 12, 1u); hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch, fprof); }
+          else hipLaunchKernelGGL(k_relax_floods, dim3(nfb), dim3(64), 0, st, ctx->d, bs, epoch, fprof);
         }
       }
     }
@@ -2390,8 +2353,7 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
     HIPCHK(rocprim::radix_sort_keys(ctx->d_tsort, tb, ctx->d_tpend[0], ctx->d_tpend[1], (size_t)n, 0u, 32u, st));
     HIPCHK(hipMemsetAsync(ctx->d_tcount + 1, 0, 4, st));     // the cursor of the dataflow kernel
     static const unsigned flow_waves = [] { const char* e = getenv("SMX_GRID_FLOW_WAVES"); const int v = e ? atoi(e) : 2048; return (unsigned)(v < 1 ? 1 : v); }();
-    static const uint32_t warm = [] { const char* e = getenv("SMX_WARM"); return e ? (uint32_t)atoi(e) : 1u; }();
-    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n, warm); }
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n); }
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
     HIPCHK(hipStreamSynchronize(st));
     ctx->grid_passes++;
