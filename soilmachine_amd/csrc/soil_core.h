@@ -44,6 +44,16 @@
 #define SMX_LD64_COHERENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
+#if defined(SMX_PROF_FLOOD) && !defined(SMX_HOSTSIM)
+// (experiment build, -DSMX_PROF_FLOOD: where does one lane's flood / grid tile go? 100 MHz ticks and counts per section, accumulated in g_sect[];
+//  printed by smx_destroy -- profiles/r06_floods.md)
+extern __device__ unsigned long long g_sect[32];
+#define SMX_SECT_T0() const unsigned long long sect_t0_ = wall_clock64()
+#define SMX_SECT(k) do { atomicAdd(&g_sect[2 * (k)], wall_clock64() - sect_t0_); atomicAdd(&g_sect[2 * (k) + 1], 1ull); } while (0)
+#else
+#define SMX_SECT_T0() do {} while (0)
+#define SMX_SECT(k) do {} while (0)
+#endif
 namespace smx {
 
 constexpr uint32_t NIL = 0xFFFFFFFFu;
@@ -866,13 +876,14 @@ struct Sim {
     if (p.volume < 0.01 || p.spill-- <= 0) return false;
     n_floods++;
     p.ix = (int)p.pos.x; p.iy = (int)p.pos.y;               // truncation (:128)
-    add(p.ix, p.iy, p.sediment * soils[p.contains].equrate, p.contains);
-    particle_cascade<0>(p.pos);
-    add(p.ix, p.iy, p.volume * 0.015, AIR);                 // volumeFactor = 0.015 (:370)
-    seep(p.ix, p.iy);
+    { SMX_SECT_T0(); add(p.ix, p.iy, p.sediment * soils[p.contains].equrate, p.contains); SMX_SECT(0); }
+    { SMX_SECT_T0(); particle_cascade<0>(p.pos); SMX_SECT(1); }
+    { SMX_SECT_T0(); add(p.ix, p.iy, p.volume * 0.015, AIR); SMX_SECT(2); }                 // volumeFactor = 0.015 (:370)
+    { SMX_SECT_T0(); seep(p.ix, p.iy); SMX_SECT(3); }
     return !ab;
   }
   SMX_D void push_frame(Frame* st, int& depth, int ix, int iy, int spill) {   // entry of WaterParticle::cascade
+    SMX_SECT_T0();
     n_wcasc++;
     size_t cc[9]; bool inb[8]; View v[9];
     block3x3(ix, iy, cc, inb, v);
@@ -895,6 +906,7 @@ struct Sim {
     if (depth >= MAX_FRAMES) { n_overflow++; return; }      // unreachable: depth is bounded by the spill budget
     Frame& f = st[depth++];
     f.ix = ix; f.iy = iy; f.spill = spill; f.num = sn.num; f.i = 0; f.codes = sn.codes; f.cand = cand; f.stamp = n_mod;
+    SMX_SECT(4);
   }
   // WaterParticle::move (water.h:43-73) on the carried block `cur` around ipos. false = move() returned false.
   // PURE: the batched engine's look-ahead -- where would this move go? No track write, no counters.
@@ -1128,7 +1140,8 @@ struct Sim {
         // fit -- a step that leaves the region, a flood whose reach does -- is suspended into a record (soil_batch.h run_nested)
         if (have) {
           have = false;
-          if (pol.run_nested(*this, p) == 0 && !(p.volume < 0.01 || p.spill <= 0) && pol.flood_fits(*this, p)) {   // water.h:125 gate, then :123-145
+          int rn_; { SMX_SECT_T0(); rn_ = pol.run_nested(*this, p); SMX_SECT(8); }
+          if (rn_ == 0 && !(p.volume < 0.01 || p.spill <= 0) && pol.flood_fits(*this, p)) {   // water.h:125 gate, then :123-145
             if (water_flood_prelude(p)) { SMX_FRAME_WRITE_BACK(); push_frame(st, depth, p.ix, p.iy, p.spill); }
           }
         }
@@ -1160,20 +1173,21 @@ struct Sim {
       if constexpr (exclusive_access<P>::value) { if (f.stamp == n_mod && !((f.cand >> k) & 1u)) continue; }   // (push_frame: nothing to do there, decided on registers)
       const int ix = f.ix, iy = f.iy;
       const int nx = ix + nb_dx(k), ny = iy + nb_dy(k);
+      SMX_SECT_T0();
       const Sec& A = cell(ix, iy);
       const Sec& B = cell(nx, ny);
       if (ab) return;
       const double whA = A.size, whB = B.size, fA = A.floor, fB = B.floor;   // 0 for empty columns (:194-214)
       const double diff = (fA + whA - fB - whB) * (double)s.scale / 80.0;
-      if (diff == 0) continue;
+      if (diff == 0) { SMX_SECT(5); continue; }
       const Sec& T = (diff > 0) ? A : B;
       const int tx = (diff > 0) ? ix : nx, ty = (diff > 0) ? iy : ny;
       const int bx = (diff > 0) ? nx : ix, by = (diff > 0) ? ny : iy;
-      if (T.type != AIR) continue;                          // :229 (EMPTY != AIR; the reference cannot reach here with NULL)
+      if (T.type != AIR) { SMX_SECT(5); continue; }         // :229 (EMPTY != AIR; the reference cannot reach here with NULL)
       double transfer = fabs(diff) / 2.0;
       const double wh = T.size;
       transfer = (wh < transfer) ? wh : transfer;
-      if (transfer <= 0) continue;
+      if (transfer <= 0) { SMX_SECT(5); continue; }
       if (transfer == wh) {                                 // :246-264 the whole water section leaves: nested particle
         if constexpr (P::DEFER_NESTED) {
           if (!pol.child_room()) continue;                  // no record left for it, should it have to be suspended: the water stays where it is
@@ -1202,6 +1216,7 @@ struct Sim {
         toplevel = false;
         susp_ok = false;                                   // nested particles run inside their parent: not resumable
         have = true;
+        SMX_SECT(7);
         if (ab) return;
       } else {                                              // :266-276
         bool recascade = false;
@@ -1211,6 +1226,7 @@ struct Sim {
         Sec& R = cell(bx, by);
         if (ab) return;
         if (R.type != EMPTY) { R.sat = 1.0f; on_sat(bx, by); }
+        SMX_SECT(6);
         if (recascade && f.spill > 0) {                     // :278-279 cascade(npos, --spill)
           const int sp = --f.spill;
           SMX_FRAME_WRITE_BACK();

@@ -24,6 +24,9 @@
 #include <vector>
 
 #include "../../include/soilmx.h"
+#ifdef SMX_PROF_FLOOD
+__device__ unsigned long long g_sect[32];                    // (experiment build: soil_core.h SMX_SECT)
+#endif
 #include "soil_core.h"
 #include "soil_serial.h"
 #include "soil_spec.h"
@@ -1364,6 +1367,15 @@ void smx_destroy(smx_ctx* ctx) {
       for (int b = 0; b < 32; b++) if (h[b]) fprintf(stderr, "   [%8.1f, %8.1f) %9llu  %7.1f\n", 0.01 * (double)(1ull << b), 0.01 * (double)(2ull << b), h[b], (double)h[32 + b] / (double)h[b]);
     }
   }
+#ifdef SMX_PROF_FLOOD
+  {
+    unsigned long long h[32];
+    static const char* nm[9] = {"prelude: add sediment", "prelude: Particle::cascade", "prelude: add water", "prelude: seep", "push_frame (9 views, sort, mask)", "neighbour: nothing to move",
+                                "neighbour: partial transfer", "neighbour: nested particle spawned", "run_nested (a nested particle's steps)"};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sect), sizeof(h)) == hipSuccess)
+      for (int k = 0; k < 9; k++) if (h[2 * k + 1]) fprintf(stderr, "[soilmx] section %-40s %10llu x %7.2f us = %9.1f ms\n", nm[k], h[2 * k + 1], 0.01 * (double)h[2 * k] / (double)h[2 * k + 1], 1e-5 * (double)h[2 * k]);
+  }
+#endif
   if (ctx->d_gbar && getenv("SMX_RELAX_MEGA_FLAGS") && (atoi(getenv("SMX_RELAX_MEGA_FLAGS")) & 2)) {   // (experiments: where an epoch of k_relax_epochs goes, workgroup 0's clock)
     GridBar hb; if (hipMemcpy(&hb, ctx->d_gbar, sizeof(hb), hipMemcpyDeviceToHost) == hipSuccess && hb.prof[10]) {
       static const char* nm[10] = {"step", "sync", "apply", "sync", "filter", "sync", "colours", "sync", "floods", "sync"};
