@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared
   const uint32_t k = relax_append(&g.count[0], act);
   if (act) g.pend[0][k] = entry;
 }
-__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n) {
+__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n, uint32_t poll_naps) {
   SMX_LOAD_SOILS(sh)
   __shared__ uint32_t s_i;
   unsigned long long vis = 0, gns = 0;
@@ -843,7 +843,10 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
           if ((!dx && !dy) || ax < g.tx_lo || ax >= g.tx_hi || ax < g.txb || ax >= g.txe || ay < 0 || ay >= g.gty) continue;
           if ((uint32_t)((ax % 3) * 3 + (ay % 3)) >= col) continue;
           uint32_t* f = &g.tdone[(size_t)(ax - g.txb) * g.gty + ay];
-          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GT_PENDING) __builtin_amdgcn_s_sleep(8);
+          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GT_PENDING) {   // (a tile takes milliseconds: its dependants poll every few microseconds -- rocprofv3 counted
+            __builtin_amdgcn_s_sleep(8);                                                                //  122 M polling loads per launch at one poll per 0.2 us, profiles/r06_pmc.json)
+            for (uint32_t r = 0; r < poll_naps; r++) __builtin_amdgcn_s_sleep(127);
+          }
         }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // what the tiles before wrote to the map is visible from here on
       BatchPolicy pol(s, bs);
@@ -2365,7 +2368,8 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
     HIPCHK(rocprim::radix_sort_keys(ctx->d_tsort, tb, ctx->d_tpend[0], ctx->d_tpend[1], (size_t)n, 0u, 32u, st));
     HIPCHK(hipMemsetAsync(ctx->d_tcount + 1, 0, 4, st));     // the cursor of the dataflow kernel
     static const unsigned flow_waves = [] { const char* e = getenv("SMX_GRID_FLOW_WAVES"); const int v = e ? atoi(e) : 2048; return (unsigned)(v < 1 ? 1 : v); }();
-    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n); }
+    static const uint32_t poll_naps = [] { const char* e = getenv("SMX_GRID_POLL_NAPS"); return e ? (uint32_t)atoi(e) : 2u; }();   // (x 3.4 us between two polls of a waiting tile)
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n, poll_naps); }
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
     HIPCHK(hipStreamSynchronize(st));
     ctx->grid_passes++;

@@ -31,12 +31,12 @@ while time.time() < t_end:
         o = Oracle(cfg, dx, dy, seed=seed); o.load(s0)        # and the fixed active set of the 9-colour grid pass depends on it
     h = HostSim(cfg, dx, dy, seed=seed); h.load(o.snapshot(), advance_rand=True)
     c0 = o.counters()
-    wg = rng.choice([1, 1, 2, 4])                             # smx_set_water_generations
+    wg = rng.choice([0, 0, 1, 2, 4])                          # smx_set_water_generations (0: the engines' own default, eight since round 6, through the tick entry points)
     desc = (soil, dx, dy, seed, nw, nd, ticks, wet, strips, wg)
     L.hs_set_batch_strips(strips, 16, 48); o.L.so_batched_set_strips(o.h, strips, 16, 48)
     for t in range(ticks):
         nt, sh = rng.choice([1, 3, 5]), rng.randrange(5)
-        if wg == 1:
+        if wg == 0:
             h.relaxed_tick(nw, nd, True, nd > 0, nthreads=nt, shuffle=sh)
             o.relaxed_tick(nw, nd, True, nd > 0)
         else:                                                 # the water phase as wg consecutive generations = wg phase calls

@@ -56,6 +56,7 @@ for s in "$@"; do
     headmega0) run headmega0 30 300 env SMX_RELAX_MEGA=0 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     headmegab) for b in ${MB_LIST:-512}; do run headmegab_$b 30 300 env SMX_RELAX_MEGA_BLOCKS=$b python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
     headmegac) for b in ${MC_LIST:-64}; do run headmegac_$b 30 300 env SMX_RELAX_MEGA_CHUNK=$b python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3; done ;;
+    steady)    run steady 60 900 python bench.py --gpus 1 --steps ${SSTEPS:-20} --warmup ${SWARM:-100} --no-lines --no-cpu-baseline; cp $out/steady.log $out/steady.json 2>/dev/null ;;
     headbatch) run headbatch 30 300 python bench.py --engine batched --no-lines --no-cpu-baseline --steps 3 --warmup 2 ;;
     tracerelax) run tracerelax 30 300 env SMX_TRACE_BATCH=1 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 1 --warmup 5 ;;
     stripstest) run stripstest 60 900 python -m pytest tests/test_gpu_strips.py -x -q -m gpu --durations=8 ;;
