@@ -160,7 +160,7 @@ def cpu_baseline(soil: str, size: int, nwater: int, nwind: int, ticks: int, pool
 
 
 def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, steps, warmup, barrier=None, rand_seed=None, keep_heights=False, save_after_warmup=None,
-            water_generations=None, save_after_window=None):
+            water_generations=None, save_after_window=None, water_stagger=None):
     """warmup ticks, then `steps` timed ticks on a fresh context. Returns a dict (rank-local numbers).
     rand_seed: re-seed the libc stream after the terrain is built (same map, another rand() stream: the parity control)."""
     from soilmachine_amd.machine import SoilMachine
@@ -170,7 +170,10 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
         m._chk(m.L.smx_srand(m.h, int(rand_seed)))
     if water_generations is not None:
         m.set_water_generations(water_generations)
+    if water_stagger is not None:
+        m.set_water_stagger(water_stagger)
     k_gen = m.water_generations()                               # the value in force (smx_get_water_generations), reported as measured
+    k_stagger = m.water_stagger()
     sm.tick(warmup, sync=True)
     if save_after_warmup:                                       # the state the timed window starts from: what cpu_baseline continues (outside the timed region)
         try:
@@ -206,7 +209,7 @@ def measure(cfg, soil, n, seed, nwater, nwind, dowind, engine, pool, device, ste
         "dt": dt, "steps_w": steps_w, "steps_d": steps_d, "tm": tm, "digest": m.digest(),
         "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"],
         "nested": c1["nested_particles"] - c0["nested_particles"], "floods": c1["floods"] - c0["floods"],
-        "pool_overflow": c1["pool_overflow"], "per_tick": per_tick, "water_generations": k_gen,
+        "pool_overflow": c1["pool_overflow"], "per_tick": per_tick, "water_generations": k_gen, "water_stagger": k_stagger,
         "flood_nested_steps": c1.get("flood_nested_steps", 0) - c0.get("flood_nested_steps", 0),
         "grid_nested_steps": c1.get("grid_nested_steps", 0) - c0.get("grid_nested_steps", 0),
         "grid_active_cells": c1["grid_active_cells"] - c0["grid_active_cells"],
@@ -289,7 +292,7 @@ def measure_strips(cfg, dimx, n, nwater, nwind, pool, device, steps, warmup, dis
     c1, tm, b1 = m.counters(), m.timing(), m.batch_stats()
     r = {"dt": dt, "steps_w": c1["steps_water_all"] - c0["steps_water_all"], "steps_d": c1["steps_wind"] - c0["steps_wind"], "tm": tm,
          "digest": {"note": "strips: each rank holds its own strip; no global digest in the timed run"},
-         "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"], "water_generations": m.water_generations(),
+         "steps_w_top": c1["steps_water_top"] - c0["steps_water_top"], "water_generations": m.water_generations(), "water_stagger": m.water_stagger(),
          "flood_nested_steps": c1.get("flood_nested_steps", 0) - c0.get("flood_nested_steps", 0),
          "grid_nested_steps": c1.get("grid_nested_steps", 0) - c0.get("grid_nested_steps", 0),
          "grid_active_cells": c1["grid_active_cells"] - c0["grid_active_cells"],
@@ -321,16 +324,16 @@ def measure_lbm(device, dims=(512, 320, 512), steps=40):
                          "algorithmic_bytes_per_cell_step": 176}}
 
 
-def headline_parity_record(k_gen, strips=1):
+def headline_parity_record(k_gen, strips=1, stagger=0):
     """The committed record of tools/p2_reference.py at the headline's own size and counts (4096^2, 64 000 + 16 000, 32 control streams) for the
     configuration this run times: read from the newest profiles/r*_p2_reference_4096.json that holds it -- never a literal."""
     pdir = os.path.join(ROOT, "profiles")
-    name = f"k{k_gen}" + (f"s{strips}" if strips > 1 else "")
+    name = f"k{k_gen}" + (f"e{stagger}" if stagger else "") + (f"s{strips}" if strips > 1 else "")
     for pf in sorted((f for f in os.listdir(pdir) if f.endswith("_p2_reference_4096.json")), reverse=True):
         try:
             rec = json.load(open(os.path.join(pdir, pf)))
             b = (rec.get("variants") or {}).get(name)
-            if b is None and not rec.get("variants") and rec.get("water_generations") == k_gen and strips == 1:
+            if b is None and not rec.get("variants") and rec.get("water_generations") == k_gen and strips == 1 and not stagger:
                 b = rec
             if b is None:
                 continue
@@ -419,7 +422,7 @@ def compact_line(d: dict, detail_path) -> dict:
     `roofline.traffic` (a separate rocprofv3 --pmc job, labelled). Everything else is in the side file."""
     rf, cpu, pref = d["roofline"], d.get("cpu_baseline"), d.get("parity_vs_reference")
     out = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
-    out["config"] = {k: d["config"][k] for k in ("workload", "engine", "water_generations", "parallelism", "parity")}
+    out["config"] = {k: d["config"].get(k) for k in ("workload", "engine", "water_generations", "water_stagger", "parallelism", "parity")}
     out["value_top_level"] = d.get("value_top_level")
     out["phase_ms_per_tick"] = d["phase_ms_per_tick"]
     out["steps_per_tick"] = d["steps_per_tick"]
@@ -458,7 +461,8 @@ def compact_line(d: dict, detail_path) -> dict:
     out["work_dropped"] = d["work_dropped"]
     if d.get("lines"):
         out["lines"] = [dict({"name": l_["name"], "value": l_.get("value"), "ms_per_tick": l_.get("ms_per_tick")},
-                             **({"cpu_1core_ms_per_tick": l_["cpu_baseline"]["ms_per_tick"]} if l_.get("cpu_baseline") else {})) for l_ in d["lines"] if l_]
+                             **({"cpu_1core_ms_per_tick": l_["cpu_baseline"]["ms_per_tick"]} if l_.get("cpu_baseline") else {}),
+                             **({"parity_gate": ("pass" if l_["parity_gate_headline_size_record"]["gate"]["pass"] else "fail")} if l_.get("parity_gate_headline_size_record") else {})) for l_ in d["lines"] if l_]
     out["detail_file"] = detail_path
     return _r(out)
 
@@ -482,6 +486,7 @@ def main():
     ap.add_argument("--water-generations", type=int, default=None, help="throughput engines: the tick's water particles as k consecutive generations (smx_set_water_generations; "
                                                                         "default: the engine's own (8 since round 6: inside the reference's spread on all eight figures at the headline workload, "
                                                                         "profiles/r06_p2_reference_4096.json); 4 = round 5's default, 1 = round 4's schedule: faster, outside it)")
+    ap.add_argument("--water-stagger", type=int, default=None, help="relaxed engine: the water generations born this many epochs apart inside ONE phase (smx_set_water_stagger; 0 = one after the other; default: the library's)")
     args = ap.parse_args()
 
     import torch
@@ -534,7 +539,7 @@ def main():
         ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"soilmx_bench_{os.getpid()}.smx") if want_cpu else None
         ckpt2 = (ckpt + ".end") if (ckpt and args.steps > 1) else None
         r = measure(cfg, soil, n, seed, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, barrier, save_after_warmup=ckpt,
-                    water_generations=args.water_generations if throughput else None, save_after_window=ckpt2)
+                    water_generations=args.water_generations if throughput else None, save_after_window=ckpt2, water_stagger=args.water_stagger if throughput else None)
         if ckpt and not os.path.exists(ckpt):
             ckpt = None
         if ckpt2 and not os.path.exists(ckpt2):
@@ -677,6 +682,20 @@ def main():
                     except Exception:
                         pass
                 lines.append(ln)
+            if eng_name == "relaxed" and args.only is None and n == 4096 and args.water_generations is None and args.water_stagger is None:
+                # the staggered variant of the schedule (smx_set_water_stagger, round 6): sixteen generations born 140 epochs apart inside ONE phase -- the same
+                # window, with ITS parity verdict read from its record (it passes the gate for SEED 0 and for the two-strip schedule; over four device streams its
+                # mean is a little further from the reference's than the default's: DESIGN.md 5)
+                try:
+                    rs = measure(cfg, soil, n, 0, nwater, nwind, nwind > 0, engine, pool, local_rank, args.steps, args.warmup, water_generations=16, water_stagger=140)
+                    ls = line_of(rs, "headline_staggered_k16_e140", workload, eng_name, args.steps)
+                    ls["steps"], ls["warmup"] = args.steps, args.warmup
+                    ls["water_generations"], ls["water_stagger"] = rs["water_generations"], rs["water_stagger"]
+                    hs_ = headline_parity_record(16, 1, 140)
+                    ls["parity_gate_headline_size_record"] = ({"file": hs_["file"], "variant": hs_["variant"], "gate": hs_["gate"], "outliers": hs_["outliers"]} if hs_ else None)
+                    lines.append(ls)
+                except Exception as e:
+                    lines.append({"name": "headline_staggered_k16_e140", "error": str(e)})
             if throughput and args.only is None:
                 try:
                     lines.append(wet_regime_line(dcfg, local_rank, ENG[eng_name], eng_name))
@@ -697,8 +716,11 @@ def main():
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
                     import p2_reference
-                    pref = p2_reference.run(soil, 1024, 10, 16, eng_name, device=local_rank, verbose=False, water_batches=r.get("water_generations"))
-                    pref["headline_size_record"] = headline_parity_record(r.get("water_generations"))
+                    pref = p2_reference.run(soil, 1024, 10, 16, eng_name, device=local_rank, verbose=False,
+                                            variants=[{"name": "run", "generations": r.get("water_generations"), "stagger": r.get("water_stagger") or 0, "strips": 1, "stream": 0}])
+                    if "variants" in pref:                          # (one configuration: the block of round 5's shape)
+                        pref.update(pref.pop("variants")["run"])
+                    pref["headline_size_record"] = headline_parity_record(r.get("water_generations"), 1, r.get("water_stagger") or 0)
                 except Exception as e:
                     pref = {"error": str(e)}
         if args.only is not None:
@@ -740,7 +762,7 @@ def main():
                     break
                 except (OSError, ValueError, KeyError):
                     pass
-        hrec = headline_parity_record(r.get("water_generations"), world if strips else 1) if (throughput and n == 4096 and nwater // max(world if (strips and not args.strong) else 1, 1) == 64000 and soil == SOIL) else None
+        hrec = headline_parity_record(r.get("water_generations"), world if strips else 1, r.get("water_stagger") or 0) if (throughput and n == 4096 and nwater // max(world if (strips and not args.strong) else 1, 1) == 64000 and soil == SOIL) else None
         # parity_gate: the rule of tests/test_gpu_relaxed.py (nothing at |z| >= 3, at most one figure in [2, 3)) applied to THIS run's own check against the
         # reference (1024^2, 16 control streams) and to the committed record at the headline's size; "fail" if either breaks it
         g_run = (pref or {}).get("gate") if isinstance(pref, dict) else None
@@ -752,6 +774,7 @@ def main():
             parity_gate = {"verdict": verdict, "rule": "no figure at |z| >= 3, at most one in [2, 3) (eight figures, z against the reference's own rand()-stream spread)",
                            "this_run_1024": g_run, "headline_size_record": ({"file": hrec["file"], "variant": hrec["variant"], "gate": g_rec, "outliers": hrec["outliers"]} if hrec else None)}
         config = {"workload": workload, "engine": eng_name, "water_generations": r.get("water_generations") if throughput else None,
+                  "water_stagger": r.get("water_stagger") if throughput else None,
                   "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
                   "parity": p2 if throughput else head["parity"]}
         detail = {

@@ -237,6 +237,12 @@ int smx_set_grid_interleave(smx_ctx* ctx, int32_t k);
  * behaviour and a cost change (the water phase ~1.3 x) unless they call smx_set_water_generations(4). Identical to k calls of n/k with k = 1. */
 int smx_set_water_generations(smx_ctx* ctx, int32_t k);
 int smx_get_water_generations(smx_ctx* ctx, int32_t* k);   /* the value in force (bench.py reports it instead of a literal) */
+/* relaxed engine: STAGGERED generations. gap_epochs > 0: a water phase of n particles is ONE phase whose k batches of ceil(n / k) particles (by slot) are
+ * born gap_epochs apart -- batch b takes its first step in epoch b * gap --; 0: k consecutive generations, each run to its end. A particle of batch b
+ * finds what the batches before it did in the epochs they are ahead (the lakes their stopped particles made); the tick's epoch chain is (k - 1) * gap + one
+ * generation long instead of k generations. Part of the schedule's definition (results depend on it); default: see SMX_WATER_STAGGER in csrc/soil_batch.h. */
+int smx_set_water_stagger(smx_ctx* ctx, int32_t gap_epochs);
+int smx_get_water_stagger(smx_ctx* ctx, int32_t* gap_epochs);
 /* batched engine: column strips (DESIGN.md "Multi-GPU"). The schedule alternates INTERIOR chunks (a particle acts iff its
  * reservation lies `inset` cells inside one of `nstrips` equal x-strips) and SEAM chunks (iff inside one seam zone of
  * +-seam_halfwidth cells around a strip boundary). nstrips == 1 (default) = the single-strip schedule. The result is a
@@ -293,6 +299,10 @@ int smx_strips_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater
 /* what the transport itself cost since it was attached: stream synchronisations it asked for and ncclGroupStart/End pairs (RCCL: 2 groups and at most
  * 2 synchronisations per seam exchange since round 6 -- pack counts, incoming header --, plus one per all-reduce) */
 int smx_strips_sync_stats(smx_ctx* ctx, uint64_t* host_syncs, uint64_t* groups);
+/* one synthetic seam message (nrec column records in nbytes bytes, npart particle records) from this rank to this very rank through the attached transport's
+ * exchange -- with RCCL: the grouped ncclSend / ncclRecv pairs of a real seam exchange -- compared byte for byte on return (0; -4 = it came back changed).
+ * What a single device can check of the path several GPUs depend on; nothing in the reference corresponds to it. */
+int smx_strips_selfcheck(smx_ctx* ctx, uint32_t nrec, uint32_t nbytes, uint32_t npart);
 int smx_strips_stats(smx_ctx* ctx, uint64_t* chunks, uint64_t* seam_chunks, uint64_t* generations, uint64_t* bytes_sent, uint64_t* messages);
 /* batched engine: epochs (kernel rounds), generations and dropped child particles since the context was created */
 int smx_get_batch_stats(smx_ctx* ctx, uint64_t* epochs, uint64_t* generations, uint64_t* children_lost);

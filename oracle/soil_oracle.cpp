@@ -939,6 +939,8 @@ struct so_ctx {
   // =====================================================================================================
   bool b_relaxed = false;
   int b_water_generations = 8;                                // so_set_water_generations (smx_set_water_generations; the engine's default)
+  int b_water_stagger = 0;                                    // (== csrc/soil_batch.h SMX_WATER_STAGGER, the engine's default) so_set_water_stagger (smx_set_water_stagger): > 0 = a relaxed water phase is ONE phase whose k batches of ceil(n / k)
+                                                              // particles (by slot) take their first step in epoch batch * gap
   struct RReq { int x, y; double vol, amount; uint32_t type; int kind; int cx, cy; };   // kind 1: erode, 2: deposit
   uint32_t r_surf(int x, int y) const { const uint32_t t = top[cidx(x, y)]; return t == NIL ? 0u : type[t]; }
   bool r_precheck(int x, int y) const {
@@ -963,6 +965,8 @@ struct so_ctx {
     std::vector<std::pair<int, int>> lists[9];
     std::vector<uint32_t> stamp((size_t)dimx * dimy, 0u);     // epoch + 1 of the last cascade request of a cell
     uint32_t epoch = 0, chunk = 0;
+    uint32_t birth_n = 0, birth_gap = 0;                      // smx_set_water_stagger: a top-level generation of a staggered phase is the whole phase
+    if (b_water_stagger > 0 && b_water_generations > 1 && nslots && sl[0].toplevel) { birth_n = (nslots + (uint32_t)b_water_generations - 1u) / (uint32_t)b_water_generations; birth_gap = (uint32_t)b_water_stagger; }
     for (uint32_t i = 0; i < nslots; i++)                    // records whose flood is what did not fit their parent's region: reserved for epoch 0
       if (sl[i].state == B_ENDED && bs_n <= 1) { sl[i].rect = b_water_need_flood(sl[i].w); claim_for[i] = 0u; waiting.push_back(i); }
     auto running = [&] { for (const BSlot& q : sl) if (q.state != B_DONE) return true; return false; };
@@ -988,6 +992,7 @@ struct so_ctx {
       for (uint32_t i = 0; i < nslots; i++) {
         BSlot& q = sl[i];
         if (q.state != B_RUN && q.state != B_NEW) continue;
+        if (q.state == B_NEW && q.toplevel && birth_gap && epoch < (i / birth_n) * birth_gap) continue;   // staggered generations: not born yet (it waits as it was spawned)
         nrun++;
         Water t = q.w;
         const double vol0 = t.volume;
@@ -1290,9 +1295,11 @@ void so_batched_water(so_ctx* c, int n) { c->b_generations(false, (uint32_t)(n >
 void so_batched_wind(so_ctx* c, int n) { c->b_generations(true, (uint32_t)(n > 0 ? n : 0), {}); }
 void so_batched_grid(so_ctx* c) { c->batched_grid(); }
 void so_set_water_generations(so_ctx* c, int k) { c->b_water_generations = k < 1 ? 1 : k; }
+void so_set_water_stagger(so_ctx* c, int gap) { c->b_water_stagger = gap < 0 ? 0 : gap; }
 void so_batched_tick(so_ctx* c, int nwater, int nwind, int dowater, int dowind) {
   if (dowater) {                                              // smx_tick_water: k consecutive top-level generations of n/k (soil_batch.h SMX_WATER_GENERATIONS)
     uint32_t left = nwater > 0 ? (uint32_t)nwater : 0u;
+    if (c->b_relaxed && c->b_water_stagger > 0 && c->b_water_generations > 1 && left > 0) { so_batched_water(c, (int)left); left = 0; }   // ONE staggered phase (smx_set_water_stagger)
     for (uint32_t q = 0, k = (uint32_t)c->b_water_generations; q < k && left > 0; q++) { const uint32_t nq = left / (k - q); left -= nq; if (nq) so_batched_water(c, (int)nq); }
     so_batched_grid(c);
   }

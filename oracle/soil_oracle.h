@@ -77,6 +77,7 @@ void so_seep(so_ctx*, int x, int y);
 void so_batched_water(so_ctx*, int n);
 void so_batched_grid(so_ctx*);
 void so_batched_wind(so_ctx*, int n);
+void so_set_water_stagger(so_ctx*, int gap_epochs);   // relaxed schedule: the k generations of a water phase born gap_epochs apart inside one phase (smx_set_water_stagger; 0 = off)
 void so_set_water_generations(so_ctx*, int k);   // the water phase of so_batched_tick as k consecutive generations of n/k (default 8, as the engine)
 void so_batched_tick(so_ctx*, int nwater, int nwind, int dowater, int dowind);
 void so_set_relaxed(so_ctx*, int on);   // SMX_ENGINE_RELAXED restated (csrc/soil_relax.h): water generations step / apply / cascade colours / floods per epoch

@@ -75,7 +75,7 @@ SYMBOLS = [
     "smx_read_frequency", "smx_read_heights", "smx_read_surface", "smx_tick_water", "smx_grid_pass", "smx_tick_wind",
     "smx_map_frequency", "smx_reset_frequency", "smx_tick", "smx_sync", "smx_add", "smx_remove",
     "smx_particle_cascade", "smx_water_cascade", "smx_seep", "smx_top", "smx_normals", "smx_heights_bilinear", "smx_fill_vertices", "smx_fill_vertices_cut", "smx_fill_vertex_cut",
-    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_get_counters_sized", "smx_get_timing_sized", "smx_timing_reset", "smx_set_engine", "smx_set_spec_limits", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind", "smx_set_relax_launch", "smx_set_grid_interleave", "smx_set_water_generations", "smx_get_water_generations", "smx_strips_rccl_unique_id", "smx_strips_attach_rccl", "smx_strips_attach", "smx_strips_detach", "smx_strips_tick", "smx_strips_stats", "smx_strips_sync_stats",
+    "smx_digest", "smx_save", "smx_load", "smx_get_counters", "smx_get_timing", "smx_get_counters_sized", "smx_get_timing_sized", "smx_timing_reset", "smx_set_engine", "smx_set_spec_limits", "smx_stream", "smx_set_batch_dilate", "smx_get_batch_stats", "smx_set_batch_strips", "smx_set_relax_wind", "smx_set_relax_launch", "smx_set_grid_interleave", "smx_set_water_generations", "smx_get_water_generations", "smx_set_water_stagger", "smx_get_water_stagger", "smx_strips_rccl_unique_id", "smx_strips_attach_rccl", "smx_strips_attach", "smx_strips_detach", "smx_strips_tick", "smx_strips_stats", "smx_strips_sync_stats", "smx_strips_selfcheck",
     "smx_d_set_own", "smx_d_gen_begin", "smx_d_gen_spawn", "smx_d_next_phase", "smx_d_chunk", "smx_d_gen_end", "smx_d_pack_columns",
     "smx_d_unpack_columns", "smx_d_pack_particles", "smx_d_unpack_particles", "smx_d_grid_begin", "smx_d_grid_sweep_cols",
     "smx_lbm_create", "smx_lbm_destroy", "smx_lbm_last_error", "smx_lbm_set_boundary", "smx_lbm_boundary_from_map", "smx_lbm_initialize",
@@ -142,6 +142,8 @@ def load() -> C.CDLL:
     L.smx_set_engine.argtypes = [vp, i32]
     L.smx_set_water_generations.argtypes = [vp, i32]
     L.smx_get_water_generations.argtypes = [vp, C.POINTER(i32)]
+    L.smx_set_water_stagger.argtypes = [vp, i32]
+    L.smx_get_water_stagger.argtypes = [vp, C.POINTER(i32)]
     L.smx_set_spec_limits.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.smx_set_batch_dilate.argtypes = [vp, i32]
     L.smx_set_batch_strips.argtypes = [vp, i32, i32, i32]
@@ -155,6 +157,7 @@ def load() -> C.CDLL:
     L.smx_strips_tick.argtypes = [vp, i32, i32, i32, i32]
     L.smx_strips_stats.argtypes = [vp] + [C.POINTER(u64)] * 5
     L.smx_strips_sync_stats.argtypes = [vp] + [C.POINTER(u64)] * 2
+    L.smx_strips_selfcheck.argtypes = [vp, u32, u32, u32]
     L.smx_d_set_own.argtypes = [vp, i32, i32]
     L.smx_d_gen_begin.argtypes = [vp, i32, u32, vp, vp]
     L.smx_d_gen_spawn.argtypes = [vp, vp, C.POINTER(u32)]

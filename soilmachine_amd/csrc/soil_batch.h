@@ -49,6 +49,8 @@ constexpr int SMX_WATER_GENERATIONS = 8;      // a tick's water particles run as
                                               // (4096^2, 64 000 + 16 000, profiles/r06_p2_reference_4096.json): one generation is outside on four of eight figures by 4.8-7.9
                                               // sigma, four (round 5's default) on three by 2.3-3.0 (nested particles -23 %), EIGHT inside |z| < 2 on all eight, also under the
                                               // two-strip schedule and two of three other device streams; sixteen: water volume +2.1
+constexpr int SMX_WATER_STAGGER = 0;          // epochs between the births of two consecutive generations inside ONE water phase (smx_set_water_stagger); 0 = the generations run one after
+                                              // the other, each to its end
 constexpr int B_CHUNK = 32;                   // epochs between two looks at the number of running particles (schedule, compaction)
 constexpr int B_MAXCHILD = 250;               // nested particles one flood / one grid tile may emit per pass (the key keeps 8 bits for the sequence). Round 5: 24 -> 250:
                                               // a 4x4 tile of lake cells spawns more than 24 (every sweep position can send off its own film and those of its eight
@@ -105,6 +107,8 @@ struct BatchShared {
   BStrips strips; int sphase;                 // column strips and the kind of the running chunk
   uint8_t* dirty;                             // [grid tiles] strips only: columns of this 4x4 tile changed since the last halo exchange
   int own_x0, own_x1;                         // strips on several devices: particles spawning outside [own_x0, own_x1) live elsewhere
+  uint32_t birth_n, birth_gap;                // STAGGERED generations (smx_set_water_stagger; 0 = off): top-level water slot i is born -- takes its first step -- in epoch
+                                              // (i / birth_n) * birth_gap of its phase; until then it waits as B_NEW (relax_water_step)
   // RELAXED schedule (soil_relax.h): running particles step without reservations; their map edits are queued per cell
   int relaxed;                                // 1: the epoch kernel only runs floods (B_ENDED); running particles belong to relax_*_step
   int rstride, rsteps;                        // request entries per slot (2 per step); steps a particle may take per epoch (water 1)

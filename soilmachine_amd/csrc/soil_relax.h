@@ -125,6 +125,7 @@ SMX_D void relax_water_step(Sim<P>& sim, const BatchShared& bs, uint32_t slot, u
   BWater& q = bs.water[slot];
   uint32_t state = q.state;
   if (state != B_RUN && state != B_NEW) { bs.rcount[slot] = 0u; return; }
+  if (state == B_NEW && bs.birth_gap && q.toplevel && epoch < (slot / bs.birth_n) * bs.birth_gap) { bs.rcount[slot] = 0u; return; }   // staggered generations: not born yet
   const DevState& s = sim.s;
   const SoilP* soils = sim.soils;
   Water w = q.w;

@@ -457,6 +457,13 @@ int smx_strips_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater
     roctx_range rw("soilmx:strips:water");
     uint32_t left = nwater > 0 ? (uint32_t)nwater : 0u;       // as smx_tick_water: k consecutive top-level generations of n/k
     const uint32_t k = ctx->water_generations < 1 ? 1u : (uint32_t)ctx->water_generations;
+    if (ctx->cfg.engine == SMX_ENGINE_RELAXED && ctx->water_stagger > 0 && k > 1u && left > 0u) {   // staggered generations: one phase (smx_tick_water)
+      ctx->stagger_phase_n = left;
+      const int rc = st_phase(ctx, S, false, left, {}, false);
+      ctx->stagger_phase_n = 0u;
+      if (rc) return -1;
+      left = 0u;
+    }
     for (uint32_t q = 0; q < k && left > 0; q++) {
       const uint32_t nq = left / (k - q);
       left -= nq;
@@ -472,6 +479,35 @@ int smx_strips_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater
 int smx_strips_sync_stats(smx_ctx* ctx, uint64_t* host_syncs, uint64_t* groups) {   // what the transport itself cost: stream synchronisations, grouped operations
   if (!ctx->strip) return -2;
   if (host_syncs) *host_syncs = ctx->strip->T->host_syncs; if (groups) *groups = ctx->strip->T->groups;
+  return 0;
+}
+// ONE synthetic seam message from this rank to this very rank through the attached transport's exchange() -- header group, size synchronisation, payload group --
+// compared byte for byte on the way back. With RCCL a send and a receive of the same rank pair up inside one group, so a single device exercises the
+// grouped ncclSend / ncclRecv calls, their stream ordering and the header ring of RcclTransport::exchange that a run on several GPUs depends on (round 6).
+int smx_strips_selfcheck(smx_ctx* ctx, uint32_t nrec, uint32_t nbytes, uint32_t npart) {
+  if (!ctx->strip) { ctx->err = "smx_strips_selfcheck: no transport attached"; return -2; }
+  if (batch_alloc(ctx, 1, false) || xbuf_alloc_strips(ctx)) return -1;
+  const uint32_t rs = 4 + (uint32_t)sizeof(BWater);
+  if (nrec > ctx->xoffs_cap || nbytes > ctx->xdata_cap || (uint64_t)npart * rs > ctx->xpart_cap) { ctx->err = "smx_strips_selfcheck: larger than the exchange buffers"; return -2; }
+  hipStream_t st = ctx->stream;
+  StripTransport* T = ctx->strip->T;
+  std::vector<uint32_t> offs(nrec); std::vector<uint8_t> data(nbytes), part((size_t)npart * rs);
+  uint32_t x = 0x9e3779b9u ^ (nrec * 31u + nbytes * 7u + npart);
+  auto nxt = [&x]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+  for (auto& v : offs) v = nxt(); for (auto& v : data) v = (uint8_t)nxt(); for (auto& v : part) v = (uint8_t)nxt();
+  if (nrec) HIPCHK(hipMemcpyAsync(ctx->d_xoffs, offs.data(), 4ull * nrec, hipMemcpyHostToDevice, st));
+  if (nbytes) HIPCHK(hipMemcpyAsync(ctx->d_xdata, data.data(), nbytes, hipMemcpyHostToDevice, st));
+  if (npart) HIPCHK(hipMemcpyAsync(ctx->d_xpart, part.data(), part.size(), hipMemcpyHostToDevice, st));
+  if (nrec) HIPCHK(hipMemsetAsync(ctx->d_roffs, 0, 4ull * nrec, st)); if (nbytes) HIPCHK(hipMemsetAsync(ctx->d_rdata, 0, nbytes, st)); if (npart) HIPCHK(hipMemsetAsync(ctx->d_rpart, 0, part.size(), st));
+  XBundle out, in; out.nrec = nrec; out.nbytes = nbytes; out.npart = npart; out.rs = rs; out.pad[0] = 0x5e1fc4ecu;
+  if (T->exchange(ctx, T->rank, &out, T->rank, &in)) return -1;
+  HIPCHK(hipStreamSynchronize(st));
+  if (memcmp(&in, &out, sizeof(XBundle)) != 0) { ctx->err = "smx_strips_selfcheck: the header came back changed"; return -4; }
+  std::vector<uint32_t> roffs(nrec); std::vector<uint8_t> rdata(nbytes), rpart(part.size());
+  if (nrec) HIPCHK(hipMemcpy(roffs.data(), ctx->d_roffs, 4ull * nrec, hipMemcpyDeviceToHost));
+  if (nbytes) HIPCHK(hipMemcpy(rdata.data(), ctx->d_rdata, nbytes, hipMemcpyDeviceToHost));
+  if (npart) HIPCHK(hipMemcpy(rpart.data(), ctx->d_rpart, part.size(), hipMemcpyDeviceToHost));
+  if (roffs != offs || rdata != data || rpart != part) { ctx->err = "smx_strips_selfcheck: a payload came back changed"; return -4; }
   return 0;
 }
 int smx_strips_stats(smx_ctx* ctx, uint64_t* chunks, uint64_t* seam_chunks, uint64_t* generations, uint64_t* bytes_sent, uint64_t* messages) {

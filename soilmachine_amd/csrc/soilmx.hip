@@ -1200,6 +1200,8 @@ struct smx_ctx {
   smx_timing timing{};
   uint32_t spec_sub = 0, spec_maxnest = 0; bool spec_realloc = false;   // smx_set_spec_limits (0 = defaults)
   int water_generations = SMX_WATER_GENERATIONS;             // smx_set_water_generations (throughput engines: 8)
+  int water_stagger = SMX_WATER_STAGGER;                     // smx_set_water_stagger: > 0 = the k generations of a water phase are BORN this many epochs apart inside ONE phase (relaxed engine)
+  uint32_t stagger_phase_n = 0;                              // ... the top-level particle count of the phase that is running staggered (0: none)
   uint64_t spec_rounds = 0, spec_aborts = 0, spec_kills = 0, spec_fallbacks = 0, spec_executed = 0, spec_subphases_cut = 0, spec_serial_particles = 0;
   SpecShared sh{};                    // speculative engine buffers (allocated on first use)
   uint32_t spec_cap = 0;              // particles the buffers are sized for
@@ -1449,6 +1451,12 @@ int smx_set_batch_dilate(smx_ctx* ctx, int32_t tiles) {
   return 0;
 }
 int smx_get_water_generations(smx_ctx* ctx, int32_t* k) { if (!k) return -2; *k = ctx->water_generations; return 0; }
+int smx_set_water_stagger(smx_ctx* ctx, int32_t gap_epochs) {
+  if (gap_epochs < 0 || gap_epochs > 65536) { ctx->err = "smx_set_water_stagger: 0 (consecutive generations) .. 65536 epochs"; return -2; }
+  ctx->water_stagger = gap_epochs;
+  return 0;
+}
+int smx_get_water_stagger(smx_ctx* ctx, int32_t* gap_epochs) { if (!gap_epochs) return -2; *gap_epochs = ctx->water_stagger; return 0; }
 int smx_set_water_generations(smx_ctx* ctx, int32_t k) {
   if (k < 1 || k > 64) { ctx->err = "smx_set_water_generations: 1..64"; return -2; }
   ctx->water_generations = k;
@@ -2049,7 +2057,11 @@ static int batch_alloc(smx_ctx* ctx, uint32_t nslots, bool wind) {
   bs.draws = ctx->d_draws; bs.dilate = ctx->batch_dilate; bs.maxsteps = 1;
   bs.strips = batch_make_strips(ctx->cfg.dimx, ctx->strips_n, ctx->strips_a, ctx->strips_b); bs.sphase = STRIP_INTERIOR;
   bs.own_x0 = ctx->own_x0; bs.own_x1 = ctx->own_x1 < 0 ? ctx->cfg.dimx : ctx->own_x1;
-  (void)wind;
+  bs.birth_n = 0u; bs.birth_gap = 0u;
+  if (!wind && ctx->stagger_phase_n) {                       // staggered generations (smx_set_water_stagger): slot i of the phase's top-level particles is born in epoch (i / birth_n) * gap
+    const uint32_t k = (uint32_t)(ctx->water_generations < 1 ? 1 : ctx->water_generations);
+    bs.birth_n = (ctx->stagger_phase_n + k - 1u) / k; bs.birth_gap = (uint32_t)ctx->water_stagger;
+  }
   return 0;
 }
 // generations of one phase: `kids` = children to start from (grid pass), else n top-level particles
@@ -2428,6 +2440,8 @@ int smx_d_set_own(smx_ctx* ctx, int32_t x0, int32_t x1) { ctx->own_x0 = x0; ctx-
 int smx_d_gen_begin(smx_ctx* ctx, int32_t wind, uint32_t nslots, const void* kids_host, uint32_t* contains_out) {
   hipStream_t st = ctx->stream;
   ctx->d_wind = wind != 0; ctx->d_first = kids_host == nullptr; ctx->d_nslots = nslots; ctx->d_epoch = 0; ctx->d_chunk = 0;
+  if (!ctx->strip)                                           // (the step-wise driver of tests/strips_ref.py: a top-level water generation of a staggered phase is the whole phase; smx_strips_tick sets it itself)
+    ctx->stagger_phase_n = (!wind && !kids_host && ctx->cfg.engine == SMX_ENGINE_RELAXED && ctx->water_stagger > 0 && ctx->water_generations > 1) ? nslots : 0u;
   if (batch_alloc(ctx, nslots ? nslots : 1, ctx->d_wind)) return -1;
   RandState r;                                              // every rank holds the same generator state and draws the same values
   HIPCHK(hipMemcpyAsync(&r, ctx->d.rnd, sizeof(r), hipMemcpyDeviceToHost, st));
@@ -2625,6 +2639,15 @@ int smx_tick_water(smx_ctx* ctx, int32_t nwater) {
     // throughput for the reference's feedback between particles of a tick (profiles/r04_p2_analysis.md). Exactly k phase calls of n/k.
     uint32_t left = nwater > 0 ? (uint32_t)nwater : 0u;
     const uint32_t k = ctx->water_generations < 1 ? 1u : (uint32_t)ctx->water_generations;
+    if (ctx->cfg.engine == SMX_ENGINE_RELAXED && ctx->water_stagger > 0 && k > 1u && left > 0u) {
+      // STAGGERED generations (smx_set_water_stagger): ONE phase; batch b of ceil(n / k) particles takes its first step in epoch b * gap. A particle of
+      // batch b finds what the batches before it have done in the `gap` epochs they are ahead -- the lakes their stopped particles made on the way --, the
+      // epoch chain of a tick is (k - 1) * gap + one generation long instead of k generations (relax_water_step)
+      ctx->stagger_phase_n = left;
+      const int rc = batch_generations(ctx, false, left, 0u);
+      ctx->stagger_phase_n = 0u;
+      return rc;
+    }
     for (uint32_t q = 0; q < k && left > 0; q++) {
       const uint32_t nq = left / (k - q);
       left -= nq;

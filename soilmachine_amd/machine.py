@@ -189,6 +189,15 @@ class Layermap:
         """throughput engines: the water phase's particles as k consecutive generations of n/k (smx_set_water_generations)"""
         self._chk(self.L.smx_set_water_generations(self.h, int(k)))
 
+    def set_water_stagger(self, gap_epochs: int):
+        """relaxed engine: the k generations of a water phase born `gap_epochs` apart inside ONE phase (smx_set_water_stagger; 0 = one after the other)"""
+        self._chk(self.L.smx_set_water_stagger(self.h, int(gap_epochs)))
+
+    def water_stagger(self) -> int:
+        g = C.c_int32()
+        self._chk(self.L.smx_get_water_stagger(self.h, C.byref(g)))
+        return int(g.value)
+
     def water_generations(self) -> int:
         k = C.c_int32()
         self._chk(self.L.smx_get_water_generations(self.h, C.byref(k)))

@@ -228,6 +228,10 @@ class LibStripRank:
             d["transport_host_syncs_per_seam_chunk"] = d["transport_host_syncs"] / d["seam_chunks"]
         return d
 
+    def selfcheck(self, nrec: int, nbytes: int, npart: int):
+        """One synthetic seam message from this rank to itself through the attached transport's exchange (smx_strips_selfcheck); raises when it comes back changed."""
+        self.lm._chk(self.L.smx_strips_selfcheck(self.h, int(nrec), int(nbytes), int(npart)))
+
     def detach(self):
         self.lm._chk(self.L.smx_strips_detach(self.h))
 

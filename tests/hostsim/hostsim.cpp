@@ -427,6 +427,10 @@ static uint32_t g_relax_wind_min = 0xFFFFFFFFu;                   // wind: relax
 static int g_relax_wind_steps = 4;                          // ... taking up to this many steps per epoch (smx_set_relax_wind)
 static std::atomic<uint32_t> g_relax_tag{0};   // (atomic: several HostSim instances may tick on different threads of one process, tools/p2_ensemble.py)
 extern "C" void hs_set_relaxed(int on) { g_relaxed = on; }
+static uint32_t g_stagger_k = 0, g_stagger_gap = SMX_WATER_STAGGER;   // smx_set_water_stagger: one water phase = k batches born `gap` epochs apart (gap 0: off; k 0: smx_set_water_generations' k)
+extern "C" void hs_set_water_stagger(uint32_t k, uint32_t gap) { g_stagger_k = k; g_stagger_gap = gap; }
+static int g_water_generations = SMX_WATER_GENERATIONS;      // smx_set_water_generations
+static uint32_t stagger_k() { return g_stagger_k ? g_stagger_k : (uint32_t)g_water_generations; }
 static int g_relax_water_steps = 1;                         // relaxed water: steps per epoch (smx_set_relax_water)
 extern "C" void hs_set_relax_water(int steps) { g_relax_water_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
 extern "C" void hs_set_relax_wind(uint32_t n, int steps) { g_relax_wind_min = n; g_relax_wind_steps = steps < 1 ? 1 : (steps > R_MAXSTEPS ? R_MAXSTEPS : steps); }
@@ -447,6 +451,8 @@ static void batch_setup(hs_ctx* c, BatchBuffers& b, uint32_t nslots, bool wind) 
   b.bs.dirty = c->dirty.data(); b.bs.own_x0 = c->own_x0; b.bs.own_x1 = c->own_x1 < 0 ? s.dimx : c->own_x1;
   b.bs.freed = b.freed.data(); b.bs.freed_cap = (uint32_t)b.freed.size(); b.bs.ctrl = b.ctrl.data(); b.bs.draws = b.draws.data();
   b.bs.relaxed = g_relaxed ? 1 : 0;
+  b.bs.birth_n = 0u; b.bs.birth_gap = 0u;
+  if (!wind && g_relaxed && stagger_k() > 1u && g_stagger_gap > 0u && nslots) { b.bs.birth_n = (nslots + stagger_k() - 1u) / stagger_k(); b.bs.birth_gap = g_stagger_gap; }   // (children: toplevel == 0, never delayed)
   b.bs.req = nullptr; b.bs.rnext = nullptr; b.bs.rcount = nullptr; b.bs.rhead = nullptr; b.bs.cflag = nullptr; b.bs.cstate = nullptr;
   b.bs.flist[0] = b.bs.flist[1] = b.bs.clist[0] = b.bs.clist[1] = b.bs.flagl[0] = b.bs.flagl[1] = nullptr; b.bs.rstride = 2; b.bs.rsteps = 1; b.bs.rtag = 0;
   if (b.bs.relaxed) {
@@ -702,11 +708,12 @@ void hs_batched_grid(hs_ctx* c, int nthreads, unsigned shuffle) {
   std::sort(kids.begin(), kids.end(), [](const BChild& a, const BChild& d) { return a.key < d.key; });
   if (!kids.empty()) { BatchBuffers b2; batch_generations(c, b2, false, 0, kids, nthreads, shuffle); }   // the nested particles that left their tile's region
 }
-static int g_water_generations = SMX_WATER_GENERATIONS;      // smx_set_water_generations
 void hs_set_water_generations(int k) { g_water_generations = k < 1 ? 1 : k; }
+void hs_reset_water_schedule() { g_water_generations = SMX_WATER_GENERATIONS; g_stagger_k = 0; g_stagger_gap = SMX_WATER_STAGGER; }   // the library's defaults (tests restore them with this)
 void hs_batched_tick(hs_ctx* c, int nwater, int nwind, int dowater, int dowind, int nthreads, unsigned shuffle) {
-  if (dowater) {                                              // smx_tick_water: k consecutive top-level generations of n/k
+  if (dowater) {                                              // smx_tick_water: k consecutive top-level generations of n/k -- or ONE staggered phase (smx_set_water_stagger)
     uint32_t left = nwater > 0 ? (uint32_t)nwater : 0u;
+    if (g_relaxed && g_stagger_gap > 0u && stagger_k() > 1u && left > 0u) { hs_batched_water(c, (int)left, nthreads, shuffle); left = 0u; }
     for (uint32_t q = 0, k = (uint32_t)g_water_generations; q < k && left > 0; q++) { const uint32_t nq = left / (k - q); left -= nq; if (nq) hs_batched_water(c, (int)nq, nthreads, shuffle); }
     hs_batched_grid(c, nthreads, shuffle);
   }

@@ -42,6 +42,7 @@ def lib():
         for f in ("hs_grid", "hs_freq"):
             getattr(L, f).argtypes = [vp]
         L.hs_set_water_generations.argtypes = [C.c_int]
+        L.hs_set_water_stagger.argtypes = [C.c_uint32, C.c_uint32]
         L.hs_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.hs_add.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_uint32]
         L.hs_remove.argtypes = [vp, C.c_int, C.c_int, C.c_double]; L.hs_remove.restype = C.c_double

@@ -79,6 +79,7 @@ def lib():
         L.so_water_cascade.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.so_seep.argtypes = [vp, C.c_int, C.c_int]
         L.so_set_water_generations.argtypes = [vp, C.c_int]
+        L.so_set_water_stagger.argtypes = [vp, C.c_int]
         L.so_batched_tick.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         for f in ("so_batched_water", "so_batched_wind"):
             getattr(L, f).argtypes = [vp, C.c_int]

@@ -88,6 +88,7 @@ class StripRank:
         backend.set_own(self.x0, self.x1)
         self.stats = {"chunks": 0, "seam_chunks": 0, "generations": 0}
         self.water_generations = 8                                # smx_set_water_generations' default (csrc/soil_batch.h SMX_WATER_GENERATIONS)
+        self.water_stagger = 0                                    # smx_set_water_stagger's default (SMX_WATER_STAGGER); > 0 and a relaxed backend: ONE staggered phase
 
     # -- halo traffic (nearest neighbours only). A rank holds, besides its strip, the b columns right of its right boundary.
     # one message per direction: [u64 length of the column part][columns][particles]
@@ -183,6 +184,8 @@ class StripRank:
     def tick(self, nwater: int, nwind: int, dowater: bool = True, dowind: bool = True):
         if dowater:                                               # smx_strips_tick: k consecutive top-level generations of n/k (csrc/soil_batch.h SMX_WATER_GENERATIONS)
             left, k = nwater, self.water_generations
+            if self.water_stagger > 0 and k > 1 and left > 0:      # (the backend -- device context or hostsim -- carries the same stagger setting: its gen_begin marks the phase)
+                self._phase(False, left); left = 0
             for q in range(k):
                 nq = left // (k - q); left -= nq
                 if nq:

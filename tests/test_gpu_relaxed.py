@@ -218,3 +218,37 @@ def test_launch_shapes_agree_at_size():
     assert {x: ca[x] for x in KEYS} == {x: cb[x] for x in KEYS}
     t = a.map.timing()
     assert t["launches_kernel_epochs"] > 0 and t["epochs_kernel_epochs"] > 0, "the persistent kernel did not run (cooperative launch refused?)"
+
+
+@pytest.mark.parametrize("strips", [1, 2])
+def test_staggered_generations_device_equals_host_threads(strips):
+    """smx_set_water_stagger (round 6): the k generations of a water phase born `gap` epochs apart inside ONE phase -- device against the same headers on
+    host threads (which equal the restatement: tests/test_relaxed.py), full state through lakes, also under the two-strip schedule."""
+    from hostsim_lib import lib
+    cfg = load_cfg("default.soil")
+    dimx = 256 if strips > 1 else 96
+    o = Oracle(cfg, dimx, 96, seed=0); o.initialize()
+    for _ in range(45):
+        o.tick(250, 0, True, False)
+    s0 = o.snapshot()
+    m = Layermap(cfg, dimx, 96, seed=0, initialize=False, engine=capi.ENGINE_RELAXED)
+    m.load(s0, rand_seed=0)
+    m.set_water_generations(4); m.set_water_stagger(30)
+    if strips > 1:
+        m.set_batch_strips(strips)
+    sm = SoilMachine.__new__(SoilMachine)
+    sm.cfg, sm.map, sm.nwater, sm.nwind, sm.dowater, sm.dowind = cfg, m, 300, 0, True, False
+    h = HostSim(cfg, dimx, 96, seed=0); h.load(s0, advance_rand=True)
+    L = lib()
+    try:
+        L.hs_set_water_generations(4); L.hs_set_water_stagger(0, 30); L.hs_set_batch_strips(strips, 16, 48)
+        for t in range(4):
+            sm.tick(1, sync=True)
+            h.relaxed_tick(300, 0, True, False, nthreads=4, shuffle=t + 3)
+            bad = compare(m.snapshot(), h.snapshot())
+            assert not bad, (t, bad)
+    finally:
+        L.hs_reset_water_schedule(); L.hs_set_batch_strips(1, 16, 48)
+    cd, ch = m.counters(), h.counters()
+    assert {k: cd[k] for k in KEYS} == {k: ch[k] for k in KEYS}
+    assert cd["floods"] > 300 and m.water_stagger() == 30

@@ -148,6 +148,13 @@ def test_rccl_transport_with_the_one_rank_a_single_device_allows():
         rk.tick(500, 250, True, True)
     assert not compare(m.snapshot(), ref)
     assert {k: m.counters()[k] for k in CK} == {k: cref[k] for k in CK}
+    # ... and the exchange itself, which one rank's ticks never reach: synthetic seam messages from the rank to itself through RcclTransport::exchange -- the
+    # grouped header send/receive, the size synchronisation, the grouped payloads -- byte for byte, from empty to tens of megabytes, repeatedly (the header ring)
+    g0 = rk.stats["transport_groups"]
+    for nrec, nbytes, npart in ((0, 0, 0), (1, 32, 0), (0, 0, 1), (1000, 96_000, 17), (300_000, 40_000_000, 4_000), (5, 160, 3)) + ((7, 224, 2),) * 70:
+        rk.selfcheck(nrec, nbytes, npart)
+    assert rk.stats["transport_groups"] - g0 == 2 * 76 - 1           # (the empty message has no payload group)
+    rk.tick(500, 250, True, True)                                    # the communicator is still usable
     rk.detach()
 
 

@@ -10,6 +10,7 @@ What is and is not claimed (DESIGN.md "Relaxed schedule"):
   * against the reference: parity tier P2 (statistical), held to the same envelope as the batched schedule -- it is NOT the
     reference's particle order and is never claimed bit-exact."""
 import numpy as np
+import ctypes
 import pytest
 
 from common import golden_snapshot, load_cfg
@@ -232,3 +233,36 @@ def test_water_generations_equal_the_independent_restatement(gens):
     ch, co = h.counters(), o.counters()
     assert {x: ch[x] for x in RKEYS if x != "rand_calls"} == {x: co[x] - base[x] for x in RKEYS if x != "rand_calls"}
     assert co["nested_particles"] - base["nested_particles"] > 300 and o.batched_stats()["guard_violations"] == 0
+
+
+@pytest.mark.parametrize("strips", [1, 2])
+def test_staggered_generations_equal_the_independent_restatement(strips):
+    """smx_set_water_stagger: ONE water phase whose k batches are born `gap` epochs apart (soil_relax.h relax_water_step) -- the device headers on host
+    threads against the restatement (oracle/soil_oracle.cpp r_water_generation): full state and counters through lakes, with and without column strips."""
+    from hostsim_lib import lib
+    cfg = load_cfg("default.soil")
+    dimx = 256 if strips > 1 else 96
+    o = Oracle(cfg, dimx, 96, seed=0); o.initialize()
+    for _ in range(45):
+        o.tick(250, 0, True, False)
+    s0 = o.snapshot()
+    o = Oracle(cfg, dimx, 96, seed=0); o.load(s0)
+    h = HostSim(cfg, dimx, 96, seed=0); h.load(s0, advance_rand=True)
+    c0 = o.counters()
+    L = lib()
+    OL = o.L
+    OL.so_batched_set_strips.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
+    L.hs_set_batch_strips.argtypes = [ctypes.c_int] * 3
+    try:
+        L.hs_set_water_generations(4); L.hs_set_water_stagger(0, 30); L.hs_set_batch_strips(strips, 16, 48)
+        OL.so_set_water_generations(o.h, 4); OL.so_set_water_stagger(o.h, 30); OL.so_batched_set_strips(o.h, strips, 16, 48)
+        for t in range(4):
+            h.relaxed_tick(300, 0, True, False, nthreads=3, shuffle=t + 1)
+            o.relaxed_tick(300, 0, True, False)
+            bad = compare(h.snapshot(), o.snapshot())
+            assert not bad, (t, bad)
+    finally:
+        L.hs_reset_water_schedule(); L.hs_set_batch_strips(1, 16, 48)
+    ch, co = h.counters(), o.counters()
+    assert {k: ch[k] for k in RKEYS} == {k: co[k] - (c0[k] if k != "rand_calls" else 0) for k in RKEYS}
+    assert ch["floods"] > 300 and o.batched_stats()["guard_violations"] == 0

@@ -35,7 +35,7 @@ for s in "$@"; do
     headrelax) run headrelax 30 300 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     headrelax8) run headrelax8 30 300 env SMX_RELAX_WIND_STEPS=8 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
     headrelaxw0) run headrelaxw0 30 300 env SMX_RELAX_WIND_MIN=4000000000 python bench.py --engine relaxed --no-lines --no-cpu-baseline --steps 5 --warmup 3 ;;
-    drv)       run drv 60 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-lines --no-cpu-baseline; cp $out/drv.log $out/drv.json 2>/dev/null ;;
+    drv)       run drv 60 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-lines --no-cpu-baseline ${BENCH_EXTRA:-}; cp $out/drv.log $out/drv.json 2>/dev/null ;;
     drvk4)     run drvk4 60 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-lines --no-cpu-baseline --water-generations ${WGEN:-1}; cp $out/drvk4.log $out/drvk4.json 2>/dev/null ;;
     gaps)      run gaps 30 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/gaps -o t -- python bench.py --engine ${ENGINE:-relaxed} --no-lines --no-cpu-baseline --steps 2 --warmup ${GWARM:-6}
                python tools/kernel_stats.py $out/gaps | tee $out/gaps.kernels

@@ -16,7 +16,8 @@ heavy-tailed at this sample size, and its z is quoted with that caveat. Height R
 CHECKER ONLY: nothing here is on the product path.
 
   p2_reference.py [--size 4096] [--ticks 10] [--nctl 32] [--variants k4,k8,k4s2,k4r1,k4r2] [--soil ...] [--out profiles/...json]
-A variant is k<generations>[s<strips>][r<device rand stream>]: k8 = eight water generations; k4s2 = the two-strip schedule in one context
+A variant is k<generations>[e<stagger>][s<strips>][r<device rand stream>]: k8 = eight water generations; k8e140 = the eight generations born 140 epochs apart inside one phase
+(smx_set_water_stagger); k4s2 = the two-strip schedule in one context
 (smx_set_batch_strips -- what `bench.py --gpus 2` runs on every rank); k4r1 = the device under srand(1000 + 7919 * 101) instead of SEED's.
 Counts are area-scaled (250 * (N/256)^2 water, NWIND/NWATER of the soil file).
 """
@@ -119,10 +120,10 @@ def calibration(ref, ctl):
 
 
 def parse_variant(name: str) -> dict:
-    m = re.fullmatch(r"k(\d+)(?:s(\d+))?(?:r(\d+))?", name)
+    m = re.fullmatch(r"k(\d+)(?:e(\d+))?(?:s(\d+))?(?:r(\d+))?", name)
     if not m:
-        raise ValueError(f"variant {name!r}: expected k<generations>[s<strips>][r<stream>]")
-    return {"name": name, "generations": int(m.group(1)), "strips": int(m.group(2) or 1), "stream": int(m.group(3) or 0)}
+        raise ValueError(f"variant {name!r}: expected k<generations>[e<stagger epochs>][s<strips>][r<stream>]")
+    return {"name": name, "generations": int(m.group(1)), "stagger": int(m.group(2) or 0), "strips": int(m.group(3) or 1), "stream": int(m.group(4) or 0)}
 
 
 def device_run(cfg, size, ticks, nwater, nwind, pool, device, engine, var):
@@ -135,6 +136,8 @@ def device_run(cfg, size, ticks, nwater, nwind, pool, device, engine, var):
         m._chk(m.L.smx_srand(m.h, 1000 + 7919 * (100 + var["stream"])))      # another rand() stream on the same terrain (never one of the controls')
     if var["generations"]:
         m.set_water_generations(var["generations"])
+    if var.get("stagger") is not None:
+        m.set_water_stagger(var["stagger"])                         # (0: consecutive generations, whatever the library's default)
     if var["strips"] > 1:
         m.set_batch_strips(var["strips"])
     tg = time.time()
@@ -179,7 +182,7 @@ def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="
     nctl = nproc - 1
     single = variants is None
     if single:
-        variants = [{"name": "default", "generations": int(water_batches or 0), "strips": 1, "stream": 0}]
+        variants = [{"name": "default", "generations": int(water_batches or 0), "stagger": None, "strips": 1, "stream": 0}]
     t0 = time.time()
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
         procs = []
@@ -238,10 +241,10 @@ def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="
         groups = {}
         for name, b in blocks.items():
             v = b["variant"]
-            groups.setdefault((v["generations"], v["strips"]), []).append(name)
+            groups.setdefault((v["generations"], v.get("stagger") or 0, v["strips"]), []).append(name)
         ens = {}
         allr = [ref] + ctl
-        for (g, s), names in groups.items():
+        for (g, e, s), names in groups.items():
             if len(names) < 2:
                 continue
             row = {}
@@ -253,7 +256,7 @@ def run(soil="rockgravelpebblessand.soil", size=4096, ticks=10, nctl=8, engine="
                 se = np.sqrt(a.var(ddof=1) / len(a) + r.var(ddof=1) / len(r))
                 row[k] = {"engine_mean": float(a.mean()), "engine_std": float(a.std(ddof=1)), "reference_mean": float(r.mean()), "reference_std": float(r.std(ddof=1)),
                           "rel": float(a.mean() / r.mean() - 1.0) if r.mean() else 0.0, "welch_t": float((a.mean() - r.mean()) / se) if se > 0 else 0.0}
-            ens[f"k{g}" + (f"s{s}" if s > 1 else "")] = {"device_streams": names, "reference_streams": len(allr), "figures": row}
+            ens[f"k{g}" + (f"e{e}" if e else "") + (f"s{s}" if s > 1 else "")] = {"device_streams": names, "reference_streams": len(allr), "figures": row}
         rep["ensembles"] = ens
     return rep
 
