@@ -236,8 +236,25 @@ struct BatchPolicy {
   template <int N> SMX_D void prefetch(const DevState&, const size_t (&)[N], const size_t (&)[N], Pre<N>&) {}
   template <int N> SMX_D bool acquire_log(const DevState&, const size_t (&)[N], const Pre<N>&, const Sec (&)[N]) { return true; }
   SMX_D void pre_write_node(const DevState&, uint32_t) {}
+  // Flag bytes (F_AIR, F_SAT of a column; the classification of the next grid pass reads them). On the device: fire-and-forget OR / AND on the byte's 32-bit word
+  // at the L2 (the plane is allocated in whole words; the other three bytes get the neutral element, so whoever owns those cells is not disturbed) -- a thread
+  // that first LOADS the byte to see whether it must change waits a memory round trip per call (35 water-onto-water transfers per active cell of the grid pass in
+  // the wet regime set F_SAT, profiles/r06_grid_tiles.md). ALL updates of this policy go this way: a plain load after an atomic could be served a stale line by
+  // the CU's vector cache. The host simulator keeps the byte-wide read-modify-write (its threads own their cells; a word-wide one would race with the neighbours').
+#ifdef SMX_HOSTSIM
   SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (!(v & f)) s.flags[c] = v | f; }
   SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) { const uint8_t v = s.flags[c]; if (v & f) s.flags[c] = v & (uint8_t)~f; }
+#else
+  SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) {
+    const uintptr_t a = (uintptr_t)(s.flags + c);
+    SMX_OR32_ASYNC(reinterpret_cast<uint32_t*>(a & ~(uintptr_t)3), (uint32_t)f << (8u * (uint32_t)(a & 3u)));
+  }
+  SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) {
+    const uintptr_t a = (uintptr_t)(s.flags + c);
+    SMX_AND32_ASYNC(reinterpret_cast<uint32_t*>(a & ~(uintptr_t)3), ~((uint32_t)f << (8u * (uint32_t)(a & 3u))));
+  }
+#endif
+  SMX_D void set_flag_async(const DevState& s, size_t c, uint8_t f) { set_flag(s, c, f); }
   // secpool::get (layermap.h:89-103) fails when live sections == capacity. Concurrent particles see the count as of
   // the kernel's start plus their own additions: exact while the pool has headroom (the host checks), approximate
   // in the last few sections before exhaustion -- stated in DESIGN.md.
@@ -643,7 +660,7 @@ SMX_D unsigned long long batch_grid_tile(Sim<P>& sim, int tx, int ty, unsigned l
       const size_t c = (size_t)x * s.dimy + y;
       if (!((s.active[c >> 6] >> (c & 63)) & 1ull)) continue;
       int depth = 0;
-      sim.seep(x, y);                                        // water.h:339
+      { SMX_SECT_T0(); sim.seep(x, y); SMX_SECT(9); }        // water.h:339
       sim.push_frame(st, depth, x, y, 3);                    // water.h:340
       sim.water_drive(dummy, false, false, st, depth);
       visited++;

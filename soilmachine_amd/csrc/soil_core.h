@@ -1178,14 +1178,14 @@ struct Sim {
       const Sec& B = cell(nx, ny);
       if (ab) return;
       const double whA = A.size, whB = B.size, fA = A.floor, fB = B.floor;   // 0 for empty columns (:194-214)
+      const uint32_t tyA = A.type, tyB = B.type;            // (with the sizes: ONE memory round trip for everything this neighbour's decision reads)
       const double diff = (fA + whA - fB - whB) * (double)s.scale / 80.0;
       if (diff == 0) { SMX_SECT(5); continue; }
-      const Sec& T = (diff > 0) ? A : B;
       const int tx = (diff > 0) ? ix : nx, ty = (diff > 0) ? iy : ny;
       const int bx = (diff > 0) ? nx : ix, by = (diff > 0) ? ny : iy;
-      if (T.type != AIR) { SMX_SECT(5); continue; }         // :229 (EMPTY != AIR; the reference cannot reach here with NULL)
+      if (((diff > 0) ? tyA : tyB) != AIR) { SMX_SECT(5); continue; }   // :229 (EMPTY != AIR; the reference cannot reach here with NULL)
       double transfer = fabs(diff) / 2.0;
-      const double wh = T.size;
+      const double wh = (diff > 0) ? whA : whB;
       transfer = (wh < transfer) ? wh : transfer;
       if (transfer <= 0) { SMX_SECT(5); continue; }
       if (transfer == wh) {                                 // :246-264 the whole water section leaves: nested particle
@@ -1220,12 +1220,32 @@ struct Sim {
         if (ab) return;
       } else {                                              // :266-276
         bool recascade = false;
-        if (remove(tx, ty, transfer) != 0) recascade = true;
-        if (transfer > 0) recascade = true;
-        add(bx, by, transfer, AIR);
-        Sec& R = cell(bx, by);
-        if (ab) return;
-        if (R.type != EMPTY) { R.sat = 1.0f; on_sat(bx, by); }
+        bool fast = false;
+        if constexpr (exclusive_access<P>::value) {
+          // Water onto water -- a lake levelling out, 35 of these per active cell of the grid pass in the wet regime (profiles/r06_grid_tiles.md): remove() only
+          // shrinks the higher column's top (0 < transfer < its size: nothing pops, :328-337), add() only elongates the other's (same type: pool.get + unget,
+          // :249-253; it needs a section to be available all the same), then sat = 1 (:273-276). The generic calls below do exactly this after loading both
+          // records again, three dependent round trips; here the sizes are in registers already. Same operations on the same operands: bit-identical.
+          if (((diff > 0) ? tyB : tyA) == AIR && !ab && pol.can_get(s)) {
+            Sec& Tw = s.cells[cidx(tx, ty)];
+            Sec& Rw = s.cells[cidx(bx, by)];
+            Tw.size = wh - transfer;                        // remove(): c.size -= h
+            Rw.size = ((diff > 0) ? whB : whA) + transfer;  // add() -> place(): c.size += size
+            n_mod += 2;
+            recascade = true;                               // (transfer > 0)
+            Rw.sat = 1.0f;
+            pol.set_flag_async(s, cidx(bx, by), F_SAT); if (grid_mode) mark_active(cidx(bx, by));   // on_sat()
+            fast = true;
+          }
+        }
+        if (!fast) {
+          if (remove(tx, ty, transfer) != 0) recascade = true;
+          if (transfer > 0) recascade = true;
+          add(bx, by, transfer, AIR);
+          Sec& R = cell(bx, by);
+          if (ab) return;
+          if (R.type != EMPTY) { R.sat = 1.0f; on_sat(bx, by); }
+        }
         SMX_SECT(6);
         if (recascade && f.spill > 0) {                     // :278-279 cascade(npos, --spill)
           const int sp = --f.spill;

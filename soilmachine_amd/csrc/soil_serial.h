@@ -25,6 +25,7 @@ struct SerialPolicy {
   SMX_D void set_flag(const DevState& s, size_t c, uint8_t f) {
     SMX_OR32_ASYNC(reinterpret_cast<uint32_t*>(s.flags + (c & ~(size_t)3)), (uint32_t)f << (8u * (uint32_t)(c & 3)));
   }
+  SMX_D void set_flag_async(const DevState& s, size_t c, uint8_t f) { set_flag(s, c, f); }
   SMX_D void clear_flag(const DevState& s, size_t c, uint8_t f) {
     SMX_AND32_ASYNC(reinterpret_cast<uint32_t*>(s.flags + (c & ~(size_t)3)), ~((uint32_t)f << (8u * (uint32_t)(c & 3))));
   }

@@ -823,7 +823,12 @@ __global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared
   const uint32_t k = relax_append(&g.count[0], act);
   if (act) g.pend[0][k] = entry;
 }
-__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n, uint32_t poll_naps) {
+// (experiments, SMX_FLOOD_PROF=1: where does a sweep go? [0..31] tiles by log2 of their sweep time in 100 MHz ticks, [32..63] their active cells, [72..103] the steps of
+//  their nested particles, [64] tiles, [65] ticks sweeping, [66] ticks waiting for tiles of earlier colours, [67] the longest sweep; printed by smx_destroy)
+__device__ unsigned long long g_tile_prof[104];
+static bool flood_prof_on() { static const bool on = [] { const char* e = getenv("SMX_FLOOD_PROF"); return e && atoi(e) != 0; }(); return on; }
+__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n, uint32_t poll_naps_prof) {
+  const uint32_t poll_naps = poll_naps_prof & 0x7FFFFFFFu; const bool prof = (poll_naps_prof >> 31) != 0u;
   SMX_LOAD_SOILS(sh)
   __shared__ uint32_t s_i;
   unsigned long long vis = 0, gns = 0;
@@ -837,6 +842,7 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
     if (threadIdx.x == 0) {
       const uint32_t entry = order[i], col = entry / nt, tile = entry - col * nt;
       const int tx = (int)(tile / (uint32_t)g.gty), ty = (int)(tile % (uint32_t)g.gty);
+      const unsigned long long tw0 = prof ? wall_clock64() : 0ull;
       for (int dx = -2; dx <= 2; dx++)                         // the tiles whose region overlaps this one's and whose colour comes first
         for (int dy = -2; dy <= 2; dy++) {
           const int ax = tx + dx, ay = ty + dy;
@@ -852,8 +858,17 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
       BatchPolicy pol(s, bs);
       Sim<BatchPolicy> sim(s, sh, pol);
       Frame st[MAX_FRAMES];
-      vis += batch_grid_tile(sim, tx, ty, g.keybase + (unsigned long long)entry, st);
-      sim.flush_counters(); gns += pol.a_nsteps; pol.finish(s);
+      const unsigned long long ts0 = prof ? wall_clock64() : 0ull;
+      const unsigned long long vt = batch_grid_tile(sim, tx, ty, g.keybase + (unsigned long long)entry, st);
+      vis += vt;
+      sim.flush_counters(); gns += pol.a_nsteps;
+      if (prof) {
+        const unsigned long long dt = wall_clock64() - ts0;
+        int b = 63 - __clzll((long long)(dt | 1ull)); if (b > 31) b = 31;
+        atomicAdd(&g_tile_prof[b], 1ull); atomicAdd(&g_tile_prof[32 + b], vt); atomicAdd(&g_tile_prof[72 + b], (unsigned long long)pol.a_nsteps);
+        atomicAdd(&g_tile_prof[64], 1ull); atomicAdd(&g_tile_prof[65], dt); atomicAdd(&g_tile_prof[66], ts0 - tw0); atomicMax(&g_tile_prof[67], dt);
+      }
+      pol.finish(s);
       __hip_atomic_store(&g.tdone[(size_t)(tx - g.txb) * g.gty + ty], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1372,13 +1387,22 @@ void smx_destroy(smx_ctx* ctx) {
       for (int b = 0; b < 32; b++) if (h[b]) fprintf(stderr, "   [%8.1f, %8.1f) %9llu  %7.1f\n", 0.01 * (double)(1ull << b), 0.01 * (double)(2ull << b), h[b], (double)h[32 + b] / (double)h[b]);
     }
   }
+  if (getenv("SMX_FLOOD_PROF") && atoi(getenv("SMX_FLOOD_PROF"))) {
+    unsigned long long h[104];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_prof), sizeof(h)) == hipSuccess && h[64]) {
+      fprintf(stderr, "[soilmx] k_grid_tiles_flow: %llu tiles swept, mean %.1f us, longest %.1f us; waiting for earlier colours: mean %.1f us per tile. sweep time bucket (us): tiles, active cells per tile, nested steps per tile, us per active cell\n",
+              h[64], 0.01 * (double)h[65] / (double)h[64], 0.01 * (double)h[67], 0.01 * (double)h[66] / (double)h[64]);
+      for (int b = 0; b < 32; b++) if (h[b]) fprintf(stderr, "   [%8.1f, %8.1f) %9llu  %6.1f  %7.1f  %7.1f\n", 0.01 * (double)(1ull << b), 0.01 * (double)(2ull << b), h[b], (double)h[32 + b] / (double)h[b],
+                                                     (double)h[72 + b] / (double)h[b], h[32 + b] ? 0.01 * 1.5 * (double)(1ull << b) * (double)h[b] / (double)h[32 + b] : 0.0);
+    }
+  }
 #ifdef SMX_PROF_FLOOD
   {
     unsigned long long h[32];
-    static const char* nm[9] = {"prelude: add sediment", "prelude: Particle::cascade", "prelude: add water", "prelude: seep", "push_frame (9 views, sort, mask)", "neighbour: nothing to move",
-                                "neighbour: partial transfer", "neighbour: nested particle spawned", "run_nested (a nested particle's steps)"};
+    static const char* nm[10] = {"prelude: add sediment", "prelude: Particle::cascade", "prelude: add water", "prelude: seep", "push_frame (9 views, sort, mask)", "neighbour: nothing to move",
+                                 "neighbour: partial transfer", "neighbour: nested particle spawned", "run_nested (a nested particle's steps)", "grid tile: seep of an active cell"};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sect), sizeof(h)) == hipSuccess)
-      for (int k = 0; k < 9; k++) if (h[2 * k + 1]) fprintf(stderr, "[soilmx] section %-40s %10llu x %7.2f us = %9.1f ms\n", nm[k], h[2 * k + 1], 0.01 * (double)h[2 * k] / (double)h[2 * k + 1], 1e-5 * (double)h[2 * k]);
+      for (int k = 0; k < 10; k++) if (h[2 * k + 1]) fprintf(stderr, "[soilmx] section %-40s %10llu x %7.2f us = %9.1f ms\n", nm[k], h[2 * k + 1], 0.01 * (double)h[2 * k] / (double)h[2 * k + 1], 1e-5 * (double)h[2 * k]);
   }
 #endif
   if (ctx->d_gbar && getenv("SMX_RELAX_MEGA_FLAGS") && (atoi(getenv("SMX_RELAX_MEGA_FLAGS")) & 2)) {   // (experiments: where an epoch of k_relax_epochs goes, workgroup 0's clock)
@@ -2381,7 +2405,7 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
     HIPCHK(hipMemsetAsync(ctx->d_tcount + 1, 0, 4, st));     // the cursor of the dataflow kernel
     static const unsigned flow_waves = [] { const char* e = getenv("SMX_GRID_FLOW_WAVES"); const int v = e ? atoi(e) : 2048; return (unsigned)(v < 1 ? 1 : v); }();
     static const uint32_t poll_naps = [] { const char* e = getenv("SMX_GRID_POLL_NAPS"); return e ? (uint32_t)atoi(e) : 2u; }();   // (x 3.4 us between two polls of a waiting tile)
-    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n, poll_naps); }
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n, poll_naps | (flood_prof_on() ? 0x80000000u : 0u)); }
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
     HIPCHK(hipStreamSynchronize(st));
     ctx->grid_passes++;

@@ -33,7 +33,10 @@ while done < a.warm + a.ticks:
     done += k
     row = dict(ticks_done=done, ms_tick=1e3 * dt / k, ms_water=tm["ms_water"] / k, ms_grid=tm["ms_grid"] / k, ms_wind=tm["ms_wind"] / k,
                nested=(c1["nested_particles"] - c0["nested_particles"]) / k, active=(c1["grid_active_cells"] - c0["grid_active_cells"]) / k,
-               steps_all=(c1["steps_water_all"] - c0["steps_water_all"]) / k, timed=done > a.warm)
+               steps_all=(c1["steps_water_all"] - c0["steps_water_all"]) / k, timed=done > a.warm,
+               floods=(c1["floods"] - c0["floods"]) / k, flood_nested_steps=(c1["flood_nested_steps"] - c0["flood_nested_steps"]) / k,
+               grid_nested_steps=(c1["grid_nested_steps"] - c0["grid_nested_steps"]) / k,
+               per_tick={kk: (vv / k) for kk, vv in tm.items() if kk.startswith(("ms_kernel", "launches_kernel", "epochs_kernel", "launches_floods"))})
     rows.append(row); print(json.dumps(row), flush=True)
 out = {"gpu": rows, "size": a.size, "soil": a.soil, "engine": a.engine, "nwater": nw, "digest": m.digest()}
 if a.cpu:
