@@ -375,7 +375,22 @@ __global__ void __launch_bounds__(64) k_relax_cascade(DevState s, BatchShared bs
 // next cell, waits until every listed cell of an earlier colour within two cells of it (3x3 blocks that overlap its own) is done, runs
 // Particle::cascade there (lane 0) and publishes it (bs.cstate). Same order between conflicting cells as nine launches with a barrier
 // each, so the same result -- without eight kernel boundaries of ~8 us in an epoch that lasts ~230 (2 300 epochs per tick: 19.8 % of it).
-__global__ void __launch_bounds__(64) k_relax_cascade_flow(DevState s, BatchShared bs, uint32_t epoch) {
+// Spin budget of the two dataflow kernels of the default schedule: a wavefront that polls a dependency longer than `budget` polls -- tens of seconds; the
+// dynamic cursor guarantees that every dependency belongs to a wavefront that is already running, so only a fault gets there -- raises bs.ctrl[BC_STALLED], every other
+// waiter sees the flag within 1 024 polls and stops waiting too, the kernel drains, and the host fails the call (-9) instead of hanging the stream.
+// SMX_SPIN_BUDGET overrides the number of polls (tests/test_gpu_relaxed.py sets 1 to see the error).
+static uint32_t spin_budget(uint32_t dflt) { static const long v = [] { const char* e = getenv("SMX_SPIN_BUDGET"); return e ? atol(e) : -1L; }(); return v >= 0 ? (uint32_t)v : dflt; }
+__device__ __forceinline__ bool spin_wait_while(const uint32_t* f, uint32_t busy, uint32_t* stalled, uint32_t budget, uint32_t sleep_a, uint32_t naps) {
+  uint32_t spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == busy) {
+    if (sleep_a == 2u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
+    for (uint32_t r = 0; r < naps; r++) __builtin_amdgcn_s_sleep(127);
+    if (++spins > budget) { __hip_atomic_store(stalled, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    if ((spins & 1023u) == 0u && __hip_atomic_load(stalled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+  }
+  return true;
+}
+__global__ void __launch_bounds__(64) k_relax_cascade_flow(DevState s, BatchShared bs, uint32_t epoch, uint32_t budget) {
   const uint32_t par = epoch & 1u;
   uint32_t cnt[9], total = 0;
 #pragma unroll
@@ -385,6 +400,7 @@ __global__ void __launch_bounds__(64) k_relax_cascade_flow(DevState s, BatchShar
   __shared__ uint32_t s_i;
   unsigned long long nc = 0, nt = 0;
   const uint32_t pending = 2u * bs.rtag;
+  bool live = true;
   while (true) {
     if (threadIdx.x == 0) s_i = atomicAdd(&bs.ctrl[BC_CASC_CURSOR], 1u);
     __syncthreads();
@@ -403,7 +419,7 @@ __global__ void __launch_bounds__(64) k_relax_cascade_flow(DevState s, BatchShar
         for (int yy = ya; yy <= yb; yy++) {
           if ((uint32_t)((xx % 3) * 3 + (yy % 3)) >= q) continue;            // (only cells of an earlier colour; the cell itself has colour q)
           uint32_t* f = &bs.cstate[(size_t)xx * (size_t)s.dimy + (size_t)yy];
-          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pending) __builtin_amdgcn_s_sleep(2);
+          if (live && !spin_wait_while(f, pending, &bs.ctrl[BC_STALLED], budget, 2u, 0u)) live = false;   // (stalled: the call fails; stop waiting, let the kernel drain)
         }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       BatchPolicy pol(s, bs);
@@ -827,12 +843,13 @@ __global__ void __launch_bounds__(256) k_grid_tiles_init(DevState s, BatchShared
 //  their nested particles, [64] tiles, [65] ticks sweeping, [66] ticks waiting for tiles of earlier colours, [67] the longest sweep; printed by smx_destroy)
 __device__ unsigned long long g_tile_prof[104];
 static bool flood_prof_on() { static const bool on = [] { const char* e = getenv("SMX_FLOOD_PROF"); return e && atoi(e) != 0; }(); return on; }
-__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n, uint32_t poll_naps_prof) {
+__global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared bs, GridTiles g, const uint32_t* __restrict__ order, uint32_t n, uint32_t poll_naps_prof, uint32_t budget) {
   const uint32_t poll_naps = poll_naps_prof & 0x7FFFFFFFu; const bool prof = (poll_naps_prof >> 31) != 0u;
   SMX_LOAD_SOILS(sh)
   __shared__ uint32_t s_i;
   unsigned long long vis = 0, gns = 0;
   const uint32_t nt = (uint32_t)g.gtx * (uint32_t)g.gty;
+  bool live = true;
   while (true) {
     if (threadIdx.x == 0) s_i = atomicAdd(&g.count[1], 1u);
     __syncthreads();
@@ -849,10 +866,8 @@ __global__ void __launch_bounds__(64) k_grid_tiles_flow(DevState s, BatchShared 
           if ((!dx && !dy) || ax < g.tx_lo || ax >= g.tx_hi || ax < g.txb || ax >= g.txe || ay < 0 || ay >= g.gty) continue;
           if ((uint32_t)((ax % 3) * 3 + (ay % 3)) >= col) continue;
           uint32_t* f = &g.tdone[(size_t)(ax - g.txb) * g.gty + ay];
-          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GT_PENDING) {   // (a tile takes milliseconds: its dependants poll every few microseconds -- rocprofv3 counted
-            __builtin_amdgcn_s_sleep(8);                                                                //  122 M polling loads per launch at one poll per 0.2 us, profiles/r06_pmc.json)
-            for (uint32_t r = 0; r < poll_naps; r++) __builtin_amdgcn_s_sleep(127);
-          }
+          // (a tile takes milliseconds: its dependants poll every few microseconds -- rocprofv3 counted 122 M polling loads per launch at one poll per 0.2 us, profiles/r06_pmc.json)
+          if (live && !spin_wait_while(f, GT_PENDING, &bs.ctrl[BC_STALLED], budget, 8u, poll_naps)) live = false;   // (stalled: the call fails; stop waiting, let the kernel drain)
         }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // what the tiles before wrote to the map is visible from here on
       BatchPolicy pol(s, bs);
@@ -2257,7 +2272,7 @@ static int run_chunk(smx_ctx* ctx, bool wind, uint32_t nlive_sched, uint32_t nli
         hipLaunchKernelGGL(k_relax_filter, dim3(ncb), dim3(64), 0, st, ctx->d, bs, epoch);
         static const unsigned casc_blocks = [] { const char* e = getenv("SMX_RELAX_CASC_BLOCKS"); return e ? (unsigned)atoi(e) : 64u; }();
         static const unsigned casc_flow = [] { const char* e = getenv("SMX_RELAX_CASC_FLOW"); return e ? (unsigned)atoi(e) : 1024u; }();   // 0: nine launches (round 4)
-        if (casc_flow && bs.cstate) hipLaunchKernelGGL(k_relax_cascade_flow, dim3(std::min(ncb, casc_flow)), dim3(64), 0, st, ctx->d, bs, epoch);
+        if (casc_flow && bs.cstate) hipLaunchKernelGGL(k_relax_cascade_flow, dim3(std::min(ncb, casc_flow)), dim3(64), 0, st, ctx->d, bs, epoch, spin_budget(1u << 24));
         else {
           const unsigned ncc = std::min(ncb, std::max(1u, casc_blocks));
           for (uint32_t col = 0; col < 9u; col++) hipLaunchKernelGGL(k_relax_cascade, dim3(ncc), dim3(64), 0, st, ctx->d, bs, epoch, col);
@@ -2348,7 +2363,7 @@ static int batch_generations(smx_ctx* ctx, bool wind, uint32_t n, uint32_t nkids
     if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
     if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
     if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
-    if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "relaxed schedule: the persistent epoch kernel ran out of its spin budget (a barrier or a dataflow wait was never released)"; return -9; }
+    if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "throughput schedule: a device-side wait ran out of its spin budget (a dataflow dependency or a barrier was never released)"; return -9; }
     if (nc > bs.child_cap) nc = bs.child_cap;
     if (wind) nc = 0;
     if (nc && sort_children(ctx, nc)) return -1;             // -> ctx->d_kids, on the device
@@ -2405,7 +2420,7 @@ static int grid_sweep(smx_ctx* ctx, int phase, int tx_lo, int tx_hi) {
     HIPCHK(hipMemsetAsync(ctx->d_tcount + 1, 0, 4, st));     // the cursor of the dataflow kernel
     static const unsigned flow_waves = [] { const char* e = getenv("SMX_GRID_FLOW_WAVES"); const int v = e ? atoi(e) : 2048; return (unsigned)(v < 1 ? 1 : v); }();
     static const uint32_t poll_naps = [] { const char* e = getenv("SMX_GRID_POLL_NAPS"); return e ? (uint32_t)atoi(e) : 2u; }();   // (x 3.4 us between two polls of a waiting tile)
-    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n, poll_naps | (flood_prof_on() ? 0x80000000u : 0u)); }
+    { PhaseTimer tk(ctx, 7); hipLaunchKernelGGL(k_grid_tiles_flow, dim3(std::min<unsigned>(n, flow_waves)), dim3(64), 0, st, ctx->d, bs, g, ctx->d_tpend[1], n, poll_naps | (flood_prof_on() ? 0x80000000u : 0u), spin_budget(1u << 22)); }
     hipLaunchKernelGGL(k_batch_merge_freed, dim3(1), dim3(256), 0, st, ctx->d, bs);
     HIPCHK(hipStreamSynchronize(st));
     ctx->grid_passes++;
@@ -2433,7 +2448,7 @@ static int batch_grid(smx_ctx* ctx) {
   if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
   if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
   if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
-  if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "relaxed schedule: the persistent epoch kernel ran out of its spin budget (a barrier or a dataflow wait was never released)"; return -9; }
+  if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "throughput schedule: a device-side wait ran out of its spin budget (a dataflow dependency or a barrier was never released)"; return -9; }
   if (nc > bs.child_cap) nc = bs.child_cap;
   if (nc && sort_children(ctx, nc)) return -1;
   HIPCHK(hipMemsetAsync(bs.ctrl + BC_NCHILD, 0, 8, st));
@@ -2538,7 +2553,7 @@ static int d_gen_end_impl(smx_ctx* ctx, void* children_out, uint32_t cap, uint32
   if (ctx->h_bctrl[BC_CHILD_LOST]) ctx->batch_children_lost += ctx->h_bctrl[BC_CHILD_LOST];
   if (ctx->h_bctrl[BC_FREED_LOST]) { ctx->err = "batched engine: freed-node list overflow (pool nodes leaked)"; return -6; }
   if (ctx->h_bctrl[BC_LIST_LOST]) { ctx->err = "relaxed schedule: flood / cascade list overflow (work was dropped)"; return -6; }
-  if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "relaxed schedule: the persistent epoch kernel ran out of its spin budget (a barrier or a dataflow wait was never released)"; return -9; }
+  if (ctx->h_bctrl[BC_STALLED]) { ctx->err = "throughput schedule: a device-side wait ran out of its spin budget (a dataflow dependency or a barrier was never released)"; return -9; }
   if (nc > bs.child_cap) nc = bs.child_cap;
   if (vec) { vec->resize(nc); children_out = vec->data(); cap = nc; }
   if (nc > cap) { ctx->err = "smx_d_gen_end: children buffer too small (call again with room for *n records)"; *n = nc; return -2; }

@@ -1,10 +1,11 @@
 """The RELAXED schedule (csrc/soil_relax.h, SMX_ENGINE_RELAXED) on the MI355X through the C-ABI: bit-identical to the same
 headers run by host threads (tests/hostsim) -- the schedule is deterministic, so device == host is an equality of full states --
 structurally sound at size, and inside the batched schedule's statistical envelope against the EXACT engine on the device."""
+import os
 import numpy as np
 import pytest
 
-from common import golden_snapshot, load_cfg
+from common import ROOT, golden_snapshot, load_cfg
 from hostsim_lib import HostSim
 from oracle_lib import Oracle
 from soilmachine_amd import capi
@@ -198,6 +199,28 @@ def test_fidelity_knobs_on_the_device_equal_host_threads():
             bad = compare(sm.map.snapshot(), h.snapshot())
             assert not bad, (t, bad)
     assert sm.map.counters()["nested_particles"] == h.counters()["nested_particles"] > 300
+
+
+def test_a_dataflow_wait_that_is_never_released_fails_the_call_instead_of_hanging_the_stream():
+    """the two dataflow kernels of the default schedule (cascade colours, grid tiles) poll their dependencies with a spin budget. With the budget
+    forced to one poll (SMX_SPIN_BUDGET=1, read once per process: a child process) some wavefront gives up, the kernel drains and the tick fails with -9
+    and a message that says so -- it does not hang, and the context stays failed."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        from common import load_cfg
+        from soilmachine_amd import capi
+        from soilmachine_amd.machine import SoilMachine, SoilmxError
+        sm = SoilMachine(load_cfg("default.soil"), 128, seed=0, nwater=250, nwind=0, dowind=False, engine=capi.ENGINE_RELAXED)
+        try:
+            sm.tick(40, sync=True)
+        except SoilmxError as e:
+            print("FAILED-AS-IT-SHOULD:", e); sys.exit(0 if "spin budget" in str(e) and "rc=-9" in str(e) else 3)
+        sys.exit(4)
+    """) % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMX_SPIN_BUDGET="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-400:], r.stderr[-400:])
 
 
 def test_launch_shapes_agree_at_size():
