@@ -2740,9 +2740,10 @@ int smx_reset_frequency(smx_ctx* ctx) {
   return 0;
 }
 int smx_tick(smx_ctx* ctx, int32_t nwater, int32_t nwind, int32_t dowater, int32_t dowind) {   // SoilMachine.cpp:283-329
-  if (dowater) { if (smx_tick_water(ctx, nwater)) return -1; if (smx_grid_pass(ctx)) return -1; }
-  if (dowind) { if (smx_tick_wind(ctx, nwind)) return -1; }
-  if (dowater) { if (smx_map_frequency(ctx)) return -1; if (smx_reset_frequency(ctx)) return -1; }
+  int rc = 0;                                                 // (a phase's own code comes through: -6 work dropped, -9 a device-side wait gave up, ...)
+  if (dowater) { if ((rc = smx_tick_water(ctx, nwater)) != 0) return rc; if ((rc = smx_grid_pass(ctx)) != 0) return rc; }
+  if (dowind) { if ((rc = smx_tick_wind(ctx, nwind)) != 0) return rc; }
+  if (dowater) { if ((rc = smx_map_frequency(ctx)) != 0) return rc; if ((rc = smx_reset_frequency(ctx)) != 0) return rc; }
   return 0;
 }
 int smx_sync(smx_ctx* ctx) {
