@@ -775,7 +775,7 @@ def main():
                            "this_run_1024": g_run, "headline_size_record": ({"file": hrec["file"], "variant": hrec["variant"], "gate": g_rec, "outliers": hrec["outliers"]} if hrec else None)}
         config = {"workload": workload, "engine": eng_name, "water_generations": r.get("water_generations") if throughput else None,
                   "water_stagger": r.get("water_stagger") if throughput else None,
-                  "parallelism": (f"{world} column strips of one map, halo exchange over RCCL" if strips else "replicas") if world > 1 else "single",
+                  "parallelism": (f"{world} column strips of one map, halo exchange over {'RCCL (ncclSend / ncclRecv on device buffers)' if dist.get_backend() == 'nccl' else 'host callbacks on torch.distributed ' + dist.get_backend()}" if strips else "replicas") if world > 1 else "single",
                   "parity": p2 if throughput else head["parity"]}
         detail = {
             "metric": "particle-steps/s", "value": total_steps / tmax, "unit": "particle-steps/s", "n_gpus": world,
