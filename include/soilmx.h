@@ -240,7 +240,10 @@ int smx_get_water_generations(smx_ctx* ctx, int32_t* k);   /* the value in force
 /* relaxed engine: STAGGERED generations. gap_epochs > 0: a water phase of n particles is ONE phase whose k batches of ceil(n / k) particles (by slot) are
  * born gap_epochs apart -- batch b takes its first step in epoch b * gap --; 0: k consecutive generations, each run to its end. A particle of batch b
  * finds what the batches before it did in the epochs they are ahead (the lakes their stopped particles made); the tick's epoch chain is (k - 1) * gap + one
- * generation long instead of k generations. Part of the schedule's definition (results depend on it); default: see SMX_WATER_STAGGER in csrc/soil_batch.h. */
+ * generation long instead of k generations. Part of the schedule's definition (results depend on it); default 0 (SMX_WATER_STAGGER in csrc/soil_batch.h).
+ * Measured against the same 33 reference streams (profiles/r06_alt1_stagger_sweep_..., r06_alt2_stagger_ensembles_p2_reference_4096.json): k = 16, gap = 140 takes
+ * 30 % off the water phase (64 M instead of 50 M particle-steps/s at the headline) and passes the parity gate with SEED 0's stream and under two strips, but two
+ * of three further device streams fail it and neighbouring (k, gap) points do too: a measured step away from the reference, hence an option. */
 int smx_set_water_stagger(smx_ctx* ctx, int32_t gap_epochs);
 int smx_get_water_stagger(smx_ctx* ctx, int32_t* gap_epochs);
 /* batched engine: column strips (DESIGN.md "Multi-GPU"). The schedule alternates INTERIOR chunks (a particle acts iff its
