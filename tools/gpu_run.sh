@@ -63,6 +63,7 @@ for s in "$@"; do
     bench2gloo) run bench2gloo 60 600 env SMX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --size ${BSIZE:-2048} ;;
     wet)       run wet 30 400 python tools/gpu_wet_exact.py --run ;;
     wetrelax)  run wetrelax 30 300 python tools/wet_regime.py --engine relaxed --warm 100 --ticks 50 --cpu 0 ;;
+    wetexact)  run wetexact 60 500 python tools/wet_regime.py --engine spec --warm 100 --ticks 20 --cpu 0 ;;
     wetprof)   run wetprof 30 300 env SMX_FLOOD_PROF=1 python tools/wet_regime.py --engine relaxed --warm 100 --ticks 20 --cpu 0; grep -A 40 "soilmx" $out/wetprof.err | cut -c1-400 ;;
     headprof)  run headprof 60 400 env SMX_FLOOD_PROF=1 python bench.py --gpus 1 --steps ${HSTEPS:-5} --warmup 5 --no-lines --no-cpu-baseline ${BENCH_EXTRA:-}; grep -A 40 "soilmx" $out/headprof.err | cut -c1-400 ;;
     bench)     run bench 60 400 python bench.py; cp $out/bench.log $out/bench.json 2>/dev/null ;;
