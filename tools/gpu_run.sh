@@ -3,8 +3,8 @@
 #   gpurun --timeout T -- 'tools/gpu_run.sh <tag> <budget-seconds> step [step ...]'
 # Every step has its own timeout, writes gpurun_out/<tag>/<step>.{log,err} and leaves a line in status.txt; steps that no
 # longer fit the budget are skipped and say so. Steps (most are thin wrappers around tools/*.py, tests/ and bench.py):
-#   smoke quick parity gpusuite relaxtest stripstest headrelax* headbatch ktrace tracerelax bench2gloo wet bench benchfull trace pmc pmcwet
-#   exact4096 envelope deep300 deep1000 deep10k
+#   smoke quick parity gpusuite relaxtest stripstest headrelax* headbatch ktrace tracerelax bench2gloo wet wetrelax wetexact wetprof headprof bench benchdrv
+#   benchfull drv drvk4 steady trace tracedrv pmc pmcwet p2ref p2multi p2var exact4096 envelope deep300 deep1000 deep10k shapes megasweep
 set -u
 tag=$1; budget=$2; shift 2
 root="${GRAFT_REPO_ROOT:-/root/repo}"
