@@ -15,7 +15,7 @@ soils = ["default.soil", "rockgravelpebblessand.soil", "painted.soil", "rocksand
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 120)
 KEYS = ["steps_water_top", "steps_water_all", "steps_wind", "nested_particles", "floods", "cascade_calls", "cascade_transfers", "wcascade_calls", "rand_calls"]
-n = floods = 0
+n = floods = nstg = 0
 while time.time() < t_end:
     soil = rng.choice(soils); cfg = load_cfg(soil)
     dx = rng.choice([5, 17, 33, 48, 64, 80, 97, 130, 224, 260, 352]); dy = rng.choice([4, 19, 32, 50, 64, 96])
@@ -32,7 +32,12 @@ while time.time() < t_end:
     h = HostSim(cfg, dx, dy, seed=seed); h.load(o.snapshot(), advance_rand=True)
     c0 = o.counters()
     wg = rng.choice([0, 0, 1, 2, 4])                          # smx_set_water_generations (0: the engines' own default, eight since round 6, through the tick entry points)
-    desc = (soil, dx, dy, seed, nw, nd, ticks, wet, strips, wg)
+    # staggered generations (smx_set_water_stagger, round 6) through the tick entry points: k batches born `gap` epochs apart inside ONE phase
+    stg = (rng.choice([2, 3, 4, 8, 16]), rng.choice([1, 4, 16, 50, 140])) if (wg == 0 and rng.random() < 0.5) else None
+    if stg:
+        L.hs_set_water_generations(stg[0]); L.hs_set_water_stagger(0, stg[1])
+        o.L.so_set_water_generations(o.h, stg[0]); o.L.so_set_water_stagger(o.h, stg[1])
+    desc = (soil, dx, dy, seed, nw, nd, ticks, wet, strips, wg, stg)
     L.hs_set_batch_strips(strips, 16, 48); o.L.so_batched_set_strips(o.h, strips, 16, 48)
     for t in range(ticks):
         nt, sh = rng.choice([1, 3, 5]), rng.randrange(5)
@@ -51,10 +56,10 @@ while time.time() < t_end:
             L.hs_freq(h.h); o.L.so_map_frequency(o.h); o.L.so_reset_frequency(o.h)
         bad = compare(h.snapshot(), o.snapshot())
         if bad: print("MISMATCH", desc, t, bad[:3]); sys.exit(1)
-    L.hs_set_batch_strips(1, 16, 48)
+    L.hs_set_batch_strips(1, 16, 48); L.hs_reset_water_schedule()
     ch, co = h.counters(), o.counters()
     co = {k: co[k] - (c0[k] if k != 'rand_calls' else 0) for k in KEYS}
     if any(ch[k] != co[k] for k in KEYS): print("COUNTERS", desc, {k: (ch[k], co[k]) for k in KEYS if ch[k] != co[k]}); sys.exit(1)
     if o.batched_stats()["guard_violations"]: print("GUARD", desc, o.batched_stats()); sys.exit(1)
-    n += 1; floods += co["floods"]
-print("ok", n, "cases,", floods, "floods")
+    n += 1; floods += co["floods"]; nstg += 1 if stg else 0
+print("ok", n, "cases,", nstg, "of them staggered,", floods, "floods")
