@@ -523,7 +523,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    strips = world > 1 and throughput
+    strips = (world > 1 or dist is not None) and throughput     # (dist with one rank: SMX_BENCH_FORCE_DIST=1, the multi-rank path on a single device)
     dimx = n
     ckpt = None
     if strips:
@@ -810,7 +810,9 @@ def main():
                 break
             except OSError:
                 detail_path = None
-        print(json.dumps(compact_line(detail, detail_path), default=float, separators=(",", ":"), allow_nan=False), flush=True)
+        final_line = json.dumps(compact_line(detail, detail_path), default=float, separators=(",", ":"), allow_nan=False)
+        if dist is None:
+            print(final_line, flush=True)
     for f_ in ("ckpt", "ckpt2"):
         try:
             if not strips and locals().get(f_):
@@ -820,6 +822,18 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        if locals().get("final_line"):
+            # Several ranks: RCCL writes a version banner ("RCCL version : ... Librccl path : ...") to the C library's stdout, which is a pipe here and therefore
+            # buffered until the process ends -- it would land AFTER a line printed earlier (seen on the MI355X box: profiles/r06_bench_multirank_path_one_rank_nccl.json).
+            # The contract is ONE JSON line, the last one: flush what C has buffered, print the line, and leave without giving exit handlers another turn at stdout.
+            import ctypes
+            sys.stdout.flush(); sys.stderr.flush()
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(final_line, flush=True)
+            os._exit(0)
 
 
 if __name__ == "__main__":

@@ -14,9 +14,11 @@ def env_rank():
 
 
 def init(world: int, local_rank: int, use_cuda: bool):
-    """Returns the torch.distributed module (initialised) or None for a single process."""
-    if world <= 1:
+    """Returns the torch.distributed module (initialised) or None for a single process. SMX_BENCH_FORCE_DIST=1 (a test switch) initialises the process
+    group for ONE rank too, so that bench.py's multi-rank path -- backend nccl, device tensors, the strip driver over RCCL -- can run on a single device."""
+    if world <= 1 and os.environ.get("SMX_BENCH_FORCE_DIST", "0") != "1":
         return None
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
     import torch
     import torch.distributed as dist
     if use_cuda:

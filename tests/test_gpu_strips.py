@@ -158,6 +158,53 @@ def test_rccl_transport_with_the_one_rank_a_single_device_allows():
     rk.detach()
 
 
+def _nccl_world_1(_i, port, path, out):
+    """bench.py --gpus N's control plane with the one rank a single device allows: torch.distributed backend "nccl" (= RCCL), TorchComm on DEVICE tensors
+    (unique-id all-gather, all-reduces), the library's own RCCL communicator beside torch's, the strip driver ticking through it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    comm = TorchComm(dist, torch.device("cuda", 0))
+    assert comm.allreduce_sum(41) == 41 and comm.allgather_bytes(b"seam") == [b"seam"] and comm.allgather_bytes(b"") == [b""]
+    assert list(comm.allreduce_min_u32(np.array([7, 3, 9], np.uint32))) == [7, 3, 9]
+    z = np.load(path)
+    cfg = load_cfg("rockgravelpebblessand.soil")
+    n = 256
+    s0 = Snapshot(n, n, cfg.SCALE, len(cfg.soils), int(z["rand_calls"]), 0, z["count"], z["type"], z["size"], z["floor"], z["sat"],
+                  z["wfreq"], z["wtrack"], z["windfreq"])
+    m = device_ctx(cfg, s0, n, capi.ENGINE_RELAXED)
+    rk = LibStripRank(m, comm, StripGeometry(n, 1), transport="rccl")
+    for _ in range(2):
+        rk.tick(500, 250, True, True)
+    rk.selfcheck(1000, 96_000, 17)
+    s = m.snapshot(); c = m.counters()
+    np.savez(out, count=s.count, type=s.type, size=s.size, floor=s.floor, sat=s.sat, wfreq=s.wfreq, wtrack=s.wtrack, windfreq=s.windfreq,
+             rand_calls=s.rand_calls, steps=c["steps_water_all"] + c["steps_wind"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_torch_distributed_nccl_control_plane_with_one_rank(tmp_path):
+    """What `bench.py --gpus N` under torchrun does before and around smx_strips_tick, on the one device the suite has: process group "nccl", TorchComm on device
+    tensors, the library's RCCL communicator next to torch's -- the result must be the single context's."""
+    import torch.multiprocessing as mp
+    n = 256
+    cfg, s0 = start_state("dry", n)
+    path, out = str(tmp_path / "s0.npz"), str(tmp_path / "out.npz")
+    np.savez(path, count=s0.count, type=s0.type, size=s0.size, floor=s0.floor, sat=s0.sat, wfreq=s0.wfreq, wtrack=s0.wtrack,
+             windfreq=s0.windfreq, rand_calls=s0.rand_calls)
+    mp.spawn(_nccl_world_1, args=(29500 + (os.getpid() % 2000), path, out), nprocs=1, join=True)
+    ref, cref = single_context(cfg, s0, n, 1, 500, 250, 2, capi.ENGINE_RELAXED)
+    z = np.load(out)
+    got = Snapshot(n, n, cfg.SCALE, len(cfg.soils), int(z["rand_calls"]), 0, z["count"], z["type"], z["size"], z["floor"], z["sat"], z["wfreq"], z["wtrack"], z["windfreq"])
+    assert not compare(got, ref)
+    assert int(z["steps"]) == cref["steps_water_all"] + cref["steps_wind"]
+
+
 def _worker(rank, world, port, path, nw, nd, ticks, n, soil, lib_driver=False, rccl=False, engine=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     here = os.path.dirname(os.path.abspath(__file__))
