@@ -5,6 +5,8 @@ import math
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
@@ -79,6 +81,26 @@ def test_the_headline_size_parity_record_is_read_from_its_file():
     four = bench.headline_parity_record(4)                        # round 5's default: in the record too, and outside
     assert four is not None and not four["gate"]["pass"] and "nested" in four["outliers"]
     assert bench.headline_parity_record(3) is None
+
+
+def test_the_parity_record_of_a_variant_is_the_newest_file_that_holds_it():
+    """`parity_gate` names the record it read: the default configuration's comes from the primary record, the staggered schedule's (k16e140, and its two-strip
+    form) from the records that measured it -- and a configuration nobody measured has none (bench.py then prints `unmeasured`, never `pass`)."""
+    import bench
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("p2_reference", os.path.join(ROOT, "tools", "p2_reference.py"))
+    p2 = importlib.util.module_from_spec(spec); spec.loader.exec_module(p2)
+    parse_variant = p2.parse_variant
+    a, b, c = bench.headline_parity_record(8), bench.headline_parity_record(16, 1, 140), bench.headline_parity_record(16, 2, 140)
+    assert a["file"] == "profiles/r06_p2_reference_4096.json" and a["variant"] == "k8" and a["gate"]["pass"] and a["outliers"] == []
+    assert b["variant"] == "k16e140" and "stagger" in b["file"] and b["gate"]["pass"]
+    assert c["variant"] == "k16e140s2" and c["gate"]["pass"]
+    assert bench.headline_parity_record(4)["gate"]["pass"] is False                       # round 5's default: measured, outside
+    assert bench.headline_parity_record(12, 1, 7) is None                                # nobody measured that
+    assert parse_variant("k16e140s2r3") == {"name": "k16e140s2r3", "generations": 16, "stagger": 140, "strips": 2, "stream": 3}
+    assert parse_variant("k8") == {"name": "k8", "generations": 8, "stagger": 0, "strips": 1, "stream": 0}
+    with pytest.raises(ValueError):
+        parse_variant("e140k16")
 
 
 def test_roofline_is_bytes_per_launch_over_the_average_bracketed_launch():
